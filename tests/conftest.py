@@ -1,0 +1,36 @@
+import os
+import sys
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import orc
+    return orc.load_oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    import orc
+    return orc.load_ref()
+
+
+def golden_cases():
+    gd = os.path.join(HERE, "golden")
+    return sorted(f[:-4] for f in os.listdir(gd) if f.startswith("g") and f.endswith(".npz"))
+
+
+@pytest.fixture(scope="session", params=golden_cases())
+def golden(request):
+    import numpy as np
+    return dict(np.load(os.path.join(HERE, "golden", request.param + ".npz")))
