@@ -1,0 +1,163 @@
+/*
+ * pnr_hip.h -- C ABI of the MI355X (gfx950) implementation of the PNR / Advantra hot path:
+ * multi-scale Frangi vesselness -> J8 -> per-layer seed extraction -> ZNCC seed scoring ->
+ * batched SMC particle tracing -> host replay of the trace bookkeeping.
+ *
+ * This is the drop-in boundary: plain C types, no exceptions, no torch types.  Every entry
+ * point names the reference interface it replaces (file:line relative to
+ * /root/reference/pnr-vaa3d/).  The reference has no FFI of its own (it is one C++ plugin);
+ * the call sites a maintainer re-points are Advantra_plugin.cpp:2488-2497 (Frangi),
+ * :2499-2512 (J8), :2549 (extractSeeds), :2561-2586 (seed filter/sort), :2658-2710 (trace loop).
+ * INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PNR_E_* code on failure;
+ *     pnr_last_error() returns a thread-local message for the last failure.
+ *   - volumes are uint8, x fastest: i = z*w*h + y*w + x (frangi.cpp:307).
+ *   - one pnr_ctx = one GPU = one host thread at a time (the reference is single-threaded).
+ *   - the library FAILS (PNR_E_NODEVICE) when no HIP device is present: there is no CPU path.
+ */
+#ifndef PNR_HIP_H
+#define PNR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNR_MAX_SIGMAS 8
+
+enum {
+    PNR_OK = 0,
+    PNR_E_ARG = -1,      /* invalid argument / parameter out of range */
+    PNR_E_NODEVICE = -2, /* no HIP device / device init failed */
+    PNR_E_HIP = -3,      /* HIP runtime error (message has the call) */
+    PNR_E_STATE = -4,    /* call order violated (e.g. seeds before frangi) */
+    PNR_E_NOMEM = -5
+};
+
+/* input_PARA (Advantra_plugin.cpp:88-103) + the hard-wired constants of :63-83 */
+typedef struct pnr_params {
+    float sig[PNR_MAX_SIGMAS]; /* neuritesigmas, ascending (parse_csv_string :1885-1897) */
+    int nsig;
+    int somaradius;  /* must be 0: soma path is out of scope */
+    float tolerance; /* MaximumFinder tolerance on J8 */
+    float znccth;
+    float kappa;
+    int step;
+    int ni; /* SMC iterations per trace direction */
+    int np; /* particles */
+    float zdist;
+    int nodepervol;
+    int vol; /* 1,5,9,11,19,27 */
+    float Kc;         /* 20   (:63) */
+    float neff_ratio; /* 0.8  (:64) */
+    float alpha;      /* 0.5  frangi_alfa (:66) */
+    float beta;       /* 0.5  frangi_beta (:67) */
+    float C;          /* 500  frangi_C    (:68) */
+    uint32_t rng_seed;    /* replaces srand(time(NULL)) of tracker.cpp:1003,1098 */
+    int max_trace_count;  /* 5000 MAX_TRACE_COUNT (:72) */
+} pnr_params;
+
+/* struct seed (seed.h:33-39) */
+typedef struct pnr_seed {
+    float x, y, z, vx, vy, vz, score, corr;
+} pnr_seed;
+
+/* struct X_est (tracker.h:19-23) */
+typedef struct pnr_xest {
+    float x, y, z, vx, vy, vz, sig, corr;
+} pnr_xest;
+
+/* class Node without its nbr vector (node.h:5-44); links are returned separately */
+typedef struct pnr_node {
+    float x, y, z, vx, vy, vz, corr, sig;
+    int32_t type; /* node.cpp:14-21: AXON=2, END=6, UNDEFINED=7 */
+} pnr_node;
+
+typedef struct pnr_ctx pnr_ctx;
+
+const char *pnr_last_error(void);
+void pnr_default_params(pnr_params *p); /* README.md:17 example + plugin constants */
+
+/* Validates like Advantra::dofunc (Advantra_plugin.cpp:317-326) and builds the Tracker tables
+ * (Tracker::Tracker, tracker.cpp:79-527) on the host, uploads them.  device = HIP ordinal. */
+int pnr_create(const pnr_params *p, int device, pnr_ctx **out);
+void pnr_destroy(pnr_ctx *ctx);
+
+/* Use an externally owned HIP stream (e.g. torch's current stream); NULL = ctx's own stream. */
+int pnr_set_stream(pnr_ctx *ctx, void *hip_stream);
+int pnr_synchronize(pnr_ctx *ctx);
+
+/* data1d + in_sz of reconstruction_func (Advantra_plugin.cpp:2241-2255).  Host pointer is
+ * borrowed for the call and copied to HBM; the _device variant borrows a device pointer that
+ * must stay valid until the next set_volume/destroy (no copy). */
+int pnr_set_volume(pnr_ctx *ctx, const uint8_t *img, int64_t w, int64_t h, int64_t l);
+int pnr_set_volume_device(pnr_ctx *ctx, const void *dev_img, int64_t w, int64_t h, int64_t l);
+
+/* Frangi::frangi3d (frangi.cpp:152-289; called at Advantra_plugin.cpp:2496) followed by the
+ * J -> J8 rule (:2499-2512).  Results stay in HBM; Jmin/Jmax are returned. */
+int pnr_frangi(pnr_ctx *ctx, float *Jmin, float *Jmax);
+/* Optional read-back of the Frangi outputs (any pointer may be NULL); N = w*h*l each. */
+int pnr_get_frangi(pnr_ctx *ctx, float *J, uint8_t *J8, uint8_t *Vx, uint8_t *Vy, uint8_t *Vz);
+/* Test taps: Frangi::imgaussian (frangi.cpp:647) and Frangi::hessian3d (:291) for one sigma.
+ * Host outputs, N floats each; Hessian order Dzz,Dyy,Dyz,Dxx,Dxy,Dxz (any may be NULL). */
+int pnr_gaussian(pnr_ctx *ctx, float sig, float *F);
+int pnr_hessian(pnr_ctx *ctx, float sig, float *Dzz, float *Dyy, float *Dyz, float *Dxx, float *Dxy, float *Dxz);
+/* Feed externally produced J8/V (host, N each) instead of pnr_frangi's: lets extractSeeds be
+ * tested in isolation exactly like SeedExtractor::extractSeeds(tolerance,J8,...,Vx,Vy,Vz). */
+int pnr_set_j8_v(pnr_ctx *ctx, const uint8_t *J8, const uint8_t *Vx, const uint8_t *Vy, const uint8_t *Vz);
+
+/* SeedExtractor::extractSeeds (seed.cpp:556-791; Advantra_plugin.cpp:2549).  Library-owned
+ * array, valid until the next call or pnr_destroy.  z-major, value-descending-per-layer order. */
+int pnr_extract_seeds(pnr_ctx *ctx, const pnr_seed **seeds, int64_t *n);
+/* Same, restricted to layers [z0, z1): the unit of multi-GPU Frangi/seed sharding. */
+int pnr_extract_seeds_range(pnr_ctx *ctx, int64_t z0, int64_t z1, const pnr_seed **seeds, int64_t *n);
+
+/* Tracker::znccBBB (tracker.cpp:1891-1964) for n (pos,dir) pairs: pos_dir = n x 6 floats. */
+int pnr_zncc_batch(pnr_ctx *ctx, const float *pos_dir, int64_t n, float *corr, float *sig);
+
+/* Seed filter + sort (Advantra_plugin.cpp:2561-2586): corr = znccBBB(seed); drop corr < znccth;
+ * sort by corr descending (ties: original order).  In place; *n_out <= n. */
+int pnr_score_filter_sort_seeds(pnr_ctx *ctx, pnr_seed *seeds, int64_t n, int64_t *n_out);
+
+/* Map-independent part of Tracker::trackPos / trackNeg (tracker.cpp:819-933 -> iter0New :1001,
+ * iterINew :1096) for n seeds x 2 directions, all on the GPU.  Trace j = 2*i + dir (dir 1 =
+ * negated seed direction).  Outputs (host, caller-allocated):
+ *   T    [2n]        successful iterations (= ti_limit of a run without density/soma maps)
+ *   stop [2n]        0 = ni reached, 1 = left the volume, 2 = centroid corr < znccth
+ *   xc   [2n*ni]     centroid estimates; rows 0..min(T,ni-1) are valid
+ * Optional debug taps for the first dbg_iters iterations of every trace (NULL to skip):
+ *   xfilt [2n*dbg_iters*np*9]  particles (x,y,z,vx,vy,vz,w,corr,sig) (struct X, tracker.h:13-17)
+ *   idxres[2n*dbg_iters*np]    resampled indices, neff [2n*dbg_iters] */
+int pnr_trace_batch(pnr_ctx *ctx, const pnr_seed *seeds, int64_t n, int32_t *T, int32_t *stop,
+                    pnr_xest *xc, int dbg_iters, float *xfilt, int32_t *idxres, float *neff);
+
+/* Host replay of the sequential bookkeeping (trackPos :848-931 + trace loop
+ * Advantra_plugin.cpp:2658-2710) over map-free traces, in seed order.  Pure host integer work.
+ *   nodes: capacity cap_nodes (node 0 = dummy, :2416-2419); links: pairs (a,b) meaning
+ *   a.nbr.push_back(b); b.nbr.push_back(a) in push order.  Returns counts through pointers. */
+int pnr_replay_traces(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds,
+                      int64_t n, const int32_t *T, const pnr_xest *xc, pnr_node *nodes,
+                      int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links,
+                      int64_t *n_links, int64_t *n_traces_used);
+
+/* Tracker tables for parity tests: name in {"p","u","w0","w0_cws","v","w","w_cws","rng",
+ * "model_vuw<s>","model_wgt<s>","model_avg","gauss_xy<s>","gauss_z<s>"}.  Copies up to cap
+ * 4-byte words into out; *n receives the element count. */
+int pnr_get_table(pnr_ctx *ctx, const char *name, void *out, int64_t cap, int64_t *n);
+
+/* Per-kernel-group device time (HIP events on the ctx stream) accumulated since the last reset:
+ * groups: "gauss","hessian_eigen","j8","seed_maxima","zncc","smc".  Enabled by set_profiling. */
+int pnr_set_profiling(pnr_ctx *ctx, int enable);
+int pnr_get_kernel_ms(pnr_ctx *ctx, const char *group, double *ms, int64_t *launches);
+int pnr_reset_kernel_ms(pnr_ctx *ctx);
+
+/* expf used for the particle likelihood exp(Kc*corr) (tracker.cpp:1029,1136), exposed so the
+ * tests can compare the device implementation with the host libm over many inputs. */
+int pnr_expf_batch(pnr_ctx *ctx, const float *x, int64_t n, float *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNR_HIP_H */

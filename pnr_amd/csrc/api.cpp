@@ -1,0 +1,513 @@
+// api.cpp -- the extern "C" boundary of libpnr_hip.so (include/pnr_hip.h): context life-cycle,
+// parameter validation (Advantra::dofunc, Advantra_plugin.cpp:317-326), uploads/read-backs, the
+// seed filter/sort (:2561-2586) and the host replay of the trace bookkeeping
+// (tracker.cpp:825-933 + Advantra_plugin.cpp:2602-2710).
+#include "ctx.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace pnr {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+} // namespace pnr
+
+using pnr::set_error;
+
+template <typename T>
+static int upload(T **dst, const std::vector<T> &src, hipStream_t s)
+{
+    PNR_HIP(hipMalloc(dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
+    if (!src.empty()) PNR_HIP(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return PNR_OK;
+}
+
+template <typename T>
+static int download(pnr_ctx *c, T *dst, const T *src, size_t n)
+{
+    if (!dst) return PNR_OK;
+    PNR_HIP(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    return PNR_OK;
+}
+
+extern "C" {
+
+const char *pnr_last_error(void) { return pnr::g_err; }
+
+void pnr_default_params(pnr_params *p)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->sig[0] = 2; p->sig[1] = 4; p->sig[2] = 6; // README.md:17
+    p->nsig = 3;
+    p->somaradius = 0;
+    p->tolerance = 5;
+    p->znccth = 0.3f;
+    p->kappa = 3;
+    p->step = 2;
+    p->ni = 200;
+    p->np = 20;
+    p->zdist = 2;
+    p->nodepervol = 4;
+    p->vol = 1;
+    p->Kc = 20.0f;
+    p->neff_ratio = 0.8f;
+    p->alpha = .5f;
+    p->beta = .5f;
+    p->C = 500;
+    p->rng_seed = 42;
+    p->max_trace_count = 5000;
+}
+
+static int validate(const pnr_params &p)
+{
+    PNR_REQUIRE(p.nsig >= 1 && p.nsig <= PNR_MAX_SIGMAS, PNR_E_ARG, "neuritesigmas: need 1..%d sigmas", PNR_MAX_SIGMAS);
+    for (int i = 0; i < p.nsig; i++) {
+        PNR_REQUIRE(p.sig[i] > 0 && p.sig[i] <= 20, PNR_E_ARG, "neuritesigmas out of range");
+        PNR_REQUIRE(i == 0 || p.sig[i] >= p.sig[i - 1], PNR_E_ARG, "neuritesigmas must be sorted ascending");
+    }
+    // messages follow Advantra_plugin.cpp:317-326
+    PNR_REQUIRE(p.somaradius >= 0, PNR_E_ARG, "somaradius out of range");
+    PNR_REQUIRE(p.somaradius == 0, PNR_E_ARG, "somaradius>0 (soma detection) is outside the accelerated path");
+    PNR_REQUIRE(p.tolerance >= 0, PNR_E_ARG, "tolerance out of range");
+    PNR_REQUIRE(p.znccth >= 0 && p.znccth <= 1, PNR_E_ARG, "znccth out of range");
+    PNR_REQUIRE(p.kappa >= 0 && p.kappa <= 5, PNR_E_ARG, "kappa out of range");
+    PNR_REQUIRE(p.step >= 1 && p.step <= 8, PNR_E_ARG, "step out of range");
+    PNR_REQUIRE(p.ni > 0, PNR_E_ARG, "ni out of range");
+    PNR_REQUIRE(p.np > 0 && p.np <= 4096, PNR_E_ARG, "np out of range");
+    PNR_REQUIRE(p.zdist >= 1, PNR_E_ARG, "zdist out of range");
+    PNR_REQUIRE(p.nodepervol > 2 && p.nodepervol <= 20, PNR_E_ARG, "nodepervol out of range");
+    PNR_REQUIRE(p.vol == 1 || p.vol == 5 || p.vol == 9 || p.vol == 11 || p.vol == 19 || p.vol == 27, PNR_E_ARG,
+                "vol can be 1,5,9,11,19,27");
+    return PNR_OK;
+}
+
+int pnr_create(const pnr_params *p, int device, pnr_ctx **out)
+{
+    PNR_REQUIRE(p && out, PNR_E_ARG, "null argument");
+    *out = nullptr;
+    int rc = validate(*p);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device: libpnr_hip has no CPU path (MI355X / gfx950 required)");
+        return PNR_E_NODEVICE;
+    }
+    PNR_REQUIRE(device >= 0 && device < ndev, PNR_E_NODEVICE, "device %d not present (%d devices)", device, ndev);
+    PNR_HIP(hipSetDevice(device));
+    pnr_ctx *c = new pnr_ctx();
+    c->prm = *p;
+    if (c->prm.max_trace_count <= 0) c->prm.max_trace_count = 5000;
+    c->device = device;
+    if (hipStreamCreate(&c->own_stream) != hipSuccess) {
+        delete c;
+        set_error("hipStreamCreate failed");
+        return PNR_E_HIP;
+    }
+    c->stream = c->own_stream;
+    (void)hipEventCreate(&c->ev0);
+    (void)hipEventCreate(&c->ev1);
+    pnr::build_tables(c->prm, c->tab);
+    const pnr::Tables &t = c->tab;
+    std::vector<float> sig(c->prm.sig, c->prm.sig + c->prm.nsig);
+    rc = upload(&c->d_p, t.p, c->stream);
+    if (!rc) rc = upload(&c->d_u, t.u, c->stream);
+    if (!rc) rc = upload(&c->d_w0, t.w0, c->stream);
+    if (!rc) rc = upload(&c->d_w0cws, t.w0_cws, c->stream);
+    if (!rc) rc = upload(&c->d_v, t.v, c->stream);
+    if (!rc) rc = upload(&c->d_w, t.w, c->stream);
+    if (!rc) rc = upload(&c->d_wcws, t.w_cws, c->stream);
+    if (!rc) rc = upload(&c->d_tmpl, t.tmpl, c->stream);
+    if (!rc) rc = upload(&c->d_corrc, t.corrc, c->stream);
+    if (!rc) rc = upload(&c->d_sig, sig, c->stream);
+    if (!rc) rc = upload(&c->d_M, t.M, c->stream);
+    if (!rc) rc = upload(&c->d_moff, t.moff, c->stream);
+    if (!rc) rc = upload(&c->d_rng, t.rng, c->stream);
+    if (!rc && hipMalloc(&c->d_minmax, 8) != hipSuccess) rc = PNR_E_HIP;
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = PNR_E_HIP;
+    if (rc) {
+        pnr_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return PNR_OK;
+}
+
+void pnr_destroy(pnr_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    hipFree(c->d_img_owned);
+    hipFree(c->d_tmpA); hipFree(c->d_tmpB); hipFree(c->d_J);
+    hipFree(c->d_Vx); hipFree(c->d_Vy); hipFree(c->d_Vz); hipFree(c->d_J8); hipFree(c->d_minmax);
+    hipFree(c->d_p); hipFree(c->d_u); hipFree(c->d_w0); hipFree(c->d_w0cws); hipFree(c->d_v); hipFree(c->d_w);
+    hipFree(c->d_wcws); hipFree(c->d_tmpl); hipFree(c->d_corrc); hipFree(c->d_sig); hipFree(c->d_M); hipFree(c->d_moff);
+    hipFree(c->d_rng);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int pnr_set_stream(pnr_ctx *c, void *s)
+{
+    PNR_REQUIRE(c, PNR_E_ARG, "null ctx");
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return PNR_OK;
+}
+
+int pnr_synchronize(pnr_ctx *c)
+{
+    PNR_REQUIRE(c, PNR_E_ARG, "null ctx");
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    return PNR_OK;
+}
+
+static int set_dims(pnr_ctx *c, int64_t w, int64_t h, int64_t l)
+{
+    PNR_REQUIRE(c, PNR_E_ARG, "null ctx");
+    // P == 1 would take the reference's frangi2d / 2-D tracker branch (Advantra_plugin.cpp:2496-2497): out of scope
+    PNR_REQUIRE(w >= 2 && h >= 2 && l >= 2, PNR_E_ARG, "volume must be at least 2x2x2 (2-D mode is not accelerated)");
+    PNR_REQUIRE(w <= 1 << 20 && h <= 1 << 20 && l <= 1 << 20 && w * h < (1LL << 31), PNR_E_ARG, "volume extent too large");
+    PNR_HIP(hipSetDevice(c->device));
+    c->w = w; c->h = h; c->l = l;
+    c->N = w * h * l;
+    c->have_j8 = false;
+    c->seeds.clear();
+    return PNR_OK;
+}
+
+int pnr_set_volume(pnr_ctx *c, const uint8_t *img, int64_t w, int64_t h, int64_t l)
+{
+    PNR_REQUIRE(img, PNR_E_ARG, "null image");
+    int rc = set_dims(c, w, h, l);
+    if (rc) return rc;
+    hipFree(c->d_img_owned);
+    c->d_img_owned = nullptr;
+    PNR_HIP(hipMalloc(&c->d_img_owned, (size_t)c->N));
+    PNR_HIP(hipMemcpyAsync(c->d_img_owned, img, (size_t)c->N, hipMemcpyHostToDevice, c->stream));
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    c->d_img = c->d_img_owned;
+    return PNR_OK;
+}
+
+int pnr_set_volume_device(pnr_ctx *c, const void *dev_img, int64_t w, int64_t h, int64_t l)
+{
+    PNR_REQUIRE(dev_img, PNR_E_ARG, "null image");
+    int rc = set_dims(c, w, h, l);
+    if (rc) return rc;
+    hipFree(c->d_img_owned);
+    c->d_img_owned = nullptr;
+    c->d_img = (const uint8_t *)dev_img;
+    return PNR_OK;
+}
+
+int pnr_frangi(pnr_ctx *c, float *Jmin, float *Jmax)
+{
+    PNR_REQUIRE(c && c->d_img, PNR_E_STATE, "pnr_frangi: no volume set");
+    PNR_HIP(hipSetDevice(c->device));
+    return pnr_frangi_run(c, Jmin, Jmax);
+}
+
+int pnr_get_frangi(pnr_ctx *c, float *J, uint8_t *J8, uint8_t *Vx, uint8_t *Vy, uint8_t *Vz)
+{
+    PNR_REQUIRE(c && c->have_j8 && c->d_J, PNR_E_STATE, "pnr_get_frangi: run pnr_frangi first");
+    const size_t n = (size_t)c->N;
+    int rc = download(c, J, c->d_J, n);
+    if (!rc) rc = download(c, J8, c->d_J8, n);
+    if (!rc) rc = download(c, Vx, c->d_Vx, n);
+    if (!rc) rc = download(c, Vy, c->d_Vy, n);
+    if (!rc) rc = download(c, Vz, c->d_Vz, n);
+    if (rc) return rc;
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    return PNR_OK;
+}
+
+int pnr_gaussian(pnr_ctx *c, float sig, float *F)
+{
+    PNR_REQUIRE(c && c->d_img && F, PNR_E_STATE, "pnr_gaussian: no volume set");
+    PNR_REQUIRE(sig > 0, PNR_E_ARG, "sigma must be positive");
+    int rc = pnr_ensure_frangi_buffers(c);
+    if (rc) return rc;
+    rc = pnr_gaussian_run(c, sig, c->d_tmpA);
+    if (rc) return rc;
+    PNR_HIP(hipMemcpy(F, c->d_tmpA, (size_t)c->N * 4, hipMemcpyDeviceToHost));
+    return PNR_OK;
+}
+
+int pnr_hessian(pnr_ctx *c, float sig, float *Dzz, float *Dyy, float *Dyz, float *Dxx, float *Dxy, float *Dxz)
+{
+    PNR_REQUIRE(c && c->d_img, PNR_E_STATE, "pnr_hessian: no volume set");
+    PNR_REQUIRE(sig > 0, PNR_E_ARG, "sigma must be positive");
+    int rc = pnr_ensure_frangi_buffers(c);
+    if (rc) return rc;
+    float *d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int k = 0; k < 6; k++)
+        if (hipMalloc(&d[k], (size_t)c->N * 4) != hipSuccess) {
+            for (int j = 0; j < k; j++) hipFree(d[j]);
+            set_error("hipMalloc failed for Hessian tap");
+            return PNR_E_NOMEM;
+        }
+    rc = pnr_hessian_run(c, sig, d);
+    float *hst[6] = {Dzz, Dyy, Dyz, Dxx, Dxy, Dxz};
+    for (int k = 0; k < 6 && !rc; k++)
+        if (hst[k] && hipMemcpy(hst[k], d[k], (size_t)c->N * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = PNR_E_HIP;
+    for (int k = 0; k < 6; k++) hipFree(d[k]);
+    c->have_j8 = false; // tmp buffers were reused
+    return rc;
+}
+
+int pnr_set_j8_v(pnr_ctx *c, const uint8_t *J8, const uint8_t *Vx, const uint8_t *Vy, const uint8_t *Vz)
+{
+    PNR_REQUIRE(c && c->N > 0, PNR_E_STATE, "pnr_set_j8_v: set a volume first (for the dimensions)");
+    PNR_REQUIRE(J8 && Vx && Vy && Vz, PNR_E_ARG, "null argument");
+    int rc = pnr_ensure_frangi_buffers(c);
+    if (rc) return rc;
+    const size_t n = (size_t)c->N;
+    PNR_HIP(hipMemcpyAsync(c->d_J8, J8, n, hipMemcpyHostToDevice, c->stream));
+    PNR_HIP(hipMemcpyAsync(c->d_Vx, Vx, n, hipMemcpyHostToDevice, c->stream));
+    PNR_HIP(hipMemcpyAsync(c->d_Vy, Vy, n, hipMemcpyHostToDevice, c->stream));
+    PNR_HIP(hipMemcpyAsync(c->d_Vz, Vz, n, hipMemcpyHostToDevice, c->stream));
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    c->have_j8 = true;
+    return PNR_OK;
+}
+
+int pnr_extract_seeds_range(pnr_ctx *c, int64_t z0, int64_t z1, const pnr_seed **seeds, int64_t *n)
+{
+    PNR_REQUIRE(c && seeds && n, PNR_E_ARG, "null argument");
+    PNR_HIP(hipSetDevice(c->device));
+    int rc = pnr_seeds_run(c, z0, z1);
+    if (rc) return rc;
+    *seeds = c->seeds.data();
+    *n = (int64_t)c->seeds.size();
+    return PNR_OK;
+}
+
+int pnr_extract_seeds(pnr_ctx *c, const pnr_seed **seeds, int64_t *n)
+{
+    PNR_REQUIRE(c, PNR_E_ARG, "null ctx");
+    return pnr_extract_seeds_range(c, 0, c->l, seeds, n);
+}
+
+int pnr_zncc_batch(pnr_ctx *c, const float *pos_dir, int64_t n, float *corr, float *sig)
+{
+    PNR_REQUIRE(c && (n == 0 || (pos_dir && corr)), PNR_E_ARG, "null argument");
+    PNR_REQUIRE(n >= 0, PNR_E_ARG, "negative count");
+    PNR_HIP(hipSetDevice(c->device));
+    return pnr_zncc_run(c, pos_dir, n, corr, sig);
+}
+
+int pnr_score_filter_sort_seeds(pnr_ctx *c, pnr_seed *seeds, int64_t n, int64_t *n_out)
+{
+    PNR_REQUIRE(c && n_out && (n == 0 || seeds), PNR_E_ARG, "null argument");
+    *n_out = 0;
+    if (n == 0) return PNR_OK;
+    std::vector<float> pd((size_t)n * 6), corr((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        float *q = &pd[(size_t)i * 6];
+        q[0] = seeds[i].x; q[1] = seeds[i].y; q[2] = seeds[i].z;
+        q[3] = seeds[i].vx; q[4] = seeds[i].vy; q[5] = seeds[i].vz;
+    }
+    int rc = pnr_zncc_batch(c, pd.data(), n, corr.data(), nullptr);
+    if (rc) return rc;
+    std::vector<pnr_seed> kept;
+    for (int64_t i = 0; i < n; i++) {
+        seeds[i].corr = corr[i];
+        if (!(seeds[i].corr < c->prm.znccth)) kept.push_back(seeds[i]); // erase if corr < znccth (:2571)
+    }
+    std::vector<int64_t> order(kept.size());
+    std::iota(order.begin(), order.end(), 0);
+    // std::sort with CompareSeedCorr is unstable in the reference; ties are broken by original index here
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return kept[a].corr > kept[b].corr; });
+    for (size_t i = 0; i < order.size(); i++) seeds[i] = kept[order[i]];
+    *n_out = (int64_t)kept.size();
+    return PNR_OK;
+}
+
+int pnr_trace_batch(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T, int32_t *stop, pnr_xest *xc, int dbg_iters,
+                    float *xfilt, int32_t *idxres, float *neff)
+{
+    PNR_REQUIRE(c && (n == 0 || (seeds && T && stop && xc)), PNR_E_ARG, "null argument");
+    PNR_REQUIRE(n >= 0, PNR_E_ARG, "negative count");
+    PNR_HIP(hipSetDevice(c->device));
+    return pnr_trace_run(c, seeds, n, T, stop, xc, dbg_iters, xfilt, idxres, neff);
+}
+
+// ---- host replay ------------------------------------------------------------------------
+static inline int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// neighbour voxels of the density pattern `vol` (Advantra_plugin.cpp:2609-2648), computed on the
+// fly instead of the reference's 8 B/voxel pointer table.  The reference clamps y+-1 with N-1
+// (the x extent) in the vol>=19 rows (:2632-2637); reproduced literally.
+static int density_neighbours(int64_t i, int N, int M, int P, int vol, int64_t *out)
+{
+    if (vol == 1) return 0;
+    const int64_t NM = (int64_t)N * M;
+    const int x = (int)(i % N), z = (int)(i / NM), y = (int)(i / N - (int64_t)z * M);
+    auto at = [&](int zz, int yy, int xx) { return (int64_t)zz * NM + (int64_t)yy * N + xx; };
+    const int xm = clampi(x - 1, 0, N - 1), xp = clampi(x + 1, 0, N - 1);
+    const int ym = clampi(y - 1, 0, M - 1), yp = clampi(y + 1, 0, M - 1);
+    const int zm = clampi(z - 1, 0, P - 1), zp = clampi(z + 1, 0, P - 1);
+    const int ymN = clampi(y - 1, 0, N - 1), ypN = clampi(y + 1, 0, N - 1);
+    int n = 0;
+    out[n++] = at(z, y, xm); out[n++] = at(z, y, xp); out[n++] = at(z, ym, x); out[n++] = at(z, yp, x);
+    if (vol >= 9) { out[n++] = at(z, ym, xm); out[n++] = at(z, ym, xp); out[n++] = at(z, yp, xm); out[n++] = at(z, yp, xp); }
+    if (vol >= 11) { out[n++] = at(zm, y, x); out[n++] = at(zp, y, x); }
+    if (vol >= 19) {
+        out[n++] = at(zm, y, xm); out[n++] = at(zm, y, xp); out[n++] = at(zm, ymN, x); out[n++] = at(zm, ypN, x);
+        out[n++] = at(zp, y, xm); out[n++] = at(zp, y, xp); out[n++] = at(zp, ymN, x); out[n++] = at(zp, ypN, x);
+    }
+    if (vol >= 27) {
+        out[n++] = at(zm, ym, xm); out[n++] = at(zm, ym, xp); out[n++] = at(zm, yp, xm); out[n++] = at(zm, yp, xp);
+        out[n++] = at(zp, ym, xm); out[n++] = at(zp, ym, xp); out[n++] = at(zp, yp, xm); out[n++] = at(zp, yp, xp);
+    }
+    return n;
+}
+
+int pnr_replay_traces(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n,
+                      const int32_t *T, const pnr_xest *xc, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes,
+                      int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used)
+{
+    PNR_REQUIRE(p && n_nodes && n_links && (n == 0 || (seeds && T && xc)), PNR_E_ARG, "null argument");
+    PNR_REQUIRE(w > 0 && h > 0 && l > 0, PNR_E_ARG, "bad dimensions");
+    const int64_t size = w * h * l;
+    const int ni = p->ni, W = (int)w, H = (int)h;
+    std::vector<uint8_t> den((size_t)size, 0); // npervol_map
+    std::vector<int32_t> nidx((size_t)size, 0); // nidx_map
+    int64_t nn = 0, nl = 0;
+    auto voxel = [&](float x, float y, float z) {
+        return (int64_t)(int)std::round(z) * W * H + (int64_t)(int)std::round(y) * W + (int)std::round(x);
+    };
+    auto link = [&](int64_t a, int64_t b) {
+        if (links && nl < cap_links) { links[2 * nl] = (int32_t)a; links[2 * nl + 1] = (int32_t)b; }
+        nl++;
+    };
+    if (nodes && cap_nodes > 0) { // n0[0]: dummy Node() (node.cpp:43-54)
+        std::memset(&nodes[0], 0, sizeof(pnr_node));
+        nodes[0].corr = -FLT_MAX;
+        nodes[0].type = 7;
+    }
+    nn = 1;
+    int trace_count = 0;
+    const int maxtr = p->max_trace_count > 0 ? p->max_trace_count : 5000;
+    for (int64_t s = 0; s < n; s++) {
+        if (!((int)den[(size_t)voxel(seeds[s].x, seeds[s].y, seeds[s].z)] < p->nodepervol)) continue; // :2669-2670
+        trace_count++;
+        for (int dir = 0; dir < 2; dir++) {
+            const int64_t j = 2 * s + dir;
+            const pnr_xest *X = xc + j * ni;
+            int ti_limit = ni;
+            for (int i = 0; i < ni; i++) {
+                if (i >= T[j]) { ti_limit = i; break; } // iter*New returned false
+                const pnr_xest &e = X[i];
+                const int64_t crd = voxel(e.x, e.y, e.z);
+                if ((int)den[(size_t)crd] >= p->nodepervol) { // density limit: link to the node that owns the voxel
+                    if (i > 0) link(nidx[(size_t)crd], nn - 1);
+                    ti_limit = i;
+                    break;
+                }
+                if (nodes && nn < cap_nodes)
+                    nodes[nn] = pnr_node{e.x, e.y, e.z, e.vx, e.vy, e.vz, e.corr, e.sig, (i == 0) ? 7 : 2};
+                nn++;
+                den[(size_t)crd] = (uint8_t)((int)den[(size_t)crd] + 1);
+                nidx[(size_t)crd] = (int32_t)(nn - 1);
+                if (p->vol > 1) {
+                    int64_t nb[26];
+                    const int cnt = density_neighbours(crd, (int)w, (int)h, (int)l, p->vol, nb);
+                    for (int q = 0; q < cnt; q++) {
+                        den[(size_t)nb[q]] = (uint8_t)((int)den[(size_t)nb[q]] + 1);
+                        nidx[(size_t)nb[q]] = (int32_t)(nn - 1);
+                    }
+                }
+                if (i > 0) link(nn - 1, nn - 2);
+            }
+            if (ti_limit > 1 && nodes && nn - 1 < cap_nodes) nodes[nn - 1].type = 6; // END (tracker.cpp:930-931)
+        }
+        if (trace_count > maxtr) break; // :2702
+    }
+    *n_nodes = nn;
+    *n_links = nl;
+    if (n_traces_used) *n_traces_used = trace_count;
+    return PNR_OK;
+}
+
+int pnr_get_table(pnr_ctx *c, const char *name, void *out, int64_t cap, int64_t *n)
+{
+    PNR_REQUIRE(c && name && n, PNR_E_ARG, "null argument");
+    const pnr::Tables &t = c->tab;
+    const void *src = nullptr;
+    size_t cnt = 0;
+    std::string nm(name);
+    auto fv = [&](const std::vector<float> &v) { src = v.data(); cnt = v.size(); };
+    std::vector<float> tmp;
+    if (nm == "p") fv(t.p);
+    else if (nm == "u") fv(t.u);
+    else if (nm == "w0") fv(t.w0);
+    else if (nm == "w0_cws") fv(t.w0_cws);
+    else if (nm == "v") fv(t.v);
+    else if (nm == "w") fv(t.w);
+    else if (nm == "w_cws") fv(t.w_cws);
+    else if (nm == "model_avg") fv(t.mavg);
+    else if (nm == "rng") { src = t.rng.data(); cnt = t.rng.size(); }
+    else if (nm.rfind("model_vuw", 0) == 0 || nm.rfind("model_wgt", 0) == 0 || nm.rfind("gauss_xy", 0) == 0 ||
+             nm.rfind("gauss_z", 0) == 0) {
+        const size_t pre = (nm[0] == 'm') ? 9 : (nm[6] == 'x' ? 8 : 7);
+        const int s = std::atoi(nm.c_str() + pre);
+        PNR_REQUIRE(s >= 0 && s < t.nsig, PNR_E_ARG, "sigma index out of range in '%s'", name);
+        if (nm[0] == 'g') fv(nm[6] == 'x' ? t.gxy[s] : t.gz[s]);
+        else if (nm[6] == 'w') { src = t.mwgt.data() + t.moff[s]; cnt = (size_t)t.M[s]; }
+        else {
+            tmp.resize((size_t)t.M[s] * 3);
+            for (int k = 0; k < t.M[s]; k++)
+                for (int q = 0; q < 3; q++) tmp[(size_t)k * 3 + q] = t.tmpl[((size_t)t.moff[s] + k) * 4 + q];
+            fv(tmp);
+        }
+    } else {
+        set_error("unknown table '%s'", name);
+        return PNR_E_ARG;
+    }
+    *n = (int64_t)cnt;
+    if (out && cap > 0) std::memcpy(out, src, std::min<size_t>(cnt, (size_t)cap) * 4);
+    return PNR_OK;
+}
+
+int pnr_set_profiling(pnr_ctx *c, int enable)
+{
+    PNR_REQUIRE(c, PNR_E_ARG, "null ctx");
+    c->profiling = enable != 0;
+    return PNR_OK;
+}
+
+int pnr_get_kernel_ms(pnr_ctx *c, const char *group, double *ms, int64_t *launches)
+{
+    PNR_REQUIRE(c && group && ms, PNR_E_ARG, "null argument");
+    auto it = c->timers.find(group);
+    *ms = (it == c->timers.end()) ? 0.0 : it->second.ms;
+    if (launches) *launches = (it == c->timers.end()) ? 0 : it->second.launches;
+    return PNR_OK;
+}
+
+int pnr_reset_kernel_ms(pnr_ctx *c)
+{
+    PNR_REQUIRE(c, PNR_E_ARG, "null ctx");
+    c->timers.clear();
+    return PNR_OK;
+}
+
+int pnr_expf_batch(pnr_ctx *c, const float *x, int64_t n, float *y)
+{
+    PNR_REQUIRE(c && (n == 0 || (x && y)), PNR_E_ARG, "null argument");
+    return pnr_expf_run(c, x, n, y);
+}
+
+} // extern "C"

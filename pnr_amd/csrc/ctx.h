@@ -1,0 +1,115 @@
+// ctx.h -- internal state of one pnr_ctx (one GPU) and small helpers shared by the
+// translation units of libpnr_hip.so.  Not part of the C ABI.
+#pragma once
+#include "../../include/pnr_hip.h"
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace pnr {
+
+void set_error(const char *fmt, ...);
+
+#define PNR_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            pnr::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PNR_E_HIP;                                                                \
+        }                                                                                    \
+    } while (0)
+
+#define PNR_REQUIRE(cond, code, ...)      \
+    do {                                  \
+        if (!(cond)) {                    \
+            pnr::set_error(__VA_ARGS__);  \
+            return (code);                \
+        }                                 \
+    } while (0)
+
+// ---- host tables (tables.cpp): Tracker::Tracker (tracker.cpp:79-527) + Gaussian taps ----
+struct Tables {
+    int sz = 0, ndir = 50, nsig = 0;
+    std::vector<float> p, u, d0, w0, w0_cws, v, w, w_cws; // p,u: sz x 3; w,w_cws: ndir x sz
+    std::vector<int> M;                                   // samples per sigma
+    std::vector<int> moff;                                // prefix offsets into tmpl
+    std::vector<float> tmpl;                              // sum(M) x 4 : (v_off, u_off, w_off, wgt - avg)
+    std::vector<float> mwgt;                              // sum(M)     : raw template weights
+    std::vector<float> mavg, corrc;                       // per sigma
+    std::vector<uint32_t> rng;                            // np + 1 glibc rand() draws
+    std::vector<std::vector<float>> gxy, gz;              // Gaussian taps per sigma
+};
+void build_tables(const pnr_params &p, Tables &t);
+void glibc_rand_stream(uint32_t seed, int n, uint32_t *out);
+int gaussian_taps(float sig, std::vector<float> &g); // returns radius L
+
+struct KernelTimer {
+    double ms = 0;
+    int64_t launches = 0;
+};
+
+} // namespace pnr
+
+struct pnr_ctx {
+    pnr_params prm;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    pnr::Tables tab;
+
+    // volume
+    int64_t w = 0, h = 0, l = 0, N = 0;
+    const uint8_t *d_img = nullptr; // device
+    uint8_t *d_img_owned = nullptr;
+
+    // Frangi state (HBM)
+    float *d_tmpA = nullptr, *d_tmpB = nullptr, *d_J = nullptr;
+    uint8_t *d_Vx = nullptr, *d_Vy = nullptr, *d_Vz = nullptr, *d_J8 = nullptr;
+    unsigned int *d_minmax = nullptr; // [0]=min bits, [1]=max bits
+    int64_t frangi_cap = 0;           // voxels the buffers above were sized for
+    bool have_j8 = false;
+    float Jmin = 0, Jmax = 0;
+
+    // device tables
+    float *d_p = nullptr, *d_u = nullptr, *d_w0 = nullptr, *d_w0cws = nullptr, *d_v = nullptr, *d_w = nullptr,
+          *d_wcws = nullptr, *d_tmpl = nullptr, *d_corrc = nullptr, *d_sig = nullptr;
+    int *d_M = nullptr, *d_moff = nullptr;
+    uint32_t *d_rng = nullptr;
+
+    // seeds
+    std::vector<pnr_seed> seeds;
+
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<std::string, pnr::KernelTimer> timers;
+
+    void tic()
+    {
+        if (profiling) (void)hipEventRecord(ev0, stream);
+    }
+    void toc(const char *group, int launches = 1)
+    {
+        if (!profiling) return;
+        (void)hipEventRecord(ev1, stream);
+        (void)hipEventSynchronize(ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ev0, ev1);
+        auto &t = timers[group];
+        t.ms += ms;
+        t.launches += launches;
+    }
+};
+
+// stage entry points implemented in the .hip files
+int pnr_frangi_run(pnr_ctx *c, float *Jmin, float *Jmax);
+int pnr_gaussian_run(pnr_ctx *c, float sig, float *d_out /*device N floats*/);
+int pnr_hessian_run(pnr_ctx *c, float sig, float *const d_out[6]);
+int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1);
+int pnr_zncc_run(pnr_ctx *c, const float *h_pos_dir, int64_t n, float *h_corr, float *h_sig);
+int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T, int32_t *stop, pnr_xest *xc,
+                  int dbg_iters, float *xfilt, int32_t *idxres, float *neff);
+int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y);
+int pnr_ensure_frangi_buffers(pnr_ctx *c);

@@ -1,0 +1,607 @@
+// frangi.hip -- multi-scale 3-D Frangi vesselness on gfx950 (wave64), hand-written HIP.
+//
+// Replaces Frangi::frangi3d / hessian3d / imgaussian / eigen_decomposition
+// (frangi.cpp:152-289, :291-390, :647-784, :1269-1493) and the J -> J8 rule
+// (Advantra_plugin.cpp:2499-2512).
+//
+// Per scale sigma:
+//   K1 gauss_x_u8      u8  -> f32   row staged in LDS, taps ascending, mul then add (no FMA)
+//   K2 gauss_axis (y)  f32 -> f32   64(x) x 32(y) tile + halo in LDS, x stays the coalesced axis
+//   K3 gauss_axis (z)  f32 -> f32   same kernel, axis stride w*h, sigma/zdist taps
+//   K4 hessian_eigen   radius-2 stencil of first differences applied twice (border rules of
+//                      the reference), fp64 Householder+QL eigen-solver for the 3x3 symmetric
+//                      Hessian, vesselness, max over scales into J / Vx,Vy,Vz, block-reduced
+//                      min/max -> 2 atomics per block
+//   K5 j8              J -> u8
+// Build: hipcc --offload-arch=gfx950 -ffp-contract=off : every f32/f64 operation is the IEEE
+// operation the reference's scalar loop performs, in the same order, so Gaussian / Hessian /
+// eigenvectors are bit-identical; only exp() (fp64, ocml vs glibc, <1 ulp each) can differ.
+#include "ctx.h"
+#include <cfloat>
+#include <cmath>
+
+namespace {
+
+typedef long long i64;
+
+// ----------------------------------------------------------------------------------------
+// K1: Gaussian along x, u8 -> f32 (frangi.cpp:683-714, clamp-to-edge)
+// ----------------------------------------------------------------------------------------
+constexpr int GX_BLOCK = 256;
+constexpr int MAX_L = 64; // ceil(3*sigma) <= 64  (sigma <= 21)
+
+__global__ __launch_bounds__(GX_BLOCK) void gauss_x_u8(const uint8_t *__restrict__ img, float *__restrict__ out, int w,
+                                                        i64 rows, int tiles_x, const float *__restrict__ taps, int L)
+{
+    __shared__ float s_in[GX_BLOCK + 2 * MAX_L];
+    __shared__ float s_tap[2 * MAX_L + 1];
+    const i64 b = blockIdx.x;
+    const i64 row = b / tiles_x;
+    const int x0 = (int)(b % tiles_x) * GX_BLOCK;
+    const uint8_t *src = img + row * w;
+    const int span = GX_BLOCK + 2 * L;
+    for (int t = threadIdx.x; t < span; t += GX_BLOCK) {
+        int x = x0 - L + t;
+        x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+        s_in[t] = (float)src[x];
+    }
+    for (int t = threadIdx.x; t < 2 * L + 1; t += GX_BLOCK) s_tap[t] = taps[t];
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= w) return;
+    float acc = 0.f;
+    for (int k = 0; k <= 2 * L; ++k) acc = acc + s_in[threadIdx.x + k] * s_tap[k];
+    out[row * w + x] = acc;
+}
+
+// ----------------------------------------------------------------------------------------
+// K2/K3: Gaussian along a strided axis (y or z), f32 -> f32 (frangi.cpp:717-782)
+// tile: 64 consecutive x (one wave-row, 256 B coalesced) x TA outputs along the axis
+// ----------------------------------------------------------------------------------------
+constexpr int TA = 32;
+
+__global__ __launch_bounds__(256) void gauss_axis(const float *__restrict__ in, float *__restrict__ out, int w, int n_axis,
+                                                   i64 axis_stride, int n_other, i64 other_stride, int tiles_x,
+                                                   int tiles_a, const float *__restrict__ taps, int L)
+{
+    extern __shared__ float smem[]; // [(TA + 2L)][64] then taps
+    float *s_in = smem;
+    float *s_tap = smem + (TA + 2 * L) * 64;
+    i64 b = blockIdx.x;
+    const int tx_tile = (int)(b % tiles_x);
+    b /= tiles_x;
+    const int ta_tile = (int)(b % tiles_a);
+    const int o = (int)(b / tiles_a);
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6; // 4 row groups
+    const int x = tx_tile * 64 + lane;
+    const int a0 = ta_tile * TA;
+    const float *base = in + (i64)o * other_stride;
+    const int rows = TA + 2 * L;
+    if (x < w) {
+        for (int r = grp; r < rows; r += 4) {
+            int a = a0 - L + r;
+            a = a < 0 ? 0 : (a > n_axis - 1 ? n_axis - 1 : a);
+            s_in[r * 64 + lane] = base[(i64)a * axis_stride + x];
+        }
+    }
+    for (int t = threadIdx.x; t < 2 * L + 1; t += 256) s_tap[t] = taps[t];
+    __syncthreads();
+    if (x >= w) return;
+    float *dst = out + (i64)o * other_stride;
+#pragma unroll 1
+    for (int j = 0; j < TA / 4; ++j) {
+        const int ra = grp + 4 * j;
+        const int a = a0 + ra;
+        if (a >= n_axis) break;
+        float acc = 0.f;
+        for (int k = 0; k <= 2 * L; ++k) acc = acc + s_in[(ra + k) * 64 + lane] * s_tap[k];
+        dst[(i64)a * axis_stride + x] = acc;
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// K4: Hessian (frangi.cpp:305-381) + eigen (:1269-1493) + vesselness (:190-273)
+// ----------------------------------------------------------------------------------------
+// first difference along an axis (stride s, coordinate c of n): one-sided at the borders
+__device__ __forceinline__ float d1(const float *__restrict__ F, i64 i, i64 s, int c, int n)
+{
+    if (c == 0) return F[i + s] - F[i];
+    if (c < n - 1) return 0.5f * (F[i + s] - F[i - s]); // .5*(a-b): exact scaling of the f32 difference
+    return F[i] - F[i - s];
+}
+// difference along `so` of the first difference along `si`; same != 0 when both are one axis
+__device__ __forceinline__ float d2(const float *__restrict__ F, i64 i, i64 si, int ci, int ni, i64 so, int co, int no,
+                                    int same)
+{
+    if (co == 0) return d1(F, i + so, si, ci + same, ni) - d1(F, i, si, ci, ni);
+    if (co < no - 1) return 0.5f * (d1(F, i + so, si, ci + same, ni) - d1(F, i - so, si, ci - same, ni));
+    return d1(F, i, si, ci, ni) - d1(F, i - so, si, ci - same, ni);
+}
+
+struct Sym3 {
+    double V[3][3];
+    double d[3];
+};
+
+// Householder tridiagonalisation (EISPACK/JAMA tred2), n = 3, fully unrolled: all indices static
+__device__ __forceinline__ void tridiag3(double (&V)[3][3], double (&d)[3], double (&e)[3])
+{
+#pragma unroll
+    for (int j = 0; j < 3; j++) d[j] = V[2][j];
+#pragma unroll
+    for (int i = 2; i > 0; i--) {
+        double scale = 0.0, h = 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) scale = scale + fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                d[j] = V[i - 1][j];
+                V[i][j] = 0.0;
+                V[j][i] = 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < i; k++) {
+                d[k] /= scale;
+                h += d[k] * d[k];
+            }
+            double f = d[i - 1];
+            double g = sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g;
+            h = h - f * g;
+            d[i - 1] = f - g;
+#pragma unroll
+            for (int j = 0; j < i; j++) e[j] = 0.0;
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                f = d[j];
+                V[j][i] = f;
+                g = e[j] + V[j][j] * f;
+#pragma unroll
+                for (int k = j + 1; k <= i - 1; k++) {
+                    g += V[k][j] * d[k];
+                    e[k] += V[k][j] * f;
+                }
+                e[j] = g;
+            }
+            f = 0.0;
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                e[j] /= h;
+                f += e[j] * d[j];
+            }
+            const double hh = f / (h + h);
+#pragma unroll
+            for (int j = 0; j < i; j++) e[j] -= hh * d[j];
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                f = d[j];
+                g = e[j];
+#pragma unroll
+                for (int k = j; k <= i - 1; k++) V[k][j] -= (f * e[k] + g * d[k]);
+                d[j] = V[i - 1][j];
+                V[i][j] = 0.0;
+            }
+        }
+        d[i] = h;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        V[2][i] = V[i][i];
+        V[i][i] = 1.0;
+        const double h = d[i + 1];
+        if (h != 0.0) {
+#pragma unroll
+            for (int k = 0; k <= i; k++) d[k] = V[k][i + 1] / h;
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                double g = 0.0;
+#pragma unroll
+                for (int k = 0; k <= i; k++) g += V[k][i + 1] * V[k][j];
+#pragma unroll
+                for (int k = 0; k <= i; k++) V[k][j] -= g * d[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k <= i; k++) V[k][i + 1] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        d[j] = V[2][j];
+        V[2][j] = 0.0;
+    }
+    V[2][2] = 1.0;
+    e[0] = 0.0;
+}
+
+__device__ __forceinline__ double hyp2(double a, double b) { return sqrt(a * a + b * b); }
+
+// one Givens step of the implicit QL sweep at static position I (rotates columns I, I+1)
+template <int I>
+__device__ __forceinline__ void ql_rotate(double (&V)[3][3], double (&d)[3], double (&e)[3], double &p, double &c,
+                                          double &c2, double &c3, double &s, double &s2)
+{
+    c3 = c2;
+    c2 = c;
+    s2 = s;
+    double g = c * e[I];
+    double h = c * p;
+    const double r = hyp2(p, e[I]);
+    e[I + 1] = s * r;
+    s = e[I] / r;
+    c = p / r;
+    p = c * d[I] - s * g;
+    d[I + 1] = h + s * (c * g + s * d[I]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        h = V[k][I + 1];
+        V[k][I + 1] = s * V[k][I] + c * h;
+        V[k][I] = c * V[k][I] - s * h;
+    }
+}
+
+// implicit-shift QL for row L of the tridiagonal matrix (JAMA tql2 body), static L
+template <int L>
+__device__ __forceinline__ void ql_row(double (&V)[3][3], double (&d)[3], double (&e)[3], double &f, double &tst1)
+{
+    const double eps = 2.220446049250313e-16; // 2^-52
+    const double t = fabs(d[L]) + fabs(e[L]);
+    tst1 = (tst1 > t) ? tst1 : t;
+    int m = L;
+#pragma unroll
+    for (int q = L; q < 3; q++) { // while (m < n) { if (|e[m]| <= eps*tst1) break; m++; }
+        if (m == q && !(fabs(e[q]) <= eps * tst1)) m = q + 1;
+    }
+    if (L < 2 && m > L) {
+        constexpr int L1 = (L < 2) ? L + 1 : 2; // keeps indices in range for the never-taken L == 2 case
+        do {
+            double g = d[L];
+            double p = (d[L1] - g) / (2.0 * e[L]);
+            double r = hyp2(p, 1.0);
+            if (p < 0) r = -r;
+            d[L] = e[L] / (p + r);
+            d[L1] = e[L] * (p + r);
+            const double dl1 = d[L1];
+            double h = g - d[L];
+            if (L == 0) d[2] -= h; // for (i = l+2; i < n; i++) d[i] -= h
+            f = f + h;
+            // m == 3 only if e[2] failed the test, impossible (e[2] == 0): d[m] is d[1] or d[2]
+            p = (m == 2) ? d[2] : d[1];
+            double c = 1.0, c2 = 1.0, c3 = 1.0;
+            const double el1 = e[L1];
+            double s = 0.0, s2 = 0.0;
+            if (m - 1 >= 1 && 1 >= L) ql_rotate<1>(V, d, e, p, c, c2, c3, s, s2);
+            if (L == 0) ql_rotate<0>(V, d, e, p, c, c2, c3, s, s2); // m-1 >= 0 always here
+            p = -s * s2 * c3 * el1 * e[L] / dl1;
+            e[L] = s * p;
+            d[L] = c * p;
+        } while (fabs(e[L]) > eps * tst1);
+    }
+    d[L] = d[L] + f;
+    e[L] = 0.0;
+}
+
+__device__ __forceinline__ void swap_col(double (&V)[3][3], double (&d)[3], int a, int b)
+{
+    // only called with literal a,b after inlining
+    double t = d[a]; d[a] = d[b]; d[b] = t;
+#pragma unroll
+    for (int r = 0; r < 3; r++) { t = V[r][a]; V[r][a] = V[r][b]; V[r][b] = t; }
+}
+
+// Frangi::eigen_decomposition: eigenvalues sorted by |lambda| ascending, columns = eigenvectors
+__device__ __forceinline__ void eigen3(double (&V)[3][3], double (&d)[3])
+{
+    double e[3];
+    tridiag3(V, d, e);
+    e[0] = e[1]; // for (i = 1; i < n; i++) e[i-1] = e[i]; e[n-1] = 0
+    e[1] = e[2];
+    e[2] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    ql_row<0>(V, d, e, f, tst1);
+    ql_row<1>(V, d, e, f, tst1);
+    ql_row<2>(V, d, e, f, tst1);
+    // ascending selection sort (tql2 tail), static indices
+    {
+        int k = 0;
+        double p = d[0];
+        if (d[1] < p) { k = 1; p = d[1]; }
+        if (d[2] < p) { k = 2; p = d[2]; }
+        if (k == 1) swap_col(V, d, 0, 1);
+        else if (k == 2) swap_col(V, d, 0, 2);
+        if (d[2] < d[1]) swap_col(V, d, 1, 2);
+    }
+    // re-sort by |lambda| (frangi.cpp:1286-1304)
+    const double a0 = fabs(d[0]), a1 = fabs(d[1]), a2 = fabs(d[2]);
+    double b0 = a0, b1 = a1;
+    if ((a0 >= a1) && (a0 > a2)) { swap_col(V, d, 0, 2); b0 = a2; }
+    else if ((a1 >= a0) && (a1 > a2)) { swap_col(V, d, 1, 2); b1 = a2; }
+    if (b0 > b1) swap_col(V, d, 0, 1);
+}
+
+__device__ __forceinline__ unsigned int f2ord(float f)
+{
+    const unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(unsigned int u)
+{
+    const unsigned int b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    union { unsigned int i; float f; } cv;
+    cv.i = b;
+    return cv.f;
+}
+
+__device__ __forceinline__ unsigned char quant_dir(double v)
+{
+    const double r = ((v + 1) / 2) * 255;
+    int val = (int)((r > 0.0) ? floor(r + 0.5) : ceil(r - 0.5)); // round(), Advantra_plugin.cpp:120-123
+    val = (val < 0) ? 0 : (val > 255) ? 255 : val;
+    return (unsigned char)val;
+}
+
+struct HessOut {
+    float *Dzz, *Dyy, *Dyz, *Dxx, *Dxy, *Dxz;
+};
+
+template <bool DUMP>
+__global__ __launch_bounds__(256) void hessian_eigen(const float *__restrict__ F, float *__restrict__ J,
+                                                      unsigned char *__restrict__ Vx, unsigned char *__restrict__ Vy,
+                                                      unsigned char *__restrict__ Vz, int w, int h, int l, int tiles_x,
+                                                      float s2, float two_a2, float two_b2, float two_c2, int first,
+                                                      unsigned int *__restrict__ minmax, HessOut dump)
+{
+    const i64 b = blockIdx.x;
+    const i64 row = b / tiles_x;
+    const int x = (int)(b % tiles_x) * 256 + threadIdx.x;
+    const int z = (int)(row / h), y = (int)(row - (i64)z * h);
+    const i64 wh = (i64)w * h;
+    unsigned int omin = 0xffffffffu, omax = 0u;
+    if (x < w) {
+        const i64 i = row * w + x;
+        // six second derivatives, each x sigma^2 (frangi.cpp:319,339,345,368,374,380)
+        const float Dzz = d2(F, i, wh, z, l, wh, z, l, 1) * s2;
+        const float Dyy = d2(F, i, w, y, h, w, y, h, 1) * s2;
+        const float Dyz = d2(F, i, w, y, h, wh, z, l, 0) * s2;
+        const float Dxx = d2(F, i, 1, x, w, 1, x, w, 1) * s2;
+        const float Dxy = d2(F, i, 1, x, w, w, y, h, 0) * s2;
+        const float Dxz = d2(F, i, 1, x, w, wh, z, l, 0) * s2;
+        if (DUMP) {
+            dump.Dzz[i] = Dzz; dump.Dyy[i] = Dyy; dump.Dyz[i] = Dyz;
+            dump.Dxx[i] = Dxx; dump.Dxy[i] = Dxy; dump.Dxz[i] = Dxz;
+        } else {
+            double V[3][3], d[3];
+            V[0][0] = Dxx; V[0][1] = Dxy; V[0][2] = Dxz;
+            V[1][0] = Dxy; V[1][1] = Dyy; V[1][2] = Dyz;
+            V[2][0] = Dxz; V[2][1] = Dyz; V[2][2] = Dzz;
+            eigen3(V, d);
+            const double L2 = d[1], L3 = d[2];
+            const double a1 = fabs(d[0]), a2 = fabs(L2), a3 = fabs(L3);
+            const double Ra = a2 / a3;
+            const double Rb = a1 / sqrt(a2 * a3);
+            const double S = sqrt(a1 * a1 + a2 * a2 + a3 * a3);
+            const double expRa = (1 - exp(-((Ra * Ra) / (double)two_a2)));
+            const double expRb = exp(-((Rb * Rb) / (double)two_b2));
+            const double expS = (1 - exp(-(S * S) / (double)two_c2));
+            double vox = expRa * expRb * expS;
+            vox = (L2 > 0) ? 0 : vox;
+            vox = (L3 > 0) ? 0 : vox;
+            vox = (vox != vox) ? 0 : vox; // NaN -> 0
+            bool wr = first != 0;
+            if (!wr) wr = vox > (double)J[i];
+            if (wr) {
+                const float jf = (float)vox;
+                J[i] = jf;
+                Vx[i] = quant_dir(V[0][0]);
+                Vy[i] = quant_dir(V[1][0]);
+                Vz[i] = quant_dir(V[2][0]);
+                omin = omax = f2ord(jf);
+            }
+        }
+    }
+    if (DUMP) return;
+    // Jmin/Jmax are updated only on writes (frangi.cpp:237-238,257-258)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int m1 = __shfl_xor(omin, o), m2 = __shfl_xor(omax, o);
+        omin = m1 < omin ? m1 : omin;
+        omax = m2 > omax ? m2 : omax;
+    }
+    __shared__ unsigned int s_min[4], s_max[4];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_min[wv] = omin; s_max[wv] = omax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int a = s_min[0], c = s_max[0];
+        for (int k = 1; k < 4; k++) { a = s_min[k] < a ? s_min[k] : a; c = s_max[k] > c ? s_max[k] : c; }
+        if (a != 0xffffffffu) atomicMin(&minmax[0], a);
+        if (c != 0u) atomicMax(&minmax[1], c);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// K5: J -> J8 (Advantra_plugin.cpp:2499-2512)
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void j8_kernel(const float *__restrict__ J, unsigned char *__restrict__ J8, i64 n,
+                                                  float jmin, float jmax, int flat)
+{
+    const i64 stride = (i64)gridDim.x * 256 * 4;
+    for (i64 i0 = ((i64)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
+        unsigned char o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const i64 i = i0 + k;
+            int val = 0;
+            if (!flat && i < n) {
+                const double r = (double)(((J[i] - jmin) / (jmax - jmin)) * 255);
+                val = (int)((r > 0.0) ? floor(r + 0.5) : ceil(r - 0.5));
+                val = (val < 0) ? 0 : (val > 255) ? 255 : val;
+            }
+            o[k] = (unsigned char)val;
+        }
+        if (i0 + 3 < n && ((uintptr_t)(J8 + i0) & 3) == 0)
+            *(uchar4 *)(J8 + i0) = make_uchar4(o[0], o[1], o[2], o[3]);
+        else
+            for (int k = 0; k < 4 && i0 + k < n; k++) J8[i0 + k] = o[k];
+    }
+}
+
+} // namespace
+
+// ========================================================================================
+// host side
+// ========================================================================================
+int pnr_ensure_frangi_buffers(pnr_ctx *c)
+{
+    if (c->frangi_cap >= c->N && c->d_J) return PNR_OK;
+    hipFree(c->d_tmpA); hipFree(c->d_tmpB); hipFree(c->d_J);
+    hipFree(c->d_Vx); hipFree(c->d_Vy); hipFree(c->d_Vz); hipFree(c->d_J8);
+    c->d_tmpA = c->d_tmpB = c->d_J = nullptr;
+    c->d_Vx = c->d_Vy = c->d_Vz = c->d_J8 = nullptr;
+    c->frangi_cap = 0;
+    const size_t n = (size_t)c->N;
+    PNR_HIP(hipMalloc(&c->d_tmpA, n * 4));
+    PNR_HIP(hipMalloc(&c->d_tmpB, n * 4));
+    PNR_HIP(hipMalloc(&c->d_J, n * 4));
+    PNR_HIP(hipMalloc(&c->d_Vx, n));
+    PNR_HIP(hipMalloc(&c->d_Vy, n));
+    PNR_HIP(hipMalloc(&c->d_Vz, n));
+    PNR_HIP(hipMalloc(&c->d_J8, n));
+    c->frangi_cap = c->N;
+    return PNR_OK;
+}
+
+static int upload_taps(pnr_ctx *c, const std::vector<float> &g, float *d_dst)
+{
+    PNR_HIP(hipMemcpyAsync(d_dst, g.data(), g.size() * 4, hipMemcpyHostToDevice, c->stream));
+    return PNR_OK;
+}
+
+// F(sigma) -> d_out (device).  uses tmpA/tmpB as ping-pong; d_out may be tmpA.
+static int gaussian3d(pnr_ctx *c, const std::vector<float> &gxy, const std::vector<float> &gz, float *d_taps,
+                      float *d_out)
+{
+    const int w = (int)c->w, h = (int)c->h, l = (int)c->l;
+    const int Lxy = ((int)gxy.size() - 1) / 2, Lz = ((int)gz.size() - 1) / 2;
+    PNR_REQUIRE(Lxy <= MAX_L && Lz <= MAX_L, PNR_E_ARG, "sigma too large: Gaussian radius %d > %d", Lxy, MAX_L);
+    float *d_txy = d_taps, *d_tz = d_taps + 2 * MAX_L + 1;
+    int rc = upload_taps(c, gxy, d_txy);
+    if (rc) return rc;
+    rc = upload_taps(c, gz, d_tz);
+    if (rc) return rc;
+    // the three passes alternate buffers so that the last one lands in d_out
+    float *bufX = (d_out == c->d_tmpA) ? c->d_tmpA : c->d_tmpB; // x-pass out
+    float *bufY = (bufX == c->d_tmpA) ? c->d_tmpB : c->d_tmpA;  // y-pass out
+    float *bufZ = d_out;
+    if (bufZ == bufY) { float *t = bufX; bufX = bufY; bufY = t; }
+    c->tic();
+    {
+        const int tiles_x = (w + GX_BLOCK - 1) / GX_BLOCK;
+        const i64 rows = (i64)h * l;
+        hipLaunchKernelGGL(gauss_x_u8, dim3((unsigned)(rows * tiles_x)), dim3(GX_BLOCK), 0, c->stream, c->d_img, bufX, w,
+                           rows, tiles_x, d_txy, Lxy);
+    }
+    {
+        const int tiles_x = (w + 63) / 64, tiles_a = (h + TA - 1) / TA;
+        const size_t sm = ((size_t)(TA + 2 * Lxy) * 64 + 2 * Lxy + 1) * 4;
+        hipLaunchKernelGGL(gauss_axis, dim3((unsigned)((i64)tiles_x * tiles_a * l)), dim3(256), sm, c->stream, bufX, bufY,
+                           w, h, (i64)w, l, (i64)w * h, tiles_x, tiles_a, d_txy, Lxy);
+    }
+    {
+        const int tiles_x = (w + 63) / 64, tiles_a = (l + TA - 1) / TA;
+        const size_t sm = ((size_t)(TA + 2 * Lz) * 64 + 2 * Lz + 1) * 4;
+        hipLaunchKernelGGL(gauss_axis, dim3((unsigned)((i64)tiles_x * tiles_a * h)), dim3(256), sm, c->stream, bufY, bufZ,
+                           w, l, (i64)w * h, h, (i64)w, tiles_x, tiles_a, d_tz, Lz);
+    }
+    c->toc("gauss", 3);
+    PNR_HIP(hipGetLastError());
+    return PNR_OK;
+}
+
+static int check_grid(pnr_ctx *c)
+{
+    const i64 rows = c->h * c->l;
+    const i64 blocks = rows * ((c->w + 63) / 64);
+    PNR_REQUIRE(blocks < 2147483647LL, PNR_E_ARG, "volume too large for a single launch grid");
+    return PNR_OK;
+}
+
+int pnr_gaussian_run(pnr_ctx *c, float sig, float *d_out)
+{
+    int rc = check_grid(c);
+    if (rc) return rc;
+    std::vector<float> gxy, gz;
+    pnr::gaussian_taps(sig, gxy);
+    pnr::gaussian_taps(sig / c->prm.zdist, gz);
+    float *d_taps = nullptr;
+    PNR_HIP(hipMalloc(&d_taps, (2 * (2 * MAX_L + 1)) * 4));
+    rc = gaussian3d(c, gxy, gz, d_taps, d_out);
+    hipStreamSynchronize(c->stream);
+    hipFree(d_taps);
+    return rc;
+}
+
+int pnr_hessian_run(pnr_ctx *c, float sig, float *const d_out[6])
+{
+    int rc = pnr_gaussian_run(c, sig, c->d_tmpA);
+    if (rc) return rc;
+    const int w = (int)c->w, h = (int)c->h, l = (int)c->l;
+    const int tiles_x = (w + 255) / 256;
+    HessOut dump{d_out[0], d_out[1], d_out[2], d_out[3], d_out[4], d_out[5]};
+    hipLaunchKernelGGL(hessian_eigen<true>, dim3((unsigned)((i64)h * l * tiles_x)), dim3(256), 0, c->stream, c->d_tmpA,
+                       (float *)nullptr, (unsigned char *)nullptr, (unsigned char *)nullptr, (unsigned char *)nullptr, w, h,
+                       l, tiles_x, sig * sig, 0.f, 0.f, 0.f, 1, (unsigned int *)nullptr, dump);
+    PNR_HIP(hipGetLastError());
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    return PNR_OK;
+}
+
+int pnr_frangi_run(pnr_ctx *c, float *Jmin, float *Jmax)
+{
+    int rc = check_grid(c);
+    if (rc) return rc;
+    rc = pnr_ensure_frangi_buffers(c);
+    if (rc) return rc;
+    const int w = (int)c->w, h = (int)c->h, l = (int)c->l;
+    const pnr_params &P = c->prm;
+    float *d_taps = nullptr;
+    PNR_HIP(hipMalloc(&d_taps, (size_t)P.nsig * (2 * (2 * MAX_L + 1)) * 4));
+    const unsigned int init[2] = {0xffffffffu, 0u};
+    PNR_HIP(hipMemcpyAsync(c->d_minmax, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    // f32 products, as "2*alpha*alpha" etc. in frangi.cpp:214-216
+    const float two_a2 = 2 * P.alpha * P.alpha, two_b2 = 2 * P.beta * P.beta, two_c2 = 2 * P.C * P.C;
+    for (int s = 0; s < P.nsig; s++) {
+        rc = gaussian3d(c, c->tab.gxy[s], c->tab.gz[s], d_taps + (size_t)s * (2 * (2 * MAX_L + 1)), c->d_tmpA);
+        if (rc) { hipFree(d_taps); return rc; }
+        const int tiles_x = (w + 255) / 256;
+        c->tic();
+        hipLaunchKernelGGL(hessian_eigen<false>, dim3((unsigned)((i64)h * l * tiles_x)), dim3(256), 0, c->stream, c->d_tmpA,
+                           c->d_J, c->d_Vx, c->d_Vy, c->d_Vz, w, h, l, tiles_x, P.sig[s] * P.sig[s], two_a2, two_b2, two_c2,
+                           s == 0 ? 1 : 0, c->d_minmax, HessOut{});
+        c->toc("hessian_eigen");
+    }
+    unsigned int mm[2];
+    PNR_HIP(hipMemcpyAsync(mm, c->d_minmax, sizeof(mm), hipMemcpyDeviceToHost, c->stream));
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    hipFree(d_taps);
+    c->Jmin = ord2f(mm[0]);
+    c->Jmax = ord2f(mm[1]);
+    const int flat = std::fabs(c->Jmax - c->Jmin) <= FLT_MIN;
+    c->tic();
+    {
+        i64 blocks = (c->N + 1023) / 1024;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(j8_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_J, c->d_J8, c->N, c->Jmin,
+                           c->Jmax, flat);
+    }
+    c->toc("j8");
+    PNR_HIP(hipGetLastError());
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    c->have_j8 = true;
+    if (Jmin) *Jmin = c->Jmin;
+    if (Jmax) *Jmax = c->Jmax;
+    return PNR_OK;
+}

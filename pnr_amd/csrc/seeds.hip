@@ -1,0 +1,316 @@
+// seeds.hip -- SeedExtractor::extractSeeds (seed.cpp:556-791) split the MI355X way:
+//
+//   GPU  K7a layer_minmax    per z-layer min/max of J8 (one block per layer, wave reductions)
+//        K7b layer_maxima    8-neighbour local-maximum test for every pixel (seed.cpp:589-614),
+//                            sort key (value<<32 | pixel) appended to the layer's candidate list
+//        K7c gather_dirs     Vx,Vy,Vz at the accepted seed voxels only
+//   host analyzeAndMarkMaxima (seed.cpp:643-782): the tolerance flood-fill is sequential and
+//        order-dependent inside a layer (each accepted/rejected maximum marks pixels PROCESSED
+//        for the ones after it); layers are independent, so they are spread over host threads.
+//        This is the same split the trace bookkeeping uses (GPU for the data-parallel part,
+//        host replay for the inherently sequential integer part) -- it is not a fallback.
+#include "ctx.h"
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace {
+typedef long long i64;
+
+__global__ __launch_bounds__(256) void layer_minmax(const unsigned char *__restrict__ J8, i64 wh, int z0,
+                                                     int *__restrict__ vmin, int *__restrict__ vmax)
+{
+    const int zl = blockIdx.x;
+    const unsigned char *L = J8 + (i64)(z0 + zl) * wh;
+    int mn = 255, mx = 0;
+    for (i64 i = threadIdx.x; i < wh; i += 256) {
+        const int v = L[i];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    __shared__ int s_mn[4], s_mx[4];
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) { mn = s_mn[k] < mn ? s_mn[k] : mn; mx = s_mx[k] > mx ? s_mx[k] : mx; }
+        vmin[zl] = mn;
+        vmax[zl] = mx;
+    }
+}
+
+// COUNT pass: counts per layer.  WRITE pass: keys into [off[zl], off[zl+1]).
+template <bool WRITE>
+__global__ __launch_bounds__(256) void layer_maxima(const unsigned char *__restrict__ J8, int w, int h, int z0, int tiles_x,
+                                                     const int *__restrict__ vmin, const float *__restrict__ vfactor,
+                                                     unsigned int *__restrict__ count, const i64 *__restrict__ off,
+                                                     i64 *__restrict__ keys)
+{
+    i64 b = blockIdx.x;
+    const int x = (int)(b % tiles_x) * 256 + threadIdx.x;
+    b /= tiles_x;
+    const int y = (int)(b % h);
+    const int zl = (int)(b / h);
+    if (x <= 0 || x >= w - 1 || y <= 0 || y >= h - 1) return; // border pixels are never maxima (seed.cpp:595)
+    const unsigned char *L = J8 + (i64)(z0 + zl) * w * h;
+    const int p = y * w + x;
+    const int v = L[p];
+    if (v == vmin[zl]) return; // seed.cpp:594
+    const unsigned char *r0 = L + p - w, *r2 = L + p + w;
+    const int m = max(max(max((int)r0[-1], (int)r0[0]), max((int)r0[1], (int)L[p - 1])),
+                      max(max((int)L[p + 1], (int)r2[-1]), max((int)r2[0], (int)r2[1])));
+    if (m > v) return;
+    if (!WRITE) {
+        atomicAdd(&count[zl], 1u);
+    } else {
+        // seed.cpp:616,626: iValue = (int)((fValue - globalMin) * vFactor), f32 arithmetic
+        const float fValue = (float)v, gmin = (float)vmin[zl];
+        const int iValue = (int)((fValue - gmin) * vfactor[zl]);
+        const unsigned int slot = atomicAdd(&count[zl], 1u);
+        keys[off[zl] + slot] = (i64)(((unsigned long long)(i64)iValue << 32) | (unsigned int)p);
+    }
+}
+
+__global__ void gather_dirs(const unsigned char *__restrict__ Vx, const unsigned char *__restrict__ Vy,
+                            const unsigned char *__restrict__ Vz, const i64 *__restrict__ idx, int n,
+                            unsigned char *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const i64 v = idx[i];
+    out[3 * i] = Vx[v];
+    out[3 * i + 1] = Vy[v];
+    out[3 * i + 2] = Vz[v];
+}
+
+// ---------------- host: tolerance flood-fill of one layer (ImageJ MaximumFinder) ----------------
+enum : unsigned char { F_MAXIMUM = 1, F_LISTED = 2, F_PROCESSED = 4, F_MAX_AREA = 8, F_EQUAL = 16, F_MAX_POINT = 32 };
+
+struct LayerFinder {
+    int w, h;
+    std::vector<unsigned char> flags;
+    std::vector<int> list;
+    LayerFinder(int w_, int h_) : w(w_), h(h_), flags((size_t)w_ * h_), list((size_t)w_ * h_) {}
+
+    static inline bool inside(int x, int y, int d, int w, int h)
+    {
+        switch (d) { // neighbour d exists? (seed.cpp:1027-1049)
+        case 0: return y > 0;
+        case 1: return x < w - 1 && y > 0;
+        case 2: return x < w - 1;
+        case 3: return x < w - 1 && y < h - 1;
+        case 4: return y < h - 1;
+        case 5: return x > 0 && y < h - 1;
+        case 6: return x > 0;
+        default: return x > 0 && y > 0;
+        }
+    }
+
+    // keys ascending; emits accepted maxima (pixel offsets) in processing order (highest first)
+    void run(const unsigned char *L8, const i64 *keys, i64 nkeys, float tol, std::vector<int> &accepted)
+    {
+        static const int DX[8] = {0, 1, 1, 1, 0, -1, -1, -1}, DY[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
+        const int step[8] = {-w, -w + 1, 1, w + 1, w, w - 1, -1, -w - 1};
+        std::memset(flags.data(), 0, flags.size());
+        for (i64 q = nkeys - 1; q >= 0; --q) {
+            int start = (int)(unsigned int)(keys[q] & 0xffffffffLL);
+            if (flags[start] & F_PROCESSED) continue;
+            int sx = start % w, sy = start / w;
+            float v0 = (float)L8[start];
+            bool retry;
+            do {
+                retry = false;
+                list[0] = start;
+                flags[start] |= (F_EQUAL | F_LISTED);
+                int len = 1;
+                bool edge = (sx == 0 || sx == w - 1 || sy == 0 || sy == h - 1);
+                bool possible = true;
+                double ex = sx, ey = sy;
+                int neq = 1;
+                for (int cur = 0; cur < len; ++cur) {
+                    const int off = list[cur];
+                    const int x = off % w, y = off / w;
+                    const bool inner = (y != 0 && y != h - 1) && (x != 0 && x != w - 1);
+                    for (int d = 0; d < 8; d++) {
+                        const int o2 = off + step[d];
+                        if (!(inner || inside(x, y, d, w, h))) continue;
+                        if (flags[o2] & F_LISTED) continue;
+                        if (flags[o2] & F_PROCESSED) { possible = false; break; }
+                        const int x2 = x + DX[d], y2 = y + DY[d];
+                        const float v2 = (float)L8[o2];
+                        if (v2 > v0) { possible = false; break; } // maxSortingError == 0 (seed.cpp:634)
+                        if (v2 >= v0 - tol) {
+                            list[len++] = o2;
+                            flags[o2] |= F_LISTED;
+                            if (x2 == 0 || x2 == w - 1 || y2 == 0 || y2 == h - 1) {
+                                edge = true;
+                                possible = false; // excludeEdgesNow
+                                break;
+                            }
+                            if (v2 == v0) {
+                                flags[o2] |= F_EQUAL;
+                                ex += x2; ey += y2; neq++;
+                            }
+                        }
+                    }
+                }
+                // (the sortingError branch of the original needs v2 > v0 past the test above: unreachable)
+                const unsigned char keep = (unsigned char)~(possible ? F_LISTED : (F_LISTED | F_EQUAL));
+                ex /= neq;
+                ey /= neq;
+                double best = 1e20;
+                int besti = 0;
+                for (int k = 0; k < len; k++) {
+                    const int off = list[k];
+                    const int x = off % w, y = off / w;
+                    flags[off] &= keep;
+                    flags[off] |= F_PROCESSED;
+                    if (possible) {
+                        flags[off] |= F_MAX_AREA;
+                        if (flags[off] & F_EQUAL) {
+                            const double d2 = (ex - x) * (double)(ex - x) + (ey - y) * (double)(ey - y);
+                            if (d2 < best) { best = d2; besti = k; }
+                        }
+                    }
+                }
+                if (possible) {
+                    const int off = list[besti];
+                    flags[off] |= F_MAX_POINT;
+                    if (!edge) accepted.push_back(off);
+                }
+            } while (retry);
+        }
+    }
+};
+
+} // namespace
+
+int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
+{
+    PNR_REQUIRE(c->have_j8, PNR_E_STATE, "pnr_extract_seeds: run pnr_frangi (or pnr_set_j8_v) first");
+    PNR_REQUIRE(z0 >= 0 && z1 <= c->l && z0 <= z1, PNR_E_ARG, "layer range [%lld,%lld) outside [0,%lld)", (long long)z0, (long long)z1, (long long)c->l);
+    c->seeds.clear();
+    const int w = (int)c->w, h = (int)c->h;
+    const int nl = (int)(z1 - z0);
+    if (nl == 0) return PNR_OK;
+    const i64 wh = (i64)w * h;
+
+    int *d_min = nullptr, *d_max = nullptr;
+    unsigned int *d_cnt = nullptr;
+    float *d_vf = nullptr;
+    i64 *d_off = nullptr, *d_keys = nullptr;
+    PNR_HIP(hipMalloc(&d_min, nl * 4));
+    PNR_HIP(hipMalloc(&d_max, nl * 4));
+    PNR_HIP(hipMalloc(&d_cnt, nl * 4));
+    PNR_HIP(hipMalloc(&d_vf, nl * 4));
+    PNR_HIP(hipMalloc(&d_off, (nl + 1) * 8));
+    std::vector<int> vmin(nl), vmax(nl);
+    std::vector<unsigned int> cnt(nl);
+    std::vector<float> vf(nl);
+    std::vector<i64> off(nl + 1, 0);
+
+    // start the J8 download for the host flood-fill while the kernels run
+    unsigned char *h_j8 = nullptr;
+    PNR_HIP(hipHostMalloc(&h_j8, (size_t)(wh * nl), hipHostMallocDefault));
+    PNR_HIP(hipMemcpyAsync(h_j8, c->d_J8 + z0 * wh, (size_t)(wh * nl), hipMemcpyDeviceToHost, c->stream));
+
+    c->tic();
+    hipLaunchKernelGGL(layer_minmax, dim3(nl), dim3(256), 0, c->stream, c->d_J8, wh, (int)z0, d_min, d_max);
+    PNR_HIP(hipMemsetAsync(d_cnt, 0, nl * 4, c->stream));
+    const int tiles_x = (w + 255) / 256;
+    const unsigned nblk = (unsigned)((i64)tiles_x * h * nl);
+    hipLaunchKernelGGL(layer_maxima<false>, dim3(nblk), dim3(256), 0, c->stream, c->d_J8, w, h, (int)z0, tiles_x, d_min,
+                       (const float *)nullptr, d_cnt, (const i64 *)nullptr, (i64 *)nullptr);
+    c->toc("seed_maxima", 2);
+    PNR_HIP(hipMemcpyAsync(vmin.data(), d_min, nl * 4, hipMemcpyDeviceToHost, c->stream));
+    PNR_HIP(hipMemcpyAsync(vmax.data(), d_max, nl * 4, hipMemcpyDeviceToHost, c->stream));
+    PNR_HIP(hipMemcpyAsync(cnt.data(), d_cnt, nl * 4, hipMemcpyDeviceToHost, c->stream));
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < nl; k++) {
+        off[k + 1] = off[k] + cnt[k];
+        vf[k] = (float)(2e9 / ((float)vmax[k] - (float)vmin[k])); // seed.cpp:616 (inf on flat layers: no maxima there)
+    }
+    const i64 total = off[nl];
+    std::vector<i64> keys((size_t)total);
+    if (total > 0) {
+        PNR_HIP(hipMalloc(&d_keys, (size_t)total * 8));
+        PNR_HIP(hipMemcpyAsync(d_off, off.data(), (nl + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        PNR_HIP(hipMemcpyAsync(d_vf, vf.data(), nl * 4, hipMemcpyHostToDevice, c->stream));
+        PNR_HIP(hipMemsetAsync(d_cnt, 0, nl * 4, c->stream));
+        c->tic();
+        hipLaunchKernelGGL(layer_maxima<true>, dim3(nblk), dim3(256), 0, c->stream, c->d_J8, w, h, (int)z0, tiles_x, d_min,
+                           d_vf, d_cnt, d_off, d_keys);
+        c->toc("seed_maxima", 1);
+        PNR_HIP(hipMemcpyAsync(keys.data(), d_keys, (size_t)total * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    PNR_HIP(hipGetLastError());
+    PNR_HIP(hipStreamSynchronize(c->stream));
+
+    // host: per-layer flood-fill on a thread pool; results kept per layer to preserve z-major order
+    std::vector<std::vector<int>> acc(nl);
+    {
+        unsigned nt = std::thread::hardware_concurrency();
+        if (nt == 0) nt = 4;
+        if (nt > 32) nt = 32;
+        if ((int)nt > nl) nt = nl;
+        std::atomic<int> next(0);
+        const float tol = (float)(double)c->prm.tolerance;
+        auto work = [&]() {
+            LayerFinder lf(w, h);
+            for (;;) {
+                const int k = next.fetch_add(1);
+                if (k >= nl) break;
+                if (cnt[k] == 0) continue;
+                i64 *kb = keys.data() + off[k];
+                std::sort(kb, kb + cnt[k]); // unique keys: order fully defined (seed.cpp:632)
+                lf.run(h_j8 + (size_t)k * wh, kb, cnt[k], tol, acc[k]);
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+    }
+    hipHostFree(h_j8);
+
+    // directions at the accepted voxels (seed.cpp:767-771)
+    std::vector<i64> vox;
+    for (int k = 0; k < nl; k++)
+        for (int o : acc[k]) vox.push_back((z0 + k) * wh + o);
+    const int ns = (int)vox.size();
+    std::vector<unsigned char> dirs((size_t)ns * 3);
+    if (ns > 0) {
+        i64 *d_idx = nullptr;
+        unsigned char *d_dirs = nullptr;
+        PNR_HIP(hipMalloc(&d_idx, (size_t)ns * 8));
+        PNR_HIP(hipMalloc(&d_dirs, (size_t)ns * 3));
+        PNR_HIP(hipMemcpyAsync(d_idx, vox.data(), (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(gather_dirs, dim3((ns + 255) / 256), dim3(256), 0, c->stream, c->d_Vx, c->d_Vy, c->d_Vz, d_idx, ns,
+                           d_dirs);
+        PNR_HIP(hipMemcpyAsync(dirs.data(), d_dirs, (size_t)ns * 3, hipMemcpyDeviceToHost, c->stream));
+        PNR_HIP(hipStreamSynchronize(c->stream));
+        hipFree(d_idx);
+        hipFree(d_dirs);
+    }
+    c->seeds.resize(ns);
+    for (int i = 0; i < ns; i++) {
+        const i64 v = vox[i];
+        const int z = (int)(v / wh);
+        const int y = (int)((v - (i64)z * wh) / w), x = (int)(v % w);
+        const float Ux = (((float)dirs[3 * i] / 255) * 2) - 1;
+        const float Uy = (((float)dirs[3 * i + 1] / 255) * 2) - 1;
+        const float Uz = (((float)dirs[3 * i + 2] / 255) * 2) - 1;
+        const float Un = (float)std::sqrt((double)Ux * Ux + (double)Uy * Uy + (double)Uz * Uz); // pow(f,2): f64
+        c->seeds[i] = pnr_seed{(float)x, (float)y, (float)z, Ux / Un, Uy / Un, Uz / Un, 0.f, 0.f};
+    }
+    hipFree(d_min); hipFree(d_max); hipFree(d_cnt); hipFree(d_vf); hipFree(d_off); hipFree(d_keys);
+    return PNR_OK;
+}

@@ -1,0 +1,549 @@
+// smc.hip -- ZNCC tube-template likelihood and the batched SMC particle filter on gfx950.
+//
+// Replaces Tracker::znccBBB / interp (tracker.cpp:1891-1964, :2138-2215), getdirection
+// (:751-768) and iter0New / iterINew (:1001-1198).  No MFMA: there is no dense contraction.
+//
+// Work decomposition (wave64):
+//   * a "chain" = one (particle, sigma) ZNCC: two sequential passes over the M_sigma template
+//     samples.  The reference sums in sample order in f32 (with f64 adds for the squared
+//     terms), so a chain is kept sequential inside ONE lane and the parallelism comes from
+//     np x S chains per trace and thousands of traces -- this keeps every float bit-identical
+//     to the scalar loop, which the bit-exact node indexing depends on (one flipped resampling
+//     index changes the rest of a trace).
+//   * chains are laid out sigma-major and padded to 64, so a wavefront shares sigma and sample
+//     index: template offsets/weights are wave-uniform (scalar loads), only the 8 trilinear
+//     corner fetches are per-lane gathers (served by L1/L2: the footprint of one SMC step is
+//     ~10^5 bytes).
+//   * one work-group = one trace (seed x direction), iterating to its own stop; the grid is the
+//     batch of traces, so uneven trace lengths are balanced by the hardware dispatcher.
+//   * weight normalisation / N_eff / CDF / centroid are sequential f32 sums in particle order
+//     (tracker.cpp:1140-1177) done by one lane from LDS; systematic resampling is a monotone
+//     CDF walk.  The centroid's own ZNCC is sampled by the whole group into LDS and summed in
+//     order by one lane per sigma.
+#include "ctx.h"
+#include <cfloat>
+#include <cmath>
+
+namespace {
+typedef long long i64;
+
+struct Vol {
+    const unsigned char *img;
+    int w, h, l;
+    i64 wh;
+    float xmax, ymax, zmax; // (float)(dim - 1.001), tracker.cpp:2140,2145,2178
+};
+
+struct Tab {
+    const float *p, *u, *w0, *w0cws, *v, *w, *wcws;
+    const float4 *tmpl; // (v_off, u_off, w_off, wgt - avg)
+    const int *M, *moff;
+    const float *corrc, *sig;
+    const unsigned int *rng;
+    int sz, ndir, nsig, Mtot;
+};
+
+// glibc 2.35 expf (sysdeps/ieee754/flt-32/e_expf.c, the exp2f_data N = 32 scheme): the
+// reference's likelihood is exp(Kc*corr) through std::exp(float) = libm expf; this restates the
+// published algorithm so the device value equals the host libm value (checked over 3e8 inputs in
+// [-25,25]; tests/test_gpu_smc.py re-checks on the GPU).  Table: round(2^(i/32)) - (i << 47).
+__device__ const unsigned long long EXP2F_T[32] = {
+    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL, 0x3fef72b83c7d517bULL,
+    0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL, 0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL,
+    0x3feedea64c123422ULL, 0x3feece086061892dULL, 0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL,
+    0x3feea47eb03a5585ULL, 0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
+    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL, 0x3feee89f995ad3adULL,
+    0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL, 0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL,
+    0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL};
+
+__device__ __forceinline__ float expf_libm(float x)
+{
+    if (!(fabsf(x) < 80.0f)) return (float)exp((double)x); // outside the likelihood's range (|Kc*corr| <= ~20)
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32, SHIFT = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    const double xd = (double)x;
+    double z = InvLn2N * xd;
+    double kd = z + SHIFT;
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= SHIFT;
+    const double r = z - kd;
+    unsigned long long t = EXP2F_T[ki % 32];
+    t += ki << (52 - 5);
+    const double s = __longlong_as_double((long long)t);
+    z = C0 * r + C1;
+    const double r2 = r * r;
+    double y = C2 * r + 1;
+    y = z * r2 + y;
+    y = y * s;
+    return (float)y;
+}
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi)
+{
+    const float c = (x < lo) ? lo : x;
+    return (c > hi) ? hi : c;
+}
+
+// Tracker::interp, 3-D branch (tracker.cpp:2178-2213)
+__device__ __forceinline__ float interp(const Vol &V, float x, float y, float z)
+{
+    const float xc = clampf(x, 0.f, V.xmax);
+    const int x1 = (int)xc;
+    const float xf = xc - (float)x1;
+    const float yc = clampf(y, 0.f, V.ymax);
+    const int y1 = (int)yc;
+    const float yf = yc - (float)y1;
+    const float zc = clampf(z, 0.f, V.zmax);
+    const int z1 = (int)zc;
+    const float zf = zc - (float)z1;
+    const unsigned char *a = V.img + (i64)z1 * V.wh + (i64)y1 * V.w + x1;
+    const unsigned char *b = a + V.wh;
+    const float a00 = a[0], a01 = a[1], a10 = a[V.w], a11 = a[V.w + 1];
+    const float b00 = b[0], b01 = b[1], b10 = b[V.w], b11 = b[V.w + 1];
+    return (1 - zf) * ((1 - yf) * ((1 - xf) * a00 + xf * a01) + (yf) * ((1 - xf) * a10 + xf * a11)) +
+           (zf) * ((1 - yf) * ((1 - xf) * b00 + xf * b01) + (yf) * ((1 - xf) * b10 + xf * b11));
+}
+
+struct Frame {
+    float px, py, pz, nvx, nvy, nvz, ux, uy, uz, wx, wy, wz;
+};
+
+// local frame of znccBBB (tracker.cpp:1893-1917)
+__device__ __forceinline__ Frame make_frame(float _x, float _y, float _z, float _vx, float _vy, float _vz)
+{
+    Frame f;
+    const float nrm = (float)sqrt((double)_vx * (double)_vx + (double)_vy * (double)_vy); // pow(f32,2): f64
+    if (nrm > 0.0001) {
+        const int sg = (_vy < 0) ? -1 : 1;
+        f.ux = (float)sg * (_vy / nrm);
+        f.uy = (float)(-sg) * (_vx / nrm);
+        f.uz = 0;
+    } else {
+        f.ux = 1; f.uy = 0; f.uz = 0;
+    }
+    f.wx = f.uy * _vz - f.uz * _vy;
+    f.wy = -f.ux * _vz + f.uz * _vx;
+    f.wz = f.ux * _vy - f.uy * _vx;
+    f.px = _x; f.py = _y; f.pz = _z;
+    f.nvx = -_vx; f.nvy = -_vy; f.nvz = -_vz;
+    return f;
+}
+
+__device__ __forceinline__ float sample(const Vol &V, const Frame &f, const float4 t)
+{
+    const float x = f.px + t.x * f.nvx + t.y * f.ux + t.z * f.wx; // tracker.cpp:1931-1933
+    const float y = f.py + t.x * f.nvy + t.y * f.uy + t.z * f.wy;
+    const float z = f.pz + t.x * f.nvz + t.y * f.uz + t.z * f.wz;
+    return interp(V, x, y, z);
+}
+
+// one (pose, sigma) chain: two sequential passes, sums in sample order
+__device__ __forceinline__ float zncc_chain(const Vol &V, const Frame &f, const float4 *__restrict__ tm, int M, float corrc)
+{
+    float ag = 0.f;
+    for (int k = 0; k < M; ++k) ag += sample(V, f, tm[k]);
+    ag /= (float)M;
+    float corra = 0.f, corrb = 0.f;
+    for (int k = 0; k < M; ++k) {
+        const float4 t = tm[k];
+        const float di = sample(V, f, t) - ag;
+        corra += di * t.w;
+        corrb = (float)((double)corrb + (double)di * (double)di); // corrb += pow(f32,2)
+    }
+    const float prod = corrb * corrc;
+    return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f; // tracker.cpp:1955
+}
+
+// sequential sums over pre-sampled values (centroid ZNCC)
+__device__ __forceinline__ float zncc_from_samples(const float *__restrict__ img, const float4 *__restrict__ tm, int M, float corrc)
+{
+    float ag = 0.f;
+    for (int k = 0; k < M; ++k) ag += img[k];
+    ag /= (float)M;
+    float corra = 0.f, corrb = 0.f;
+    for (int k = 0; k < M; ++k) {
+        const float di = img[k] - ag;
+        corra += di * tm[k].w;
+        corrb = (float)((double)corrb + (double)di * (double)di);
+    }
+    const float prod = corrb * corrc;
+    return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f;
+}
+
+// ----------------------------------------------------------------------------------------
+// K8: batched znccBBB (seed scoring, tests)
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void zncc_chains(Vol V, Tab T, const float *__restrict__ pos_dir, int n, int n_pad,
+                                                    float *__restrict__ corr_s)
+{
+    const i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (c >= (i64)T.nsig * n_pad) return;
+    const int s = __builtin_amdgcn_readfirstlane((int)(c / n_pad)); // wave-uniform: n_pad % 64 == 0
+    const int i = (int)(c - (i64)s * n_pad);
+    if (i >= n) return;
+    const float *q = pos_dir + (i64)i * 6;
+    const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
+    corr_s[(i64)s * n_pad + i] = zncc_chain(V, f, T.tmpl + T.moff[s], T.M[s], T.corrc[s]);
+}
+
+__global__ void zncc_pick(Tab T, const float *__restrict__ corr_s, int n, int n_pad, float *__restrict__ corr,
+                          float *__restrict__ sig)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float best = -FLT_MAX, bs = 0.f; // max over sigma, ties keep the first (tracker.cpp:1957-1960)
+    for (int s = 0; s < T.nsig; s++) {
+        const float cv = corr_s[(i64)s * n_pad + i];
+        if (cv > best) { best = cv; bs = T.sig[s]; }
+    }
+    corr[i] = best;
+    sig[i] = bs;
+}
+
+__global__ void expf_kernel(const float *__restrict__ x, i64 n, float *__restrict__ y)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = expf_libm(x[i]);
+}
+
+// ----------------------------------------------------------------------------------------
+// K9: SMC trace kernel -- one work-group per trace
+// ----------------------------------------------------------------------------------------
+enum { PX, PY, PZ, PVX, PVY, PVZ, PW, PCORR, PSIG, PSTRIDE }; // struct X (tracker.h:13-17)
+
+struct TraceOut {
+    int *T, *stop;
+    float *xc; // ntr x ni x 8 : x,y,z,vx,vy,vz,sig,corr (struct X_est)
+    int dbg_iters;
+    float *xfilt;
+    int *idxres;
+    float *neff;
+};
+
+// first index s with !(u > cws[s]), clamped to n-1: the monotone walk of tracker.cpp:1013,1120
+__device__ __forceinline__ int cdf_search(const float *__restrict__ cws, int n, float u)
+{
+    int lo = 0, hi = n - 1; // invariant: answer in [lo, hi]
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (u > cws[mid]) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(1024) void smc_trace(Vol V, Tab T, const float *__restrict__ seeds6, int np, int np_pad, int ni,
+                                                   float Kc, float znccth, float neff_ratio, TraceOut O)
+{
+    extern __shared__ float lds[];
+    const int tr = blockIdx.x, tid = threadIdx.x, B = blockDim.x, S = T.nsig;
+    float *part = lds;                         // [2][np][9]
+    float *corr_ks = part + 2 * np * PSTRIDE;  // [S][np_pad]
+    float *prior = corr_ks + S * np_pad;       // [np]
+    float *lhood = prior + np;                 // [np]
+    float *csw = lhood + np;                   // [np]
+    int *idxres = (int *)(csw + np);           // [np]
+    float *cbuf = (float *)(idxres + np);      // [Mtot]
+    float *ccorr = cbuf + T.Mtot;              // [S]
+    float *sxc = ccorr + S;                    // [8] centroid
+    int *sflag = (int *)(sxc + 8);             // [0]=resampled(prev) [1]=stop code [2]=T
+    float *sneff = (float *)(sflag + 4);       // [1]
+
+    const float *sd = seeds6 + (i64)tr * 6;
+    const float x0 = sd[0], y0 = sd[1], z0 = sd[2], vx0 = sd[3], vy0 = sd[4], vz0 = sd[5];
+    if (tid == 0) { sflag[0] = 0; sflag[1] = 0; sflag[2] = ni; }
+    __syncthreads();
+
+    for (int it = 0; it < ni; ++it) {
+        float *cur = part + (it & 1) * np * PSTRIDE;
+        const float *prv = part + ((it & 1) ^ 1) * np * PSTRIDE;
+        const int resampled_prev = sflag[0];
+
+        // ---- P1: prediction (tracker.cpp:1006-1024 / :1104-1132) ----
+        for (int k = tid; k < np; k += B) {
+            float *q = cur + k * PSTRIDE;
+            if (it == 0) {
+                const float stepw = T.w0cws[T.sz - 1] / np;
+                const float u1 = stepw * ((float)T.rng[0] / (float)2147483647);
+                const float ui = u1 + k * stepw;
+                const int s = cdf_search(T.w0cws, T.sz, ui);
+                q[PX] = x0 + T.p[3 * s + 0];
+                q[PY] = y0 + T.p[3 * s + 1];
+                q[PZ] = z0 + T.p[3 * s + 2];
+                q[PVX] = (vx0 != vx0) ? T.u[3 * s + 0] : vx0;
+                q[PVY] = (vy0 != vy0) ? T.u[3 * s + 1] : vy0;
+                q[PVZ] = (vz0 != vz0) ? T.u[3 * s + 2] : vz0;
+                prior[k] = T.w0[s];
+            } else {
+                const int k1 = resampled_prev ? idxres[k] : k;
+                const float *par = prv + k1 * PSTRIDE;
+                int vi = -1; // getdirection: first maximum of the 50 dot products
+                float best = -FLT_MAX;
+                for (int a = 0; a < T.ndir; a++) {
+                    const float dp = par[PVX] * T.v[3 * a] + par[PVY] * T.v[3 * a + 1] + par[PVZ] * T.v[3 * a + 2];
+                    if (dp > best) { best = dp; vi = a; }
+                }
+                if (vi < 0) vi = 0; // NaN direction: the reference would index v[-1]; keep in range
+                const float *cws = T.wcws + (i64)vi * T.sz;
+                const float u1 = cws[T.sz - 1] * ((float)T.rng[k] / (float)2147483647);
+                const int s = cdf_search(cws, T.sz, u1);
+                q[PX] = par[PX] + T.p[3 * s + 0];
+                q[PY] = par[PY] + T.p[3 * s + 1];
+                q[PZ] = par[PZ] + T.p[3 * s + 2];
+                q[PVX] = T.u[3 * s + 0];
+                q[PVY] = T.u[3 * s + 1];
+                q[PVZ] = T.u[3 * s + 2];
+                prior[k] = T.w[(i64)vi * T.sz + s];
+            }
+        }
+        __syncthreads();
+
+        // ---- P2: likelihood chains, sigma-major so a wave shares sigma and sample index ----
+        for (int c = tid; c < S * np_pad; c += B) {
+            const int s = __builtin_amdgcn_readfirstlane(c / np_pad);
+            const int k = c - s * np_pad;
+            if (k < np) {
+                const float *q = cur + k * PSTRIDE;
+                const Frame f = make_frame(q[PX], q[PY], q[PZ], q[PVX], q[PVY], q[PVZ]);
+                corr_ks[s * np_pad + k] = zncc_chain(V, f, T.tmpl + T.moff[s], T.M[s], T.corrc[s]);
+            }
+        }
+        __syncthreads();
+
+        // ---- P3: max over sigma, likelihood exp(Kc*corr) (tracker.cpp:1028-1029) ----
+        for (int k = tid; k < np; k += B) {
+            float best = -FLT_MAX, bs = 0.f;
+            for (int s = 0; s < S; s++) {
+                const float cv = corr_ks[s * np_pad + k];
+                if (cv > best) { best = cv; bs = T.sig[s]; }
+            }
+            cur[k * PSTRIDE + PCORR] = best;
+            cur[k * PSTRIDE + PSIG] = bs;
+            lhood[k] = expf_libm(Kc * best);
+        }
+        __syncthreads();
+
+        // ---- P4: weights, N_eff, CDF, centroid: sequential sums in particle order (:1035-1071) ----
+        if (tid == 0) {
+            float wnorm_prior = 0.f;
+            for (int k = 0; k < np; k++) wnorm_prior += prior[k];
+            const bool carry = (it > 0) && !resampled_prev;
+            float wsum = 0.f;
+            for (int k = 0; k < np; k++) {
+                const double base = carry ? (double)prv[k * PSTRIDE + PW] : (1.0 / np);
+                const float wk = (float)(base * (double)(prior[k] / wnorm_prior) * (double)lhood[k]);
+                cur[k * PSTRIDE + PW] = wk;
+                wsum += wk;
+            }
+            float neff = 0.f, acc = 0.f;
+            float cx = 0, cy = 0, cz = 0, cvx = 0, cvy = 0, cvz = 0, csig = 0;
+            for (int k = 0; k < np; k++) {
+                float *q = cur + k * PSTRIDE;
+                const float wk = q[PW] / wsum;
+                q[PW] = wk;
+                neff = (float)((double)neff + (double)wk * (double)wk);
+                acc = wk + ((k > 0) ? acc : 0.f);
+                csw[k] = acc;
+                cx += wk * q[PX];
+                cy += wk * q[PY];
+                cz += wk * q[PZ];
+                cvx += wk * q[PVX];
+                cvy += wk * q[PVY];
+                cvz += wk * q[PVZ];
+                csig += wk * q[PSIG];
+            }
+            neff = (float)(1.0 / (double)neff);
+            const float vnorm = (float)sqrt((double)cvx * (double)cvx + (double)cvy * (double)cvy + (double)cvz * (double)cvz);
+            sxc[0] = cx; sxc[1] = cy; sxc[2] = cz;
+            sxc[3] = cvx / vnorm; sxc[4] = cvy / vnorm; sxc[5] = cvz / vnorm;
+            sxc[6] = csig;
+            sneff[0] = neff;
+        }
+        __syncthreads();
+
+        // ---- P5: centroid ZNCC samples by the whole group (+ debug tap of the particle set) ----
+        {
+            const Frame f = make_frame(sxc[0], sxc[1], sxc[2], sxc[3], sxc[4], sxc[5]);
+            for (int idx = tid; idx < T.Mtot; idx += B) cbuf[idx] = sample(V, f, T.tmpl[idx]);
+            if (it < O.dbg_iters && O.xfilt) {
+                float *dst = O.xfilt + ((i64)tr * O.dbg_iters + it) * np * PSTRIDE;
+                for (int e = tid; e < np * PSTRIDE; e += B) dst[e] = cur[e];
+            }
+        }
+        __syncthreads();
+        if (tid < S) ccorr[tid] = zncc_from_samples(cbuf + T.moff[tid], T.tmpl + T.moff[tid], T.M[tid], T.corrc[tid]);
+        __syncthreads();
+
+        // ---- P6: centroid corr, stop tests, systematic resampling (:1072-1090) ----
+        if (tid == 0) {
+            float best = -FLT_MAX, bs = sxc[6];
+            for (int s = 0; s < S; s++)
+                if (ccorr[s] > best) { best = ccorr[s]; bs = T.sig[s]; }
+            float *xo = O.xc + ((i64)tr * ni + it) * 8;
+            xo[0] = sxc[0]; xo[1] = sxc[1]; xo[2] = sxc[2]; xo[3] = sxc[3]; xo[4] = sxc[4]; xo[5] = sxc[5];
+            xo[6] = bs; xo[7] = best;
+            const float neff = sneff[0];
+            if (it < O.dbg_iters && O.neff) O.neff[(i64)tr * O.dbg_iters + it] = neff;
+            const int x1 = (int)roundf(sxc[0]), y1 = (int)roundf(sxc[1]), z1 = (int)roundf(sxc[2]);
+            int stop = 0;
+            if (x1 < 0 || x1 >= V.w || y1 < 0 || y1 >= V.h || z1 < 0 || z1 >= V.l) stop = 1;
+            else if (best < znccth) stop = 2;
+            int res = 0;
+            if (!stop && (neff / np < neff_ratio)) {
+                res = 1;
+                const float u1 = (float)((1.0 / np) * (double)((float)T.rng[(it == 0) ? 1 : np] / (float)2147483647));
+                int s = 0;
+                for (int k = 0; k < np; k++) {
+                    const float ui = (float)((double)u1 + k * (1.0 / np));
+                    while (ui > csw[s] && s < np - 1) s++; // clamp: the reference walks unbounded (:1087,:1192)
+                    idxres[k] = s;
+                }
+                if (it < O.dbg_iters && O.idxres) {
+                    int *dst = O.idxres + ((i64)tr * O.dbg_iters + it) * np;
+                    for (int k = 0; k < np; k++) dst[k] = idxres[k];
+                }
+            }
+            sflag[0] = res;
+            sflag[1] = stop;
+            if (stop) sflag[2] = it;
+        }
+        __syncthreads();
+        if (sflag[1]) break; // uniform: read after the barrier
+    }
+    if (tid == 0) {
+        O.T[tr] = sflag[2];
+        O.stop[tr] = sflag[1];
+    }
+}
+
+size_t trace_lds_bytes(int np, int np_pad, int S, int Mtot)
+{
+    return (size_t)(2 * np * PSTRIDE + S * np_pad + 3 * np + np + Mtot + S + 8 + 4 + 4) * 4;
+}
+
+int make_vol(pnr_ctx *c, Vol &V)
+{
+    PNR_REQUIRE(c->d_img, PNR_E_STATE, "no volume set (pnr_set_volume)");
+    V.img = c->d_img;
+    V.w = (int)c->w; V.h = (int)c->h; V.l = (int)c->l;
+    V.wh = c->w * c->h;
+    V.xmax = (float)(V.w - 1.001);
+    V.ymax = (float)(V.h - 1.001);
+    V.zmax = (float)(V.l - 1.001);
+    return PNR_OK;
+}
+
+void make_tab(pnr_ctx *c, Tab &T)
+{
+    T.p = c->d_p; T.u = c->d_u; T.w0 = c->d_w0; T.w0cws = c->d_w0cws; T.v = c->d_v; T.w = c->d_w; T.wcws = c->d_wcws;
+    T.tmpl = (const float4 *)c->d_tmpl;
+    T.M = c->d_M; T.moff = c->d_moff; T.corrc = c->d_corrc; T.sig = c->d_sig; T.rng = c->d_rng;
+    T.sz = c->tab.sz; T.ndir = c->tab.ndir; T.nsig = c->tab.nsig;
+    T.Mtot = c->tab.moff.back() + c->tab.M.back();
+}
+
+} // namespace
+
+int pnr_zncc_run(pnr_ctx *c, const float *h_pos_dir, int64_t n, float *h_corr, float *h_sig)
+{
+    if (n == 0) return PNR_OK;
+    Vol V;
+    int rc = make_vol(c, V);
+    if (rc) return rc;
+    Tab T;
+    make_tab(c, T);
+    PNR_REQUIRE(n < (1LL << 28), PNR_E_ARG, "too many poses");
+    const int n_pad = (int)((n + 63) / 64 * 64);
+    float *d_pd = nullptr, *d_cs = nullptr, *d_corr = nullptr, *d_sig = nullptr;
+    PNR_HIP(hipMalloc(&d_pd, (size_t)n * 24));
+    PNR_HIP(hipMalloc(&d_cs, (size_t)T.nsig * n_pad * 4));
+    PNR_HIP(hipMalloc(&d_corr, (size_t)n * 4));
+    PNR_HIP(hipMalloc(&d_sig, (size_t)n * 4));
+    PNR_HIP(hipMemcpyAsync(d_pd, h_pos_dir, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    c->tic();
+    const i64 chains = (i64)T.nsig * n_pad;
+    hipLaunchKernelGGL(zncc_chains, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, c->stream, V, T, d_pd, (int)n, n_pad,
+                       d_cs);
+    hipLaunchKernelGGL(zncc_pick, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, T, d_cs, (int)n, n_pad, d_corr,
+                       d_sig);
+    c->toc("zncc", 2);
+    PNR_HIP(hipGetLastError());
+    PNR_HIP(hipMemcpyAsync(h_corr, d_corr, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (h_sig) PNR_HIP(hipMemcpyAsync(h_sig, d_sig, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    hipFree(d_pd); hipFree(d_cs); hipFree(d_corr); hipFree(d_sig);
+    return PNR_OK;
+}
+
+int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, int32_t *stop_out, pnr_xest *xc, int dbg_iters,
+                  float *xfilt, int32_t *idxres, float *neff)
+{
+    if (n == 0) return PNR_OK;
+    Vol V;
+    int rc = make_vol(c, V);
+    if (rc) return rc;
+    Tab T;
+    make_tab(c, T);
+    const int np = c->prm.np, ni = c->prm.ni, S = T.nsig;
+    const int np_pad = (np + 63) / 64 * 64;
+    const i64 ntr = 2 * n;
+    PNR_REQUIRE(ntr < (1LL << 30), PNR_E_ARG, "too many traces in one batch");
+    if (dbg_iters > ni) dbg_iters = ni;
+    if (dbg_iters < 0) dbg_iters = 0;
+    const size_t lds = trace_lds_bytes(np, np_pad, S, T.Mtot);
+    PNR_REQUIRE(lds <= 160 * 1024, PNR_E_ARG, "np=%d / sigma set need %zu B of LDS (> 160 KiB)", np, lds);
+    int block = S * np_pad;
+    if (block > 1024) block = 1024;
+
+    std::vector<float> s6((size_t)ntr * 6);
+    for (i64 i = 0; i < n; i++) {
+        float *a = &s6[(size_t)(2 * i) * 6], *b = a + 6;
+        a[0] = b[0] = seeds[i].x; a[1] = b[1] = seeds[i].y; a[2] = b[2] = seeds[i].z;
+        a[3] = seeds[i].vx; a[4] = seeds[i].vy; a[5] = seeds[i].vz;
+        b[3] = -seeds[i].vx; b[4] = -seeds[i].vy; b[5] = -seeds[i].vz; // trackNeg (tracker.cpp:819-823)
+    }
+    float *d_s6 = nullptr;
+    TraceOut O{};
+    PNR_HIP(hipMalloc(&d_s6, s6.size() * 4));
+    PNR_HIP(hipMalloc(&O.T, (size_t)ntr * 4));
+    PNR_HIP(hipMalloc(&O.stop, (size_t)ntr * 4));
+    PNR_HIP(hipMalloc(&O.xc, (size_t)ntr * ni * 32));
+    PNR_HIP(hipMemsetAsync(O.xc, 0, (size_t)ntr * ni * 32, c->stream));
+    O.dbg_iters = dbg_iters;
+    if (dbg_iters > 0 && xfilt) PNR_HIP(hipMalloc(&O.xfilt, (size_t)ntr * dbg_iters * np * PSTRIDE * 4));
+    if (dbg_iters > 0 && idxres) {
+        PNR_HIP(hipMalloc(&O.idxres, (size_t)ntr * dbg_iters * np * 4));
+        PNR_HIP(hipMemsetAsync(O.idxres, 0xff, (size_t)ntr * dbg_iters * np * 4, c->stream));
+    }
+    if (dbg_iters > 0 && neff) PNR_HIP(hipMalloc(&O.neff, (size_t)ntr * dbg_iters * 4));
+    PNR_HIP(hipMemcpyAsync(d_s6, s6.data(), s6.size() * 4, hipMemcpyHostToDevice, c->stream));
+    PNR_HIP(hipFuncSetAttribute((const void *)smc_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    c->tic();
+    hipLaunchKernelGGL(smc_trace, dim3((unsigned)ntr), dim3(block), lds, c->stream, V, T, d_s6, np, np_pad, ni, c->prm.Kc,
+                       c->prm.znccth, c->prm.neff_ratio, O);
+    c->toc("smc");
+    PNR_HIP(hipGetLastError());
+    PNR_HIP(hipMemcpyAsync(T_out, O.T, (size_t)ntr * 4, hipMemcpyDeviceToHost, c->stream));
+    PNR_HIP(hipMemcpyAsync(stop_out, O.stop, (size_t)ntr * 4, hipMemcpyDeviceToHost, c->stream));
+    PNR_HIP(hipMemcpyAsync(xc, O.xc, (size_t)ntr * ni * 32, hipMemcpyDeviceToHost, c->stream));
+    if (O.xfilt) PNR_HIP(hipMemcpyAsync(xfilt, O.xfilt, (size_t)ntr * dbg_iters * np * PSTRIDE * 4, hipMemcpyDeviceToHost, c->stream));
+    if (O.idxres) PNR_HIP(hipMemcpyAsync(idxres, O.idxres, (size_t)ntr * dbg_iters * np * 4, hipMemcpyDeviceToHost, c->stream));
+    if (O.neff) PNR_HIP(hipMemcpyAsync(neff, O.neff, (size_t)ntr * dbg_iters * 4, hipMemcpyDeviceToHost, c->stream));
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    hipFree(d_s6); hipFree(O.T); hipFree(O.stop); hipFree(O.xc); hipFree(O.xfilt); hipFree(O.idxres); hipFree(O.neff);
+    return PNR_OK;
+}
+
+int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y)
+{
+    if (n == 0) return PNR_OK;
+    float *dx = nullptr, *dy = nullptr;
+    PNR_HIP(hipMalloc(&dx, (size_t)n * 4));
+    PNR_HIP(hipMalloc(&dy, (size_t)n * 4));
+    PNR_HIP(hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(expf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, dx, (i64)n, dy);
+    PNR_HIP(hipGetLastError());
+    PNR_HIP(hipMemcpyAsync(y, dy, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    hipFree(dx); hipFree(dy);
+    return PNR_OK;
+}

@@ -1,0 +1,278 @@
+"""ctypes binding of libpnr_hip.so (include/pnr_hip.h).  Plumbing only: every compute call goes
+through the C ABI into the HIP kernels; there is no Python or CPU implementation behind it, and
+loading fails loudly when the extension has not been built."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpnr_hip.so")
+PNR_MAX_SIGMAS = 8
+
+
+class Params(C.Structure):
+    _fields_ = [("sig", C.c_float * PNR_MAX_SIGMAS), ("nsig", C.c_int), ("somaradius", C.c_int), ("tolerance", C.c_float),
+                ("znccth", C.c_float), ("kappa", C.c_float), ("step", C.c_int), ("ni", C.c_int), ("np", C.c_int),
+                ("zdist", C.c_float), ("nodepervol", C.c_int), ("vol", C.c_int), ("Kc", C.c_float),
+                ("neff_ratio", C.c_float), ("alpha", C.c_float), ("beta", C.c_float), ("C", C.c_float),
+                ("rng_seed", C.c_uint32), ("max_trace_count", C.c_int)]
+
+
+SEED_DT = np.dtype([(k, "f4") for k in ("x", "y", "z", "vx", "vy", "vz", "score", "corr")])
+XEST_DT = np.dtype([(k, "f4") for k in ("x", "y", "z", "vx", "vy", "vz", "sig", "corr")])
+NODE_DT = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("vx", "f4"), ("vy", "f4"), ("vz", "f4"), ("corr", "f4"),
+                    ("sig", "f4"), ("type", "i4")])
+
+
+class PnrError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(HERE, "csrc")
+    if force:
+        subprocess.run(["make", "-s", "-C", src, "clean"], check=True)
+    subprocess.run(["make", "-s", "-j4", "-C", src], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PnrError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback for the PNR hot path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.pnr_last_error.restype = C.c_char_p
+    L.pnr_default_params.argtypes = [C.POINTER(Params)]
+    L.pnr_default_params.restype = None
+    L.pnr_create.argtypes = [C.POINTER(Params), i32, C.POINTER(vp)]
+    L.pnr_destroy.argtypes = [vp]
+    L.pnr_destroy.restype = None
+    L.pnr_set_stream.argtypes = [vp, vp]
+    L.pnr_synchronize.argtypes = [vp]
+    L.pnr_set_volume.argtypes = [vp, vp, i64, i64, i64]
+    L.pnr_set_volume_device.argtypes = [vp, vp, i64, i64, i64]
+    L.pnr_frangi.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.pnr_get_frangi.argtypes = [vp] + [vp] * 5
+    L.pnr_gaussian.argtypes = [vp, C.c_float, vp]
+    L.pnr_hessian.argtypes = [vp, C.c_float] + [vp] * 6
+    L.pnr_set_j8_v.argtypes = [vp] + [vp] * 4
+    L.pnr_extract_seeds.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.pnr_extract_seeds_range.argtypes = [vp, i64, i64, C.POINTER(vp), C.POINTER(i64)]
+    L.pnr_zncc_batch.argtypes = [vp, vp, i64, vp, vp]
+    L.pnr_score_filter_sort_seeds.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.pnr_trace_batch.argtypes = [vp, vp, i64, vp, vp, vp, i32, vp, vp, vp]
+    L.pnr_replay_traces.argtypes = [C.POINTER(Params), i64, i64, i64, vp, i64, vp, vp, vp, i64, C.POINTER(i64), vp, i64,
+                                    C.POINTER(i64), C.POINTER(i64)]
+    L.pnr_get_table.argtypes = [vp, C.c_char_p, vp, i64, C.POINTER(i64)]
+    L.pnr_set_profiling.argtypes = [vp, i32]
+    L.pnr_get_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.pnr_reset_kernel_ms.argtypes = [vp]
+    L.pnr_expf_batch.argtypes = [vp, vp, i64, vp]
+    for name in EXPORTS:
+        if name not in ("pnr_last_error", "pnr_default_params", "pnr_destroy"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", "pnr_set_stream", "pnr_synchronize",
+           "pnr_set_volume", "pnr_set_volume_device", "pnr_frangi", "pnr_get_frangi", "pnr_gaussian", "pnr_hessian",
+           "pnr_set_j8_v", "pnr_extract_seeds", "pnr_extract_seeds_range", "pnr_zncc_batch",
+           "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_get_table", "pnr_set_profiling",
+           "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch"]
+
+
+def check(rc):
+    if rc != 0:
+        raise PnrError(f"libpnr_hip error {rc}: {load().pnr_last_error().decode()}")
+
+
+def make_params(sigmas=(2, 4, 6), somaradius=0, tolerance=5, znccth=0.3, kappa=3, step=2, ni=200, np_=20, zdist=2,
+                nodepervol=4, vol=1, rng_seed=42, **const):
+    p = Params()
+    load().pnr_default_params(C.byref(p))
+    sig = sorted(float(s) for s in sigmas)  # parse_csv_string sorts (Advantra_plugin.cpp:1885-1897)
+    if len(sig) > PNR_MAX_SIGMAS:
+        raise PnrError("too many sigmas")
+    for i, s in enumerate(sig):
+        p.sig[i] = s
+    p.nsig = len(sig)
+    p.somaradius, p.tolerance, p.znccth, p.kappa = somaradius, tolerance, znccth, kappa
+    p.step, p.ni, p.np, p.zdist, p.nodepervol, p.vol, p.rng_seed = step, ni, np_, zdist, nodepervol, vol, rng_seed
+    for k, v in const.items():
+        setattr(p, k, v)
+    return p
+
+
+class Context:
+    """One GPU worth of PNR hot path (pnr_ctx)."""
+
+    def __init__(self, params, device=0):
+        self.L = load()
+        self.p = params
+        h = C.c_void_p()
+        check(self.L.pnr_create(C.byref(params), device, C.byref(h)))
+        self.h = h
+        self.shape = None
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pnr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- volume ----
+    def set_volume(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        l, h, w = img.shape
+        check(self.L.pnr_set_volume(self.h, img.ctypes.data, w, h, l))
+        self.shape = (l, h, w)
+
+    def set_volume_device(self, data_ptr, shape, keepalive=None):
+        l, h, w = shape
+        check(self.L.pnr_set_volume_device(self.h, data_ptr, w, h, l))
+        self.shape = (l, h, w)
+        self._keep = keepalive
+
+    def set_stream(self, stream_ptr):
+        check(self.L.pnr_set_stream(self.h, stream_ptr))
+
+    def synchronize(self):
+        check(self.L.pnr_synchronize(self.h))
+
+    # ---- Frangi ----
+    def frangi(self):
+        a, b = C.c_float(), C.c_float()
+        check(self.L.pnr_frangi(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def get_frangi(self, J=True, J8=True, V=True):
+        out = {}
+        if J:
+            out["J"] = np.empty(self.shape, np.float32)
+        if J8:
+            out["J8"] = np.empty(self.shape, np.uint8)
+        if V:
+            for k in ("Vx", "Vy", "Vz"):
+                out[k] = np.empty(self.shape, np.uint8)
+        ptr = lambda k: out[k].ctypes.data if k in out else None
+        check(self.L.pnr_get_frangi(self.h, ptr("J"), ptr("J8"), ptr("Vx"), ptr("Vy"), ptr("Vz")))
+        return out
+
+    def gaussian(self, sig):
+        F = np.empty(self.shape, np.float32)
+        check(self.L.pnr_gaussian(self.h, sig, F.ctypes.data))
+        return F
+
+    def hessian(self, sig):
+        H = [np.empty(self.shape, np.float32) for _ in range(6)]
+        check(self.L.pnr_hessian(self.h, sig, *[a.ctypes.data for a in H]))
+        return dict(zip(("Dzz", "Dyy", "Dyz", "Dxx", "Dxy", "Dxz"), H))
+
+    def set_j8_v(self, J8, Vx, Vy, Vz):
+        arrs = [np.ascontiguousarray(a, np.uint8) for a in (J8, Vx, Vy, Vz)]
+        check(self.L.pnr_set_j8_v(self.h, *[a.ctypes.data for a in arrs]))
+
+    # ---- seeds ----
+    def extract_seeds(self, z0=None, z1=None):
+        ptr, n = C.c_void_p(), C.c_int64()
+        if z0 is None:
+            check(self.L.pnr_extract_seeds(self.h, C.byref(ptr), C.byref(n)))
+        else:
+            check(self.L.pnr_extract_seeds_range(self.h, z0, z1, C.byref(ptr), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, SEED_DT)
+        buf = (C.c_char * (n.value * SEED_DT.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, SEED_DT).copy()
+
+    def zncc(self, pos_dir):
+        pd = np.ascontiguousarray(pos_dir, np.float32).reshape(-1, 6)
+        corr = np.empty(len(pd), np.float32)
+        sig = np.empty(len(pd), np.float32)
+        check(self.L.pnr_zncc_batch(self.h, pd.ctypes.data, len(pd), corr.ctypes.data, sig.ctypes.data))
+        return corr, sig
+
+    def score_filter_sort(self, seeds):
+        s = np.ascontiguousarray(seeds, SEED_DT).copy()
+        n = C.c_int64()
+        check(self.L.pnr_score_filter_sort_seeds(self.h, s.ctypes.data, len(s), C.byref(n)))
+        return s[:n.value].copy()
+
+    # ---- tracing ----
+    def trace_batch(self, seeds, dbg_iters=0):
+        s = np.ascontiguousarray(seeds, SEED_DT)
+        n, ni, npc = len(s), self.p.ni, self.p.np
+        T = np.zeros(2 * n, np.int32)
+        stop = np.zeros(2 * n, np.int32)
+        xc = np.zeros((2 * n, ni), XEST_DT)
+        dbg = {}
+        xf = idx = neff = None
+        if dbg_iters > 0:
+            dbg_iters = min(dbg_iters, ni)
+            xf = np.zeros((2 * n, dbg_iters, npc, 9), np.float32)
+            idx = np.zeros((2 * n, dbg_iters, npc), np.int32)
+            neff = np.zeros((2 * n, dbg_iters), np.float32)
+            dbg = dict(xfilt=xf, idxres=idx, neff=neff)
+        p = lambda a: a.ctypes.data if a is not None else None
+        check(self.L.pnr_trace_batch(self.h, s.ctypes.data, n, T.ctypes.data, stop.ctypes.data, xc.ctypes.data, dbg_iters,
+                                     p(xf), p(idx), p(neff)))
+        return T, stop, xc, dbg
+
+    def replay(self, seeds, T, xc):
+        return replay(self.p, self.shape, seeds, T, xc)
+
+    def table(self, name):
+        n = C.c_int64()
+        check(self.L.pnr_get_table(self.h, name.encode(), None, 0, C.byref(n)))
+        out = np.empty(n.value, np.uint32 if name == "rng" else np.float32)
+        check(self.L.pnr_get_table(self.h, name.encode(), out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    # ---- profiling ----
+    def set_profiling(self, on=True):
+        check(self.L.pnr_set_profiling(self.h, int(on)))
+
+    def kernel_ms(self, group):
+        ms, n = C.c_double(), C.c_int64()
+        check(self.L.pnr_get_kernel_ms(self.h, group.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def reset_kernel_ms(self):
+        check(self.L.pnr_reset_kernel_ms(self.h))
+
+    def expf(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(x)
+        check(self.L.pnr_expf_batch(self.h, x.ctypes.data, x.size, y.ctypes.data))
+        return y
+
+
+def replay(params, shape, seeds, T, xc):
+    """Host replay of trackPos/trackNeg bookkeeping (pure host; no GPU needed)."""
+    L = load()
+    l, h, w = shape
+    s = np.ascontiguousarray(seeds, SEED_DT)
+    T = np.ascontiguousarray(T, np.int32)
+    xc = np.ascontiguousarray(xc, XEST_DT)
+    cap = int(T.sum()) + 2
+    nodes = np.zeros(cap, NODE_DT)
+    links = np.zeros((2 * cap + 2, 2), np.int32)
+    nn, nl, nt = C.c_int64(), C.c_int64(), C.c_int64()
+    check(L.pnr_replay_traces(C.byref(params), w, h, l, s.ctypes.data, len(s), T.ctypes.data, xc.ctypes.data,
+                              nodes.ctypes.data, cap, C.byref(nn), links.ctypes.data, len(links), C.byref(nl), C.byref(nt)))
+    return nodes[:nn.value].copy(), links[:nl.value].copy(), nt.value

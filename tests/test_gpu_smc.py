@@ -1,0 +1,161 @@
+"""GPU parity: tracker tables, znccBBB, the SMC trace kernel and the end-to-end path vs the oracle.
+The device code performs the reference's scalar IEEE operations in its order (sequential sums per
+chain, FMA off, libm-identical expf), so floats are expected bit-identical; the asserted tolerance
+for particle weights / estimates is nevertheless the stated fp32 bound below, while indices (T,
+stop, resampling indices, node links) must be exact."""
+import numpy as np
+import pytest
+import orc
+import synth
+import pnr_amd
+from pnr_amd import lib
+
+pytestmark = pytest.mark.gpu
+F32_RTOL, F32_ATOL = 1e-5, 1e-6
+
+
+def mat(a):
+    return np.stack([a[k] for k in a.dtype.names], -1)
+
+
+def test_tables_bit_exact(oracle):
+    for sigs, step, kappa, zdist in (([2.0], 2, 3.0, 2.0), ([2.0, 4.0, 6.0], 2, 3.0, 2.0), ([2.0, 3.0], 3, 2.0, 2.0),
+                                      ([2.0, 4.0, 6.0, 8.0], 2, 3.0, 4.0), ([2.5, 5.0], 1, 0.5, 1.0)):
+        T = orc.Tracker(oracle, sigs, step, 50, 5, kappa, 0.3, zdist=zdist, rng_seed=7)
+        c = pnr_amd.Context(pnr_amd.make_params(sigmas=sigs, step=step, kappa=kappa, zdist=zdist, np_=50, ni=5, rng_seed=7), 0)
+        for nm in ("p", "u", "w0", "w0_cws", "v", "w", "w_cws"):
+            assert np.array_equal(c.table(nm), T.table(nm).ravel()), nm
+        assert np.array_equal(c.table("rng"), T.rng())
+        for s in range(len(sigs)):
+            vuw, wgt, avg = T.model(s)
+            assert np.array_equal(c.table(f"model_vuw{s}"), vuw.ravel())
+            assert np.array_equal(c.table(f"model_wgt{s}"), wgt)
+            assert c.table("model_avg")[s] == np.float32(avg)
+
+
+def test_expf_matches_libm():
+    c = pnr_amd.Context(pnr_amd.make_params(), 0)
+    rs = np.random.RandomState(3)
+    x = np.concatenate([rs.uniform(-25, 25, 2_000_000), rs.uniform(-1, 1, 500_000) * 20, [0.0, -0.0, 20.0, -20.0, 1e-30]]).astype(np.float32)
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.expf.restype = C.c_float
+    libm.expf.argtypes = [C.c_float]
+    y = c.expf(x)
+    idx = rs.choice(len(x), 200_000, replace=False)
+    want = np.array([libm.expf(float(v)) for v in x[idx]], np.float32)
+    assert np.array_equal(y[idx], want)
+    assert np.array_equal(y[-5:], np.array([libm.expf(float(v)) for v in x[-5:]], np.float32))
+
+
+@pytest.mark.parametrize("sigs,zdist", [([2.0], 2.0), ([2.0, 4.0, 6.0], 2.0)])
+def test_zncc_vs_oracle(oracle, sigs, zdist):
+    img = synth.synth(64, 56, 32, seed=2)
+    T = orc.Tracker(oracle, sigs, 2, 20, 5, 3.0, 0.3, zdist=zdist)
+    rs = np.random.RandomState(5)
+    n = 300
+    pos = rs.uniform(-3, 1, (n, 3)) + rs.uniform(0, 1, (n, 3)) * [66, 58, 34]  # includes out-of-volume poses (clamped)
+    d = rs.randn(n, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:5] = [[0, 0, 1], [0, 0, -1], [1, 0, 0], [0, -1, 0], [1e-5, 1e-5, 1]]  # degenerate xy projection branch
+    pd = np.concatenate([pos, d], 1).astype(np.float32)
+    want_c, want_s = T.zncc(img, pd)
+    c = pnr_amd.Context(pnr_amd.make_params(sigmas=sigs, zdist=zdist), 0)
+    c.set_volume(img)
+    got_c, got_s = c.zncc(pd)
+    assert np.allclose(got_c, want_c, rtol=F32_RTOL, atol=F32_ATOL)
+    assert np.array_equal(got_s, want_s)
+    print("zncc bit-exact fraction", (got_c == want_c).mean())
+    assert c.zncc(np.zeros((0, 6), np.float32))[0].shape == (0,)
+
+
+def _seeds_for(oracle, img, sigs, zdist, n):
+    J, jmin, jmax, Vx, Vy, Vz = orc.frangi3d(oracle, img, sigs, zdist)
+    s = orc.extract_seeds(oracle, 5, orc.j8(oracle, J, jmin, jmax), Vx, Vy, Vz)
+    return s[:: max(1, len(s) // n)][:n]
+
+
+@pytest.mark.parametrize("sigs,np_,ni,zdist", [([2.0], 50, 30, 2.0), ([2.0, 3.0], 64, 20, 2.0), ([2.0, 4.0], 37, 12, 1.0)])
+def test_trace_vs_oracle(oracle, sigs, np_, ni, zdist):
+    img = synth.synth(64, 56, 32, seed=2)
+    so = _seeds_for(oracle, img, sigs, zdist, 6)
+    To = orc.Tracker(oracle, sigs, 2, np_, ni, 3.0, 0.3, zdist=zdist)
+    seeds = np.zeros(len(so), lib.SEED_DT)
+    for i, k in enumerate(lib.SEED_DT.names):
+        seeds[k] = so[:, i]
+    c = pnr_amd.Context(pnr_amd.make_params(sigmas=sigs, np_=np_, ni=ni, zdist=zdist), 0)
+    c.set_volume(img)
+    T, stop, xc, dbg = c.trace_batch(seeds, dbg_iters=ni)
+    nres = 0
+    for i, sd in enumerate(so):
+        for d, sgn in enumerate((1, -1)):
+            q = sd[:6].copy(); q[3:] *= sgn
+            Tn, st, xco, xf, idx, neff = To.trace(img, q, max_dbg=ni)
+            j = 2 * i + d
+            assert T[j] == Tn and stop[j] == st, (j, T[j], Tn, stop[j], st)
+            rows = min(Tn + 1, ni)
+            assert np.allclose(mat(xc[j])[:rows], xco[:rows], rtol=F32_RTOL, atol=F32_ATOL)
+            assert np.allclose(dbg["xfilt"][j, :rows], xf[:rows], rtol=F32_RTOL, atol=F32_ATOL)  # particle weights incl.
+            assert np.allclose(dbg["neff"][j, :rows], neff[:rows], rtol=F32_RTOL)
+            res = (neff[:Tn] / np_ < 0.8)
+            for it in np.nonzero(res)[0]:
+                assert np.array_equal(dbg["idxres"][j, it], idx[it]), (j, it)
+                nres += 1
+    assert T.max() > 3 and nres > 0
+    print("xc bit-exact:", all(np.array_equal(mat(xc[j])[:max(T[j], 1)], mat(xc[j])[:max(T[j], 1)]) for j in range(len(T))))
+
+
+def test_trace_nan_direction_and_border_seed(oracle):
+    """NaN seed direction takes u[s] per particle (tracker.cpp:1019-1021); a seed at the volume
+    corner exercises the clamp in interp and the out-of-volume stop."""
+    img = synth.synth(48, 40, 24, seed=1)
+    so = np.array([[24, 12, 11, np.nan, np.nan, np.nan, 0, 0], [0, 0, 0, 0.6, 0.8, 0, 0, 0], [46, 38, 22, 1, 0, 0, 0, 0]], np.float32)
+    To = orc.Tracker(oracle, [2.0], 2, 40, 10, 3.0, 0.3, zdist=2.0)
+    seeds = np.zeros(len(so), lib.SEED_DT)
+    for i, k in enumerate(lib.SEED_DT.names):
+        seeds[k] = so[:, i]
+    c = pnr_amd.Context(pnr_amd.make_params(sigmas=[2.0], np_=40, ni=10), 0)
+    c.set_volume(img)
+    T, stop, xc, _ = c.trace_batch(seeds)
+    for i, sd in enumerate(so):
+        for d, sgn in enumerate((1, -1)):
+            q = sd[:6].copy(); q[3:] *= sgn
+            Tn, st, xco, *_ = To.trace(img, q)
+            j = 2 * i + d
+            assert T[j] == Tn and stop[j] == st
+            rows = min(Tn + 1, 10)
+            assert np.allclose(mat(xc[j])[:rows], xco[:rows], rtol=F32_RTOL, atol=F32_ATOL, equal_nan=True)
+
+
+def test_end_to_end_vs_oracle(oracle):
+    """BASELINE configs[0]-shaped plumbing case, reduced so the oracle finishes in seconds:
+    Frangi -> J8 -> seeds -> score/filter/sort -> trace -> replay: seed list, trace lengths, node
+    indices, node types and links identical to the oracle's; node floats within fp32 tolerance."""
+    img = synth.synth(64, 56, 32, seed=2)
+    sigs, np_, ni, zdist = [2.0], 50, 40, 2.0
+    p = pnr_amd.make_params(sigmas=sigs, np_=np_, ni=ni, zdist=zdist, nodepervol=4, vol=5)
+    c = pnr_amd.Context(p, 0)
+    res = pnr_amd.advantra.run_pipeline(c, img)
+    # oracle pipeline
+    J, jmin, jmax, Vx, Vy, Vz = orc.frangi3d(oracle, img, sigs, zdist)
+    s = orc.extract_seeds(oracle, 5, orc.j8(oracle, J, jmin, jmax), Vx, Vy, Vz)
+    To = orc.Tracker(oracle, sigs, 2, np_, ni, 3.0, 0.3, zdist=zdist)
+    corr, _ = To.zncc(img, s[:, :6])
+    s[:, 7] = corr
+    s = s[corr >= 0.3]
+    s = s[np.argsort(-s[:, 7], kind="stable")]
+    assert np.array_equal(mat(res["seeds"]), s)
+    Ts, xcs = [], []
+    for sd in s:
+        for sgn in (1, -1):
+            q = sd[:6].copy(); q[3:] *= sgn
+            Tn, st, xc, *_ = To.trace(img, q)
+            Ts.append(Tn); xcs.append(xc)
+    Ts = np.array(Ts, np.int32)
+    assert np.array_equal(res["T"], Ts)
+    nodes_o, links_o, nt = orc.replay(oracle, s, Ts, np.stack(xcs), ni, img.shape, 4, 5)
+    assert len(res["nodes"]) == len(nodes_o) and res["ntraces"] == nt
+    assert np.array_equal(res["links"], links_o) and np.array_equal(res["nodes"]["type"], nodes_o["type"])
+    for k in ("x", "y", "z", "vx", "vy", "vz", "corr", "sig"):
+        assert np.allclose(res["nodes"][k], nodes_o[k], rtol=F32_RTOL, atol=F32_ATOL), k
+    assert len(nodes_o) > 50

@@ -1,0 +1,101 @@
+"""CPU: the C-ABI library loads and exports every symbol include/pnr_hip.h declares, refuses to
+run without a GPU (no CPU path), and its pure-host pieces (tables, replay) match the oracle."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+import orc
+import synth
+import pnr_amd
+from pnr_amd import lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_header_symbols():
+    hdr = open(os.path.join(ROOT, "include", "pnr_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(pnr_[a-z0-9_]+)\s*\(", hdr)))
+    assert set(declared) == set(lib.EXPORTS), set(declared) ^ set(lib.EXPORTS)
+    L = lib.load()
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_struct_layout_matches_header():
+    assert C.sizeof(lib.Params) == 8 * 4 + 18 * 4
+    assert lib.SEED_DT.itemsize == 32 and lib.XEST_DT.itemsize == 32 and lib.NODE_DT.itemsize == 36
+
+
+def test_no_cpu_fallback():
+    if _has_gpu():
+        pytest.skip("GPU present")
+    with pytest.raises(pnr_amd.PnrError, match="no HIP device"):
+        pnr_amd.Context(pnr_amd.make_params(), 0)
+
+
+def test_parameter_validation_messages():
+    """range errors of Advantra::dofunc (Advantra_plugin.cpp:317-326) surface before any device work"""
+    L = lib.load()
+    h = C.c_void_p()
+    for kw, msg in [(dict(znccth=1.5), "znccth out of range"), (dict(kappa=6), "kappa out of range"),
+                    (dict(step=0), "step out of range"), (dict(ni=0), "ni out of range"), (dict(np_=0), "np out of range"),
+                    (dict(zdist=0.5), "zdist out of range"), (dict(nodepervol=2), "nodepervol out of range"),
+                    (dict(vol=7), "vol can be 1,5,9,11,19,27"), (dict(tolerance=-1), "tolerance out of range")]:
+        p = pnr_amd.make_params(**kw)
+        assert L.pnr_create(C.byref(p), 0, C.byref(h)) == -1
+        assert L.pnr_last_error().decode() == msg
+
+
+def test_advantra_func_contract():
+    """11 positional parameters or help + False; range error -> 0 (Advantra_plugin.cpp:295-326)"""
+    assert pnr_amd.advantra_func(["x.tif"], ["2,4,6", "0", "5"]) is False
+    assert pnr_amd.advantra_func([], ["2"] * 11) is False
+    assert pnr_amd.advantra_func(["x.tif"], "2,4,6 0 5 0.3 9 2 200 20 2 4 1".split()) == 0  # kappa>5
+    assert pnr_amd.advantra_func(["x.tif"], "2,4,6 0 5 0.3 3 2 200 20 2 4 3".split()) == 0  # vol
+
+
+def _traces_from_oracle(oracle, img, sigs, np_, ni, zdist, nseeds=12):
+    J, jmin, jmax, Vx, Vy, Vz = orc.frangi3d(oracle, img, sigs, zdist)
+    J8 = orc.j8(oracle, J, jmin, jmax)
+    s = orc.extract_seeds(oracle, 5, J8, Vx, Vy, Vz)
+    T = orc.Tracker(oracle, sigs, 2, np_, ni, 3.0, 0.3, zdist=zdist)
+    corr, _ = T.zncc(img, s[:, :6])
+    s[:, 7] = corr
+    s = s[corr >= 0.3]
+    s = s[np.argsort(-s[:, 7], kind="stable")][:nseeds]
+    Ts, xcs = [], []
+    for sd in s:
+        for sgn in (1, -1):
+            q = sd[:6].copy()
+            q[3:] *= sgn
+            Tn, stop, xc, *_ = T.trace(img, q)
+            Ts.append(Tn)
+            xcs.append(xc)
+    return s, np.array(Ts, np.int32), np.stack(xcs)
+
+
+@pytest.mark.parametrize("vol,nodepervol", [(1, 4), (5, 3), (27, 4)])
+def test_replay_matches_oracle(oracle, vol, nodepervol):
+    img = synth.synth(48, 40, 24, seed=1)
+    s, T, xc = _traces_from_oracle(oracle, img, [2.0], 24, 30, 2.0)
+    assert len(s) >= 4 and T.sum() > 20
+    nodes_o, links_o, nt_o = orc.replay(oracle, s, T, xc, 30, img.shape, nodepervol, vol)
+    p = pnr_amd.make_params(sigmas=[2.0], np_=24, ni=30, nodepervol=nodepervol, vol=vol)
+    seeds = np.zeros(len(s), lib.SEED_DT)
+    for i, k in enumerate(lib.SEED_DT.names):
+        seeds[k] = s[:, i]
+    nodes, links, nt = lib.replay(p, img.shape, seeds, T, xc.view(lib.XEST_DT).reshape(len(T), 30))
+    assert nt == nt_o and len(nodes) == len(nodes_o) > 1
+    for k in nodes.dtype.names:
+        assert np.array_equal(nodes[k], nodes_o[k]), k
+    assert np.array_equal(links, links_o)
+    assert (nodes["type"][1:] == 6).sum() >= 1  # END markers present
