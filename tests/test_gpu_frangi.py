@@ -71,16 +71,23 @@ def test_frangi_constant_volume():
     assert jmin == 0 and jmax == 0 and g["J"].max() == 0 and g["J8"].max() == 0
 
 
-def test_frangi_scale_linearity_property():
-    """size-independent property at a larger size: mirrored input gives mirrored J8; tubes respond."""
+def test_frangi_properties_larger():
+    """size-independent properties at a larger size: (1) re-running gives identical bytes
+    (idempotent state, no stale J from the previous run); (2) a y-mirrored input gives the mirrored
+    J8 up to rounding of the (order-dependent) f32 tap sums: |diff| <= 1 level on < 1% of voxels;
+    (3) the response is on the tubes: maximum 255, mostly-zero background."""
     img = synth.synth(160, 96, 48, seed=6)
     c = ctx_for([2.0, 4.0], 2.0)
     c.set_volume(img)
     c.frangi()
     a = c.get_frangi()
+    c.frangi()
+    a2 = c.get_frangi()
+    for k in a:
+        assert np.array_equal(a[k], a2[k]), k
     c.set_volume(np.ascontiguousarray(img[:, ::-1, :]))
     c.frangi()
     b = c.get_frangi()
-    assert np.array_equal(a["J8"], b["J8"][:, ::-1, :])  # y-mirror symmetry of the whole filter chain
-    assert np.array_equal(a["Vz"], b["Vz"][:, ::-1, :]) or True  # eigenvector sign is solver-defined: not asserted
+    d = np.abs(a["J8"].astype(int) - b["J8"][:, ::-1, :].astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01
     assert a["J8"].max() == 255 and (a["J8"] > 0).mean() < 0.5
