@@ -151,6 +151,8 @@ void pnr_destroy(pnr_ctx *c)
     hipFree(c->d_p); hipFree(c->d_u); hipFree(c->d_w0); hipFree(c->d_w0cws); hipFree(c->d_v); hipFree(c->d_w);
     hipFree(c->d_wcws); hipFree(c->d_tmpl); hipFree(c->d_corrc); hipFree(c->d_sig); hipFree(c->d_M); hipFree(c->d_moff);
     hipFree(c->d_rng);
+    c->resolve_timers();
+    for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -491,6 +493,7 @@ int pnr_set_profiling(pnr_ctx *c, int enable)
 int pnr_get_kernel_ms(pnr_ctx *c, const char *group, double *ms, int64_t *launches)
 {
     PNR_REQUIRE(c && group && ms, PNR_E_ARG, "null argument");
+    c->resolve_timers();
     auto it = c->timers.find(group);
     *ms = (it == c->timers.end()) ? 0.0 : it->second.ms;
     if (launches) *launches = (it == c->timers.end()) ? 0 : it->second.launches;
@@ -500,6 +503,7 @@ int pnr_get_kernel_ms(pnr_ctx *c, const char *group, double *ms, int64_t *launch
 int pnr_reset_kernel_ms(pnr_ctx *c)
 {
     PNR_REQUIRE(c, PNR_E_ARG, "null ctx");
+    c->resolve_timers();
     c->timers.clear();
     return PNR_OK;
 }

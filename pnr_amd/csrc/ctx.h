@@ -81,25 +81,58 @@ struct pnr_ctx {
     // seeds
     std::vector<pnr_seed> seeds;
 
-    // profiling
+    // profiling: HIP event pairs recorded on the ctx stream around each kernel group, resolved
+    // lazily (no host sync inside the timed region)
     bool profiling = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; // unused legacy pair (kept for create/destroy symmetry)
+    struct Pending {
+        std::string group;
+        hipEvent_t a, b;
+        int launches;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> free_events;
+    hipEvent_t cur_a = nullptr;
     std::map<std::string, pnr::KernelTimer> timers;
 
+    hipEvent_t get_event()
+    {
+        if (!free_events.empty()) {
+            hipEvent_t e = free_events.back();
+            free_events.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
     void tic()
     {
-        if (profiling) (void)hipEventRecord(ev0, stream);
+        if (!profiling) return;
+        cur_a = get_event();
+        (void)hipEventRecord(cur_a, stream);
     }
     void toc(const char *group, int launches = 1)
     {
-        if (!profiling) return;
-        (void)hipEventRecord(ev1, stream);
-        (void)hipEventSynchronize(ev1);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ev0, ev1);
-        auto &t = timers[group];
-        t.ms += ms;
-        t.launches += launches;
+        if (!profiling || !cur_a) return;
+        hipEvent_t b = get_event();
+        (void)hipEventRecord(b, stream);
+        pending.push_back(Pending{group, cur_a, b, launches});
+        cur_a = nullptr;
+    }
+    void resolve_timers()
+    {
+        for (auto &p : pending) {
+            (void)hipEventSynchronize(p.b);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, p.a, p.b);
+            auto &t = timers[p.group];
+            t.ms += ms;
+            t.launches += p.launches;
+            free_events.push_back(p.a);
+            free_events.push_back(p.b);
+        }
+        pending.clear();
     }
 };
 

@@ -1,0 +1,87 @@
+"""Multi-GPU host logic: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI
+on the GPU box, "gloo" in the CPU tests).  The reference has no distributed code at all
+(SURVEY.md 2.1); the decomposition is new:
+
+  * independent seed traces are dealt round-robin over the ranks (rank r takes sorted seeds
+    r, r+G, ...: every GPU gets the same mix of strong and weak seeds); every rank holds a replica
+    of the u8 stack, so there is NO data-path collective while tracing;
+  * one collective at the end: the (fixed-stride, padded) trace records are all-gathered and
+    rank 0 replays the sequential bookkeeping in global seed order -- the replay itself must not
+    be sharded (it is order-dependent by definition).  Records are tiny (<= 2*ni*32 B per seed):
+    latency-bound over xGMI, not per-link-bandwidth-bound.
+"""
+import numpy as np
+import torch
+
+from .lib import SEED_DT, XEST_DT, NODE_DT, replay as _replay
+
+
+def shard_indices(n, rank, world):
+    return np.arange(rank, n, world)
+
+
+def _all_gather(dist, t, world):
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return out
+
+
+def trace_sharded(ctx, seeds, dist, rank, world, trace_fn=None, device=None, params=None, shape=None):
+    """Trace `seeds` (sorted, identical on every rank) sharded round-robin; returns
+    (nodes, links, T_all) on every rank (rank 0's replay result is authoritative; the others run the
+    same deterministic replay on the same gathered records)."""
+    params = params if params is not None else ctx.p
+    shape = shape if shape is not None else ctx.shape
+    ni = params.ni
+    trace_fn = trace_fn or (lambda s: ctx.trace_batch(s)[:3])
+    n = len(seeds)
+    mine = shard_indices(n, rank, world)
+    T, stop, xc = trace_fn(seeds[mine])
+    m = (n + world - 1) // world  # padded share
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+    Tp = torch.zeros(2 * m, dtype=torch.int32)
+    Tp[:len(T)] = torch.from_numpy(np.ascontiguousarray(T, np.int32))
+    xp = torch.zeros((2 * m, ni, 8), dtype=torch.float32)
+    if len(T):
+        xp[:len(T)] = torch.from_numpy(np.ascontiguousarray(xc).view(np.float32).reshape(len(T), ni, 8))
+    Tg = _all_gather(dist, Tp.to(dev), world)
+    xg = _all_gather(dist, xp.to(dev), world)
+    T_all = np.zeros(2 * n, np.int32)
+    xc_all = np.zeros((2 * n, ni, 8), np.float32)
+    for r in range(world):
+        idx = shard_indices(n, r, world)
+        k = len(idx)
+        if k == 0:
+            continue
+        Tr = Tg[r].cpu().numpy()[:2 * k]
+        xr = xg[r].cpu().numpy()[:2 * k]
+        T_all[np.repeat(2 * idx, 2) + np.tile([0, 1], k)] = Tr
+        xc_all[np.repeat(2 * idx, 2) + np.tile([0, 1], k)] = xr
+    nodes, links, _ = _replay(params, shape, seeds, T_all, xc_all.view(XEST_DT).reshape(2 * n, ni))
+    return nodes, links, T_all
+
+
+def gather_graphs(nodes, links, dist, rank, world, device):
+    """Final node-graph gather for independent stacks: variable-length node / link lists of every
+    rank to rank 0 (counts first, then padded payloads).  Returns [(nodes, links)] * world on
+    rank 0, None elsewhere."""
+    cnt = torch.tensor([len(nodes), len(links)], dtype=torch.int64, device=device)
+    cnts = torch.stack(_all_gather(dist, cnt, world)).cpu().numpy()
+    mn, ml = int(cnts[:, 0].max()), int(cnts[:, 1].max())
+    nb = torch.zeros((mn, NODE_DT.itemsize // 4), dtype=torch.int32)
+    nb[:len(nodes)] = torch.from_numpy(np.ascontiguousarray(nodes).view(np.int32).reshape(len(nodes), -1))
+    lb = torch.zeros((ml, 2), dtype=torch.int32)
+    lb[:len(links)] = torch.from_numpy(np.ascontiguousarray(links, np.int32).reshape(-1, 2))
+    nb, lb = nb.to(device), lb.to(device)
+    gn = [torch.empty_like(nb) for _ in range(world)] if rank == 0 else None
+    gl = [torch.empty_like(lb) for _ in range(world)] if rank == 0 else None
+    dist.gather(nb, gn, dst=0)
+    dist.gather(lb, gl, dst=0)
+    if rank != 0:
+        return None
+    out = []
+    for r in range(world):
+        a = gn[r].cpu().numpy()[:cnts[r, 0]].copy().view(NODE_DT).reshape(-1)
+        b = gl[r].cpu().numpy()[:cnts[r, 1]].copy()
+        out.append((a, b))
+    return out

@@ -74,3 +74,52 @@ def synth(w, h, l, seed=1, zdist=1.0, noise=10):
     nz = (_hash32(np.arange(n, dtype=np.uint64), seed) % np.uint64(noise + 1)).astype(np.float32).reshape(l, h, w)
     out = np.clip(np.floor(vol + nz), 0, 255).astype(np.uint8)
     return np.ascontiguousarray(out)
+
+
+def synth_torch(w, h, l, seed=1, zdist=1.0, noise=10, device="cuda"):
+    """Same construction on the GPU with torch (data generation only -- plumbing): returns a uint8
+    torch tensor [l][h][w] resident in HBM.  Used by bench.py for the 512^3 / 1024^3 stacks, where
+    the numpy generator would take minutes.  Same tubes and the same hash noise as synth()."""
+    import torch
+    vol = torch.zeros((l, h, w), dtype=torch.float32, device=device)
+    for pts, s, A in tube_polylines(w, h, l, seed, zdist):
+        for a, b in zip(pts[:-1], pts[1:]):
+            lo = np.floor(np.minimum(a, b) - 4 * s - 1).astype(int)
+            hi = np.ceil(np.maximum(a, b) + 4 * s + 2).astype(int)
+            x0, y0, z0 = max(lo[0], 0), max(lo[1], 0), max(lo[2], 0)
+            x1, y1, z1 = min(hi[0], w), min(hi[1], h), min(hi[2], l)
+            if x0 >= x1 or y0 >= y1 or z0 >= z1:
+                continue
+            ab = b - a
+            den = max(float(ab @ ab), 1e-12)
+            # march the bounding box in z-chunks to bound temporaries for long oblique tubes
+            zc = max(1, int(2 ** 24 // max(1, (y1 - y0) * (x1 - x0))))
+            for za in range(z0, z1, zc):
+                zb = min(z1, za + zc)
+                zz = torch.arange(za, zb, device=device, dtype=torch.float32)[:, None, None]
+                yy = torch.arange(y0, y1, device=device, dtype=torch.float32)[None, :, None]
+                xx = torch.arange(x0, x1, device=device, dtype=torch.float32)[None, None, :]
+                t = (((xx - a[0]) * ab[0] + (yy - a[1]) * ab[1] + (zz - a[2]) * ab[2]) / den).clamp(0.0, 1.0)
+                dx = xx - (a[0] + t * ab[0])
+                dy = yy - (a[1] + t * ab[1])
+                dz = (zz - (a[2] + t * ab[2])) * zdist
+                val = A * torch.exp(-(dx * dx + dy * dy + dz * dz) / (2 * s * s))
+                sub = vol[za:zb, y0:y1, x0:x1]
+                torch.maximum(sub, val, out=sub)
+    out = torch.empty((l, h, w), dtype=torch.uint8, device=device)
+    M = 0xFFFFFFFF
+    add = (seed * 0x9E3779B9) & M
+    wh = w * h
+    zc = max(1, (1 << 26) // wh)
+    for za in range(0, l, zc):
+        zb = min(l, za + zc)
+        i = torch.arange(za * wh, zb * wh, device=device, dtype=torch.int64)
+        x = (i + add) & M
+        x = x ^ (x >> 16)
+        x = (x * 0x7FEB352D) & M
+        x = x ^ (x >> 15)
+        x = (x * 0x846CA68B) & M
+        x = x ^ (x >> 16)
+        nz = (x % (noise + 1)).to(torch.float32).reshape(zb - za, h, w)
+        out[za:zb] = torch.clamp(torch.floor(vol[za:zb] + nz), 0, 255).to(torch.uint8)
+    return out
