@@ -130,6 +130,10 @@ int pnr_create(const pnr_params *p, int device, pnr_ctx **out)
     if (!rc) rc = upload(&c->d_M, t.M, c->stream);
     if (!rc) rc = upload(&c->d_moff, t.moff, c->stream);
     if (!rc) rc = upload(&c->d_rng, t.rng, c->stream);
+    if (!rc) rc = upload(&c->d_grid, t.grid, c->stream);
+    if (!rc) rc = upload(&c->d_axes, t.axes, c->stream);
+    if (!rc) rc = upload(&c->d_axes_off, t.axes_off, c->stream);
+    if (!rc) rc = upload(&c->d_wd, t.wd, c->stream);
     if (!rc && hipMalloc(&c->d_minmax, 8) != hipSuccess) rc = PNR_E_HIP;
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = PNR_E_HIP;
     if (rc) {
@@ -150,7 +154,7 @@ void pnr_destroy(pnr_ctx *c)
     hipFree(c->d_Vx); hipFree(c->d_Vy); hipFree(c->d_Vz); hipFree(c->d_J8); hipFree(c->d_minmax);
     hipFree(c->d_p); hipFree(c->d_u); hipFree(c->d_w0); hipFree(c->d_w0cws); hipFree(c->d_v); hipFree(c->d_w);
     hipFree(c->d_wcws); hipFree(c->d_tmpl); hipFree(c->d_corrc); hipFree(c->d_sig); hipFree(c->d_M); hipFree(c->d_moff);
-    hipFree(c->d_rng);
+    hipFree(c->d_rng); hipFree(c->d_grid); hipFree(c->d_axes); hipFree(c->d_axes_off); hipFree(c->d_wd);
     c->resolve_timers();
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

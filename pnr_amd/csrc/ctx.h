@@ -39,6 +39,11 @@ struct Tables {
     std::vector<float> tmpl;                              // sum(M) x 4 : (v_off, u_off, w_off, wgt - avg)
     std::vector<float> mwgt;                              // sum(M)     : raw template weights
     std::vector<float> mavg, corrc;                       // per sigma
+    std::vector<int> grid;                                // per sigma: nv, nu, nw, first sample
+    std::vector<float> axes;                              // per sigma: vv[nv] | uu[nu] | ww[nw]
+    std::vector<int> axes_off;                            // per sigma offset into axes
+    std::vector<float> wd;                                // sum(M): wgt - avg
+    float ext_v = 0, ext_uw = 0;                          // largest |vv| and |uu|,|ww|
     std::vector<uint32_t> rng;                            // np + 1 glibc rand() draws
     std::vector<std::vector<float>> gxy, gz;              // Gaussian taps per sigma
 };
@@ -75,7 +80,8 @@ struct pnr_ctx {
     // device tables
     float *d_p = nullptr, *d_u = nullptr, *d_w0 = nullptr, *d_w0cws = nullptr, *d_v = nullptr, *d_w = nullptr,
           *d_wcws = nullptr, *d_tmpl = nullptr, *d_corrc = nullptr, *d_sig = nullptr;
-    int *d_M = nullptr, *d_moff = nullptr;
+    int *d_M = nullptr, *d_moff = nullptr, *d_grid = nullptr, *d_axes_off = nullptr;
+    float *d_axes = nullptr, *d_wd = nullptr;
     uint32_t *d_rng = nullptr;
 
     // seeds

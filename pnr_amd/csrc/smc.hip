@@ -83,6 +83,9 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi)
     const float c = (x < lo) ? lo : x;
     return (c > hi) ? hi : c;
 }
+// same value as clampf for every non-NaN x (lo <= hi); the sign of a zero result may differ, which
+// cannot change an interpolated value (it only multiplies/adds into non-negative image samples)
+__device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 // Tracker::interp, 3-D branch (tracker.cpp:2178-2213)
 __device__ __forceinline__ float interp(const Vol &V, float x, float y, float z)
@@ -206,8 +209,21 @@ __global__ void expf_kernel(const float *__restrict__ x, i64 n, float *__restric
     if (i < n) y[i] = expf_libm(x[i]);
 }
 
+// Diagnostic build only (make STAMPS=1 -> libpnr_hip_stamps.so): per-phase shader-clock sums of
+// wave 0, written to a buffer of their own.  No stamp executes in the product library.
+#ifdef PNR_SMC_STAMPS
+#define STAMP(i)                                                       \
+    do {                                                               \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
+        if (threadIdx.x == 0) st_acc[i] += t_ - st_prev;               \
+        st_prev = t_;                                                  \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 // ----------------------------------------------------------------------------------------
-// K9: SMC trace kernel -- one work-group per trace
+// K9: SMC trace kernel -- one work-group per trace, image neighbourhood resident in LDS
 // ----------------------------------------------------------------------------------------
 enum { PX, PY, PZ, PVX, PVY, PVZ, PW, PCORR, PSIG, PSTRIDE }; // struct X (tracker.h:13-17)
 
@@ -218,6 +234,11 @@ struct TraceOut {
     float *xfilt;
     int *idxres;
     float *neff;
+};
+
+// template sample grid of one sigma: nested loops vv (outer) / uu / ww (inner), tracker.cpp:219-221
+struct Grid {
+    int nv, nu, nw, off; // off: first sample in tmpl / wd
 };
 
 // first index s with !(u > cws[s]), clamped to n-1: the monotone walk of tracker.cpp:1013,1120
@@ -231,85 +252,319 @@ __device__ __forceinline__ int cdf_search(const float *__restrict__ cws, int n, 
     return lo;
 }
 
-__global__ __launch_bounds__(1024) void smc_trace(Vol V, Tab T, const float *__restrict__ seeds6, int np, int np_pad, int ni,
-                                                   float Kc, float znccth, float neff_ratio, TraceOut O)
+// The u8 neighbourhood of the current particle cloud, staged in LDS once per SMC iteration:
+// axis-aligned box [o, o+b) chosen from the bounding box of every particle's template.
+struct Box {
+    const unsigned char *lds;
+    int ox, oy, oz, bx, by, bz, sxy, base; // base = -(oz*sxy + oy*bx + ox)
+};
+
+// Tracker::interp with the 8 corners fetched from the LDS box; CHECK: a corner outside the box
+// (box had to be clipped to fit LDS) is fetched from HBM/L2 instead.
+template <bool CHECK>
+__device__ __forceinline__ float interp_box(const Vol &V, const Box &B, float x, float y, float z)
+{
+    const float xc = clamp3(x, 0.f, V.xmax);
+    const int x1 = (int)xc;
+    const float xf = xc - (float)x1;
+    const float yc = clamp3(y, 0.f, V.ymax);
+    const int y1 = (int)yc;
+    const float yf = yc - (float)y1;
+    const float zc = clamp3(z, 0.f, V.zmax);
+    const int z1 = (int)zc;
+    const float zf = zc - (float)z1;
+    float a00, a01, a10, a11, b00, b01, b10, b11;
+    bool in = true;
+    if (CHECK) {
+        const unsigned rx = (unsigned)(x1 - B.ox), ry = (unsigned)(y1 - B.oy), rz = (unsigned)(z1 - B.oz);
+        in = (rx < (unsigned)(B.bx - 1)) && (ry < (unsigned)(B.by - 1)) && (rz < (unsigned)(B.bz - 1));
+    }
+    if (in) {
+        const unsigned char *a = B.lds + (__mul24(z1, B.sxy) + __mul24(y1, B.bx) + x1 + B.base);
+        const unsigned char *a2 = a + B.bx, *b = a + B.sxy, *b2 = b + B.bx;
+        a00 = a[0]; a01 = a[1]; a10 = a2[0]; a11 = a2[1];
+        b00 = b[0]; b01 = b[1]; b10 = b2[0]; b11 = b2[1];
+    } else {
+        const unsigned char *a = V.img + (i64)z1 * V.wh + (i64)y1 * V.w + x1;
+        const unsigned char *b = a + V.wh;
+        a00 = a[0]; a01 = a[1]; a10 = a[V.w]; a11 = a[V.w + 1];
+        b00 = b[0]; b01 = b[1]; b10 = b[V.w]; b11 = b[V.w + 1];
+    }
+    return (1 - zf) * ((1 - yf) * ((1 - xf) * a00 + xf * a01) + (yf) * ((1 - xf) * a10 + xf * a11)) +
+           (zf) * ((1 - yf) * ((1 - xf) * b00 + xf * b01) + (yf) * ((1 - xf) * b10 + xf * b11));
+}
+
+__device__ __forceinline__ float bcast(float v, int lane) // wave-uniform lane index -> SGPR broadcast
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// one (pose, sigma) chain on the LDS box.  Same operations in the same order as znccBBB: the
+// position is ((p + vv*(-v)) + uu*u) + ww*w; the two inner partial sums only change in the outer
+// loops, so they are hoisted (bit-identical, 6 instead of 18 f32 ops per sample).  `ax`: the
+// three axis value lists (vv | uu | ww) of this sigma, `wd` = wgt - avg per sample.
+// The template values are wave-uniform: each is fetched ONCE per wave by a coalesced vector load
+// (lane i holds element i of the row) and broadcast with v_readlane, so the inner loop has no
+// memory access other than the four 16-bit LDS corner-pair reads.  MUST be called with all 64
+// lanes of the wave active (callers give idle lanes a dummy pose).
+template <bool CHECK>
+__device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
+                                                const float *__restrict__ ax, const float *__restrict__ wd, float corrc)
+{
+    const int lane = threadIdx.x & 63;
+    const float r_av = ax[lane < nv ? lane : 0];
+    const float r_au = ax[nv + (lane < nu ? lane : 0)];
+    const float r_aw = ax[nv + nu + (lane < nw ? lane : 0)];
+    float ag = 0.f;
+    for (int iv = 0; iv < nv; ++iv) {
+        const float vv = bcast(r_av, iv);
+        const float x0 = f.px + vv * f.nvx, y0 = f.py + vv * f.nvy, z0 = f.pz + vv * f.nvz;
+        for (int iu = 0; iu < nu; ++iu) {
+            const float uu = bcast(r_au, iu);
+            const float x1 = x0 + uu * f.ux, y1 = y0 + uu * f.uy, z1 = z0 + uu * f.uz;
+            for (int iw = 0; iw < nw; ++iw) {
+                const float ww = bcast(r_aw, iw);
+                ag += interp_box<CHECK>(V, B, x1 + ww * f.wx, y1 + ww * f.wy, z1 + ww * f.wz);
+            }
+        }
+    }
+    ag /= (float)(nv * nu * nw);
+    float corra = 0.f, corrb = 0.f;
+    const float *wk = wd;
+    float r_wd = wk[lane < nw ? lane : 0]; // row 0 of (wgt - avg); next rows are prefetched one row ahead
+    for (int iv = 0; iv < nv; ++iv) {
+        const float vv = bcast(r_av, iv);
+        const float x0 = f.px + vv * f.nvx, y0 = f.py + vv * f.nvy, z0 = f.pz + vv * f.nvz;
+        for (int iu = 0; iu < nu; ++iu) {
+            const float uu = bcast(r_au, iu);
+            const float x1 = x0 + uu * f.ux, y1 = y0 + uu * f.uy, z1 = z0 + uu * f.uz;
+            const float r_cur = r_wd;
+            wk += nw;
+            const bool more = (iv * nu + iu + 1) < nv * nu;
+            const float *nxt = more ? wk : wk - nw; // after the last row: re-read it (stays in range)
+            r_wd = nxt[lane < nw ? lane : 0];
+            for (int iw = 0; iw < nw; ++iw) {
+                const float ww = bcast(r_aw, iw);
+                const float di = interp_box<CHECK>(V, B, x1 + ww * f.wx, y1 + ww * f.wy, z1 + ww * f.wz) - ag;
+                corra += di * bcast(r_cur, iw);
+                corrb = (float)((double)corrb + (double)di * (double)di); // corrb += pow(f32,2)
+            }
+        }
+    }
+    const float prod = corrb * corrc;
+    return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f; // tracker.cpp:1955
+}
+
+struct TabX { // extra template tables for the box kernel
+    const Grid *grid;   // per sigma
+    const float *axes;  // per sigma: vv[nv] | uu[nu] | ww[nw], at axes_off[s]
+    const int *axes_off;
+    const float *wd;    // sum(M): wgt - avg
+    float ext_v, ext_uw; // largest template half-extents (voxels) along v and along u / w
+};
+
+__global__ __launch_bounds__(1024) void smc_trace(Vol V, Tab T, TabX X, const float *__restrict__ seeds6, int np, int np_pad,
+                                                   int ni, float Kc, float znccth, float neff_ratio, int box_cap, TraceOut O)
 {
     extern __shared__ float lds[];
     const int tr = blockIdx.x, tid = threadIdx.x, B = blockDim.x, S = T.nsig;
     float *part = lds;                         // [2][np][9]
-    float *corr_ks = part + 2 * np * PSTRIDE;  // [S][np_pad]
+    float *corr_ks = part + 2 * np * PSTRIDE;  // [S][np_pad]  (slot k == np: centroid of the previous iteration)
     float *prior = corr_ks + S * np_pad;       // [np]
     float *lhood = prior + np;                 // [np]
     float *csw = lhood + np;                   // [np]
     int *idxres = (int *)(csw + np);           // [np]
-    float *cbuf = (float *)(idxres + np);      // [Mtot]
-    float *ccorr = cbuf + T.Mtot;              // [S]
-    float *sxc = ccorr + S;                    // [8] centroid
-    int *sflag = (int *)(sxc + 8);             // [0]=resampled(prev) [1]=stop code [2]=T
-    float *sneff = (float *)(sflag + 4);       // [1]
+    float *sxc = (float *)(idxres + np);       // [2][8] centroid of iteration it (cur) and it-1 (pending)
+    int *sflag = (int *)(sxc + 16);            // [0]=resampled(prev) [1]=stop code [2]=T [3]=box clipped
+    int *sbox = sflag + 4;                     // [0..2]=lo xyz, [3..5]=hi xyz (atomics) then [6..11] = o, b
+    float *sneff = (float *)(sbox + 12);       // [2]
+    unsigned char *cube = (unsigned char *)(sneff + 2);
 
     const float *sd = seeds6 + (i64)tr * 6;
     const float x0 = sd[0], y0 = sd[1], z0 = sd[2], vx0 = sd[3], vy0 = sd[4], vz0 = sd[5];
-    if (tid == 0) { sflag[0] = 0; sflag[1] = 0; sflag[2] = ni; }
+    if (tid == 0) { sflag[0] = 0; sflag[1] = 0; sflag[2] = ni; sflag[3] = 0; }
+    int pending = -1; // iteration whose centroid ZNCC has not been evaluated yet (uniform)
     __syncthreads();
+#ifdef PNR_SMC_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
 
-    for (int it = 0; it < ni; ++it) {
+    for (int it = 0; it <= ni; ++it) {
+        // it == ni, or a stop already decided by geometry: tail pass that only finishes the pending centroid
+        const bool tail = (it == ni) || (sflag[1] != 0);
         float *cur = part + (it & 1) * np * PSTRIDE;
         const float *prv = part + ((it & 1) ^ 1) * np * PSTRIDE;
+        float *xc_cur = sxc + (it & 1) * 8;
+        const float *xc_pen = sxc + ((it & 1) ^ 1) * 8;
         const int resampled_prev = sflag[0];
+        if (tid < 3) { sbox[tid] = 0x7fffffff; sbox[3 + tid] = -0x7fffffff; }
+        if (tid == 3) sflag[3] = 0;
+        __syncthreads();
+        STAMP(0);
 
-        // ---- P1: prediction (tracker.cpp:1006-1024 / :1104-1132) ----
-        for (int k = tid; k < np; k += B) {
-            float *q = cur + k * PSTRIDE;
-            if (it == 0) {
-                const float stepw = T.w0cws[T.sz - 1] / np;
-                const float u1 = stepw * ((float)T.rng[0] / (float)2147483647);
-                const float ui = u1 + k * stepw;
-                const int s = cdf_search(T.w0cws, T.sz, ui);
-                q[PX] = x0 + T.p[3 * s + 0];
-                q[PY] = y0 + T.p[3 * s + 1];
-                q[PZ] = z0 + T.p[3 * s + 2];
-                q[PVX] = (vx0 != vx0) ? T.u[3 * s + 0] : vx0;
-                q[PVY] = (vy0 != vy0) ? T.u[3 * s + 1] : vy0;
-                q[PVZ] = (vz0 != vz0) ? T.u[3 * s + 2] : vz0;
-                prior[k] = T.w0[s];
+        // ---- P1: prediction (tracker.cpp:1006-1024 / :1104-1132) + bounding box of all templates ----
+        for (int k = tid; k <= np; k += B) {
+            float qx, qy, qz, qvx, qvy, qvz;
+            if (k == np) { // the pending centroid is evaluated with this iteration's chains
+                if (pending < 0) continue;
+                qx = xc_pen[0]; qy = xc_pen[1]; qz = xc_pen[2]; qvx = xc_pen[3]; qvy = xc_pen[4]; qvz = xc_pen[5];
             } else {
-                const int k1 = resampled_prev ? idxres[k] : k;
-                const float *par = prv + k1 * PSTRIDE;
-                int vi = -1; // getdirection: first maximum of the 50 dot products
-                float best = -FLT_MAX;
-                for (int a = 0; a < T.ndir; a++) {
-                    const float dp = par[PVX] * T.v[3 * a] + par[PVY] * T.v[3 * a + 1] + par[PVZ] * T.v[3 * a + 2];
-                    if (dp > best) { best = dp; vi = a; }
+                if (tail) continue;
+                float *q = cur + k * PSTRIDE;
+                if (it == 0) {
+                    const float stepw = T.w0cws[T.sz - 1] / np;
+                    const float u1 = stepw * ((float)T.rng[0] / (float)2147483647);
+                    const float ui = u1 + k * stepw;
+                    const int s = cdf_search(T.w0cws, T.sz, ui);
+                    q[PX] = x0 + T.p[3 * s + 0];
+                    q[PY] = y0 + T.p[3 * s + 1];
+                    q[PZ] = z0 + T.p[3 * s + 2];
+                    q[PVX] = (vx0 != vx0) ? T.u[3 * s + 0] : vx0;
+                    q[PVY] = (vy0 != vy0) ? T.u[3 * s + 1] : vy0;
+                    q[PVZ] = (vz0 != vz0) ? T.u[3 * s + 2] : vz0;
+                    prior[k] = T.w0[s];
+                } else {
+                    const int k1 = resampled_prev ? idxres[k] : k;
+                    const float *par = prv + k1 * PSTRIDE;
+                    int vi = -1; // getdirection: first maximum of the 50 dot products
+                    float best = -FLT_MAX;
+                    for (int a = 0; a < T.ndir; a++) {
+                        const float dp = par[PVX] * T.v[3 * a] + par[PVY] * T.v[3 * a + 1] + par[PVZ] * T.v[3 * a + 2];
+                        if (dp > best) { best = dp; vi = a; }
+                    }
+                    if (vi < 0) vi = 0; // NaN direction: the reference would index v[-1]; keep in range
+                    const float *cws = T.wcws + (i64)vi * T.sz;
+                    const float u1 = cws[T.sz - 1] * ((float)T.rng[k] / (float)2147483647);
+                    const int s = cdf_search(cws, T.sz, u1);
+                    q[PX] = par[PX] + T.p[3 * s + 0];
+                    q[PY] = par[PY] + T.p[3 * s + 1];
+                    q[PZ] = par[PZ] + T.p[3 * s + 2];
+                    q[PVX] = T.u[3 * s + 0];
+                    q[PVY] = T.u[3 * s + 1];
+                    q[PVZ] = T.u[3 * s + 2];
+                    prior[k] = T.w[(i64)vi * T.sz + s];
                 }
-                if (vi < 0) vi = 0; // NaN direction: the reference would index v[-1]; keep in range
-                const float *cws = T.wcws + (i64)vi * T.sz;
-                const float u1 = cws[T.sz - 1] * ((float)T.rng[k] / (float)2147483647);
-                const int s = cdf_search(cws, T.sz, u1);
-                q[PX] = par[PX] + T.p[3 * s + 0];
-                q[PY] = par[PY] + T.p[3 * s + 1];
-                q[PZ] = par[PZ] + T.p[3 * s + 2];
-                q[PVX] = T.u[3 * s + 0];
-                q[PVY] = T.u[3 * s + 1];
-                q[PVZ] = T.u[3 * s + 2];
-                prior[k] = T.w[(i64)vi * T.sz + s];
+                qx = q[PX]; qy = q[PY]; qz = q[PZ]; qvx = q[PVX]; qvy = q[PVY]; qvz = q[PVZ];
+            }
+            // conservative extent of this pose's largest template along each axis (+ margin)
+            const Frame f = make_frame(qx, qy, qz, qvx, qvy, qvz);
+            const float ex = X.ext_v * fabsf(qvx) + X.ext_uw * (fabsf(f.ux) + fabsf(f.wx)) + 1.5f;
+            const float ey = X.ext_v * fabsf(qvy) + X.ext_uw * (fabsf(f.uy) + fabsf(f.wy)) + 1.5f;
+            const float ez = X.ext_v * fabsf(qvz) + X.ext_uw * (fabsf(f.uz) + fabsf(f.wz)) + 1.5f;
+            if (qx == qx && qy == qy && qz == qz && ex == ex && ey == ey && ez == ez) {
+                const float big = 1e6f;
+                atomicMin(&sbox[0], (int)floorf(fmaxf(qx - ex, -big)));
+                atomicMin(&sbox[1], (int)floorf(fmaxf(qy - ey, -big)));
+                atomicMin(&sbox[2], (int)floorf(fmaxf(qz - ez, -big)));
+                atomicMax(&sbox[3], (int)floorf(fminf(qx + ex, big)) + 2);
+                atomicMax(&sbox[4], (int)floorf(fminf(qy + ey, big)) + 2);
+                atomicMax(&sbox[5], (int)floorf(fminf(qz + ez, big)) + 2);
+            } else {
+                atomicOr(&sflag[3], 1); // NaN/inf pose: its samples are range-checked and fetched from HBM
             }
         }
         __syncthreads();
+        STAMP(1); // P1 prediction
+        if (tid == 0) { // box = bounding box clipped to the volume, then to the LDS capacity
+            int lo[3], hi[3];
+            const int dim[3] = {V.w, V.h, V.l};
+            for (int a = 0; a < 3; a++) { // box must hold x1 and x1+1 of every sample: at least 2 voxels, inside the volume
+                lo[a] = sbox[a] < 0 ? 0 : (sbox[a] > dim[a] - 2 ? dim[a] - 2 : sbox[a]);
+                hi[a] = sbox[3 + a] > dim[a] - 1 ? dim[a] - 1 : (sbox[3 + a] < lo[a] + 1 ? lo[a] + 1 : sbox[3 + a]);
+            }
+            int clipped = sflag[3]; // non-finite pose seen: checked path
+            while ((i64)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1) > box_cap) {
+                int a = 0; // shrink the longest side symmetrically
+                if (hi[1] - lo[1] > hi[a] - lo[a]) a = 1;
+                if (hi[2] - lo[2] > hi[a] - lo[a]) a = 2;
+                lo[a]++; hi[a]--;
+                clipped = 1;
+            }
+            for (int a = 0; a < 3; a++) { sbox[6 + a] = lo[a]; sbox[9 + a] = hi[a] - lo[a] + 1; }
+            sflag[3] = clipped;
+        }
+        __syncthreads();
+        Box Bx;
+        Bx.lds = cube;
+        Bx.ox = sbox[6]; Bx.oy = sbox[7]; Bx.oz = sbox[8];
+        Bx.bx = sbox[9]; Bx.by = sbox[10]; Bx.bz = sbox[11];
+        Bx.sxy = Bx.bx * Bx.by;
+        Bx.base = -(Bx.oz * Bx.sxy + Bx.oy * Bx.bx + Bx.ox);
+        const int clipped = sflag[3];
+        { // stage the box: one wave per (z,y) row, lanes along x (coalesced bytes)
+            const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6;
+            const int rows = Bx.by * Bx.bz;
+            for (int r0 = wv; r0 < rows; r0 += 4 * nwv) { // 4 rows in flight per wave
+                unsigned char v[4];
+                bool ok[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int r = r0 + j * nwv;
+                    ok[j] = (r < rows) && (lane < Bx.bx);
+                    const int rr = ok[j] ? r : 0;
+                    const int zz = rr / Bx.by, yy = rr - zz * Bx.by;
+                    const unsigned char *src = V.img + (i64)(Bx.oz + zz) * V.wh + (i64)(Bx.oy + yy) * V.w + Bx.ox;
+                    v[j] = ok[j] ? src[lane] : (unsigned char)0;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (ok[j]) cube[(r0 + j * nwv) * Bx.bx + lane] = v[j];
+                for (int xx = lane + 64; xx < Bx.bx; xx += 64) // rows wider than a wave (large sigma sets)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int r = r0 + j * nwv;
+                        if (r < rows) {
+                            const int zz = r / Bx.by, yy = r - zz * Bx.by;
+                            cube[r * Bx.bx + xx] = V.img[(i64)(Bx.oz + zz) * V.wh + (i64)(Bx.oy + yy) * V.w + Bx.ox + xx];
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+        STAMP(2); // box staging
 
         // ---- P2: likelihood chains, sigma-major so a wave shares sigma and sample index ----
         for (int c = tid; c < S * np_pad; c += B) {
             const int s = __builtin_amdgcn_readfirstlane(c / np_pad);
             const int k = c - s * np_pad;
-            if (k < np) {
-                const float *q = cur + k * PSTRIDE;
-                const Frame f = make_frame(q[PX], q[PY], q[PZ], q[PVX], q[PVY], q[PVZ]);
-                corr_ks[s * np_pad + k] = zncc_chain(V, f, T.tmpl + T.moff[s], T.M[s], T.corrc[s]);
-            }
+            const bool is_cen = (k == np) && (pending >= 0);
+            const bool valid = (k < np && !tail) || is_cen;
+            if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue; // wave-uniform: nothing to do in this wave
+            // every lane of the wave runs the chain (the template broadcasts need a full wave);
+            // idle lanes recompute a pose that is known to lie inside the box and discard the result
+            const float *q = is_cen ? xc_pen : (valid ? cur + k * PSTRIDE : (tail ? xc_pen : cur));
+            const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
+            const Grid g = X.grid[s];
+            const int nv = __builtin_amdgcn_readfirstlane(g.nv), nu = __builtin_amdgcn_readfirstlane(g.nu);
+            const int nw = __builtin_amdgcn_readfirstlane(g.nw), goff = __builtin_amdgcn_readfirstlane(g.off);
+            const float *ax = X.axes + __builtin_amdgcn_readfirstlane(X.axes_off[s]);
+            float cv;
+            if (clipped) cv = zncc_chain_box<true>(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s]);
+            else cv = zncc_chain_box<false>(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s]);
+            if (valid) corr_ks[s * np_pad + k] = cv;
         }
         __syncthreads();
+        STAMP(3); // chains
 
-        // ---- P3: max over sigma, likelihood exp(Kc*corr) (tracker.cpp:1028-1029) ----
+        // ---- P3a: finish the pending centroid: corr, stop tests of that iteration (:1072-1079) ----
+        if (pending >= 0) {
+            if (tid == 0) {
+                float best = -FLT_MAX, bs = xc_pen[6];
+                for (int s = 0; s < S; s++) {
+                    const float cv = corr_ks[s * np_pad + np];
+                    if (cv > best) { best = cv; bs = T.sig[s]; }
+                }
+                float *xo = O.xc + ((i64)tr * ni + pending) * 8;
+                xo[0] = xc_pen[0]; xo[1] = xc_pen[1]; xo[2] = xc_pen[2]; xo[3] = xc_pen[3]; xo[4] = xc_pen[4]; xo[5] = xc_pen[5];
+                xo[6] = bs; xo[7] = best;
+                if (sflag[1] == 0 && best < znccth) { sflag[1] = 2; sflag[2] = pending; }
+            }
+            __syncthreads();
+        }
+        if (tail || sflag[1] != 0) break; // uniform (flags written before the barrier above / at loop top)
+
+        // ---- P3b: max over sigma, likelihood exp(Kc*corr) (tracker.cpp:1028-1029) ----
         for (int k = tid; k < np; k += B) {
             float best = -FLT_MAX, bs = 0.f;
             for (int s = 0; s < S; s++) {
@@ -321,8 +576,10 @@ __global__ __launch_bounds__(1024) void smc_trace(Vol V, Tab T, const float *__r
             lhood[k] = expf_libm(Kc * best);
         }
         __syncthreads();
+        STAMP(4); // P3
 
-        // ---- P4: weights, N_eff, CDF, centroid: sequential sums in particle order (:1035-1071) ----
+        // ---- P4: weights, N_eff, CDF, centroid (sequential sums in particle order, :1035-1071),
+        //          out-of-volume test and systematic resampling (:1075-1090) ----
         if (tid == 0) {
             float wnorm_prior = 0.f;
             for (int k = 0; k < np; k++) wnorm_prior += prior[k];
@@ -353,42 +610,18 @@ __global__ __launch_bounds__(1024) void smc_trace(Vol V, Tab T, const float *__r
             }
             neff = (float)(1.0 / (double)neff);
             const float vnorm = (float)sqrt((double)cvx * (double)cvx + (double)cvy * (double)cvy + (double)cvz * (double)cvz);
-            sxc[0] = cx; sxc[1] = cy; sxc[2] = cz;
-            sxc[3] = cvx / vnorm; sxc[4] = cvy / vnorm; sxc[5] = cvz / vnorm;
-            sxc[6] = csig;
-            sneff[0] = neff;
-        }
-        __syncthreads();
-
-        // ---- P5: centroid ZNCC samples by the whole group (+ debug tap of the particle set) ----
-        {
-            const Frame f = make_frame(sxc[0], sxc[1], sxc[2], sxc[3], sxc[4], sxc[5]);
-            for (int idx = tid; idx < T.Mtot; idx += B) cbuf[idx] = sample(V, f, T.tmpl[idx]);
-            if (it < O.dbg_iters && O.xfilt) {
-                float *dst = O.xfilt + ((i64)tr * O.dbg_iters + it) * np * PSTRIDE;
-                for (int e = tid; e < np * PSTRIDE; e += B) dst[e] = cur[e];
-            }
-        }
-        __syncthreads();
-        if (tid < S) ccorr[tid] = zncc_from_samples(cbuf + T.moff[tid], T.tmpl + T.moff[tid], T.M[tid], T.corrc[tid]);
-        __syncthreads();
-
-        // ---- P6: centroid corr, stop tests, systematic resampling (:1072-1090) ----
-        if (tid == 0) {
-            float best = -FLT_MAX, bs = sxc[6];
-            for (int s = 0; s < S; s++)
-                if (ccorr[s] > best) { best = ccorr[s]; bs = T.sig[s]; }
-            float *xo = O.xc + ((i64)tr * ni + it) * 8;
-            xo[0] = sxc[0]; xo[1] = sxc[1]; xo[2] = sxc[2]; xo[3] = sxc[3]; xo[4] = sxc[4]; xo[5] = sxc[5];
-            xo[6] = bs; xo[7] = best;
-            const float neff = sneff[0];
+            xc_cur[0] = cx; xc_cur[1] = cy; xc_cur[2] = cz;
+            xc_cur[3] = cvx / vnorm; xc_cur[4] = cvy / vnorm; xc_cur[5] = cvz / vnorm;
+            xc_cur[6] = csig;
             if (it < O.dbg_iters && O.neff) O.neff[(i64)tr * O.dbg_iters + it] = neff;
-            const int x1 = (int)roundf(sxc[0]), y1 = (int)roundf(sxc[1]), z1 = (int)roundf(sxc[2]);
-            int stop = 0;
-            if (x1 < 0 || x1 >= V.w || y1 < 0 || y1 >= V.h || z1 < 0 || z1 >= V.l) stop = 1;
-            else if (best < znccth) stop = 2;
+            const int x1 = (int)roundf(cx), y1 = (int)roundf(cy), z1 = (int)roundf(cz);
             int res = 0;
-            if (!stop && (neff / np < neff_ratio)) {
+            if (x1 < 0 || x1 >= V.w || y1 < 0 || y1 >= V.h || z1 < 0 || z1 >= V.l) {
+                sflag[1] = 1; // left the volume: the centroid's corr is still evaluated (tail pass) for the record
+                sflag[2] = it;
+            } else if (neff / np < neff_ratio) {
+                // resampling does not depend on the centroid's corr; if that later fails znccth the
+                // trace ends at this iteration and these indices are never used
                 res = 1;
                 const float u1 = (float)((1.0 / np) * (double)((float)T.rng[(it == 0) ? 1 : np] / (float)2147483647));
                 int s = 0;
@@ -397,27 +630,36 @@ __global__ __launch_bounds__(1024) void smc_trace(Vol V, Tab T, const float *__r
                     while (ui > csw[s] && s < np - 1) s++; // clamp: the reference walks unbounded (:1087,:1192)
                     idxres[k] = s;
                 }
-                if (it < O.dbg_iters && O.idxres) {
-                    int *dst = O.idxres + ((i64)tr * O.dbg_iters + it) * np;
-                    for (int k = 0; k < np; k++) dst[k] = idxres[k];
-                }
             }
             sflag[0] = res;
-            sflag[1] = stop;
-            if (stop) sflag[2] = it;
         }
         __syncthreads();
-        if (sflag[1]) break; // uniform: read after the barrier
+        STAMP(5); // P4 serial
+        if (it < O.dbg_iters) { // debug taps (tests): particle set and resampling indices of this iteration
+            if (O.xfilt) {
+                float *dst = O.xfilt + ((i64)tr * O.dbg_iters + it) * np * PSTRIDE;
+                for (int e = tid; e < np * PSTRIDE; e += B) dst[e] = cur[e];
+            }
+            if (O.idxres && sflag[0]) {
+                int *dst = O.idxres + ((i64)tr * O.dbg_iters + it) * np;
+                for (int k = tid; k < np; k += B) dst[k] = idxres[k];
+            }
+        }
+        pending = it;
     }
     if (tid == 0) {
         O.T[tr] = sflag[2];
         O.stop[tr] = sflag[1];
+#ifdef PNR_SMC_STAMPS
+        if (O.neff) // diagnostic build: phase cycle sums replace the neff tap (8 x u64 per trace needs dbg_iters >= 16)
+            for (int i = 0; i < 8; i++) ((unsigned long long *)(O.neff + (i64)tr * O.dbg_iters))[i] = st_acc[i];
+#endif
     }
 }
 
-size_t trace_lds_bytes(int np, int np_pad, int S, int Mtot)
+size_t trace_fixed_lds_bytes(int np, int np_pad, int S)
 {
-    return (size_t)(2 * np * PSTRIDE + S * np_pad + 3 * np + np + Mtot + S + 8 + 4 + 4) * 4;
+    return (size_t)(2 * np * PSTRIDE + S * np_pad + 3 * np + np + 16 + 4 + 12 + 2) * 4;
 }
 
 int make_vol(pnr_ctx *c, Vol &V)
@@ -484,15 +726,24 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
     Tab T;
     make_tab(c, T);
     const int np = c->prm.np, ni = c->prm.ni, S = T.nsig;
-    const int np_pad = (np + 63) / 64 * 64;
+    const int np_pad = (np + 1 + 63) / 64 * 64; // slot np = the pending centroid
     const i64 ntr = 2 * n;
     PNR_REQUIRE(ntr < (1LL << 30), PNR_E_ARG, "too many traces in one batch");
     if (dbg_iters > ni) dbg_iters = ni;
     if (dbg_iters < 0) dbg_iters = 0;
-    const size_t lds = trace_lds_bytes(np, np_pad, S, T.Mtot);
-    PNR_REQUIRE(lds <= 160 * 1024, PNR_E_ARG, "np=%d / sigma set need %zu B of LDS (> 160 KiB)", np, lds);
+    const size_t fixed = trace_fixed_lds_bytes(np, np_pad, S);
+    const size_t lds_total = 160 * 1024;
+    PNR_REQUIRE(fixed + 16 * 1024 <= lds_total, PNR_E_ARG, "np=%d needs %zu B of LDS state: no room for the image box", np, fixed);
+    const int box_cap = (int)(lds_total - fixed - 64);
+    const size_t lds = fixed + (size_t)box_cap;
     int block = S * np_pad;
     if (block > 1024) block = 1024;
+    for (int s = 0; s < S; s++)
+        PNR_REQUIRE(c->tab.grid[4 * s] <= 64 && c->tab.grid[4 * s + 1] <= 64 && c->tab.grid[4 * s + 2] <= 64, PNR_E_ARG,
+                    "template grid axis longer than a wavefront");
+    TabX X;
+    X.grid = (const Grid *)c->d_grid; X.axes = c->d_axes; X.axes_off = c->d_axes_off; X.wd = c->d_wd;
+    X.ext_v = c->tab.ext_v; X.ext_uw = c->tab.ext_uw;
 
     std::vector<float> s6((size_t)ntr * 6);
     for (i64 i = 0; i < n; i++) {
@@ -518,8 +769,8 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
     PNR_HIP(hipMemcpyAsync(d_s6, s6.data(), s6.size() * 4, hipMemcpyHostToDevice, c->stream));
     PNR_HIP(hipFuncSetAttribute((const void *)smc_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     c->tic();
-    hipLaunchKernelGGL(smc_trace, dim3((unsigned)ntr), dim3(block), lds, c->stream, V, T, d_s6, np, np_pad, ni, c->prm.Kc,
-                       c->prm.znccth, c->prm.neff_ratio, O);
+    hipLaunchKernelGGL(smc_trace, dim3((unsigned)ntr), dim3(block), lds, c->stream, V, T, X, d_s6, np, np_pad, ni, c->prm.Kc,
+                       c->prm.znccth, c->prm.neff_ratio, box_cap, O);
     c->toc("smc");
     PNR_HIP(hipGetLastError());
     PNR_HIP(hipMemcpyAsync(T_out, O.T, (size_t)ntr * 4, hipMemcpyDeviceToHost, c->stream));

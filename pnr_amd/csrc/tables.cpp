@@ -61,6 +61,7 @@ static void build_templates(const pnr_params &P, Tables &t)
 {
     // model2_* of tracker.cpp:178-231 (3-D branch); model2_N = 12 samples per 3*sigma
     t.M.clear(); t.moff.clear(); t.tmpl.clear(); t.mwgt.clear(); t.mavg.clear(); t.corrc.clear();
+    t.grid.clear(); t.axes.clear(); t.axes_off.clear(); t.wd.clear(); t.ext_v = t.ext_uw = 0;
     int off = 0;
     for (int s = 0; s < P.nsig; s++) {
         const float sg = P.sig[s];
@@ -69,6 +70,20 @@ static void build_templates(const pnr_params &P, Tables &t)
         if (Vs < 1.0) Vs = 1.0f;
         std::vector<float> vuw, wgt;
         float avg = 0.f;
+        // the three nested float-stepped loops visit a product grid: record its axes once, so the
+        // kernel can hoist the outer partial sums of the sample position
+        std::vector<float> av, au, aw;
+        for (float vv = (float)-V2; vv <= V2 + FLT_MIN; vv += Vs) av.push_back(vv);
+        for (float uu = (float)-U2; uu <= U2 + FLT_MIN; uu += Vs) au.push_back(uu);
+        for (float ww = (float)-W2; ww <= W2 + FLT_MIN; ww += Vs) aw.push_back(ww);
+        t.grid.push_back((int)av.size()); t.grid.push_back((int)au.size()); t.grid.push_back((int)aw.size()); t.grid.push_back(off);
+        t.axes_off.push_back((int)t.axes.size());
+        t.axes.insert(t.axes.end(), av.begin(), av.end());
+        t.axes.insert(t.axes.end(), au.begin(), au.end());
+        t.axes.insert(t.axes.end(), aw.begin(), aw.end());
+        for (float x : av) t.ext_v = std::fmax(t.ext_v, std::fabs(x));
+        for (float x : au) t.ext_uw = std::fmax(t.ext_uw, std::fabs(x));
+        for (float x : aw) t.ext_uw = std::fmax(t.ext_uw, std::fabs(x));
         for (float vv = (float)-V2; vv <= V2 + FLT_MIN; vv += Vs)
             for (float uu = (float)-U2; uu <= U2 + FLT_MIN; uu += Vs)
                 for (float ww = (float)-W2; ww <= W2 + FLT_MIN; ww += Vs) {
@@ -88,6 +103,7 @@ static void build_templates(const pnr_params &P, Tables &t)
             t.tmpl.push_back(vuw[3 * k]); t.tmpl.push_back(vuw[3 * k + 1]); t.tmpl.push_back(vuw[3 * k + 2]);
             t.tmpl.push_back(wd);
             t.mwgt.push_back(wgt[k]);
+            t.wd.push_back(wd);
             cc = (float)((double)cc + (double)wd * (double)wd);
         }
         t.M.push_back(M);

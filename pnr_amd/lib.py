@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpnr_hip.so")
+LIB_PATH = os.environ.get("PNR_LIB_DIAG") or os.path.join(HERE, "libpnr_hip.so")  # PNR_LIB_DIAG: diagnostic builds only
 PNR_MAX_SIGMAS = 8
 
 

@@ -3,10 +3,13 @@ import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.
 import numpy as np, torch, synth, pnr_amd
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 nseed = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+sigs = tuple(float(x) for x in sys.argv[3].split(',')) if len(sys.argv) > 3 else (2, 4, 6)
 t0 = time.time(); img = synth.synth_torch(S, S, S, seed=3); torch.cuda.synchronize(); print('synth', time.time() - t0, flush=True)
 if S <= 128:
     ref = synth.synth(S, S, S, seed=3); print('synth torch==numpy frac', (img.cpu().numpy() == ref).mean())
-p = pnr_amd.make_params(sigmas=(2, 4, 6), np_=200, ni=200, zdist=2)
+p = pnr_amd.make_params(sigmas=sigs, np_=200, ni=200, zdist=2)
+Mtot = {2.0: 845, 4.0: 5625, 6.0: 5625, 8.0: 5625}
+nchain = sum(Mtot.get(float(x), 5625) for x in sigs)
 c = pnr_amd.Context(p, 0)
 c.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
 c.set_profiling(True)
@@ -24,4 +27,4 @@ for rep in range(2):
         print('   ', g, c.kernel_ms(g))
     steps = int((T + (T < p.ni)).sum())  # iterations executed incl. the failing one
     ms, _ = c.kernel_ms('smc')
-    print('   trace-iterations', steps, 'evals', steps * 201, 'Mevals/s', steps * 201 / ms / 1e3, 'ms/iter/trace-avg', ms / max(steps, 1))
+    print('   trace-iterations', steps, 'evals', steps * 201, 'Mevals/s', steps * 201 / ms / 1e3, 'ms/iter/trace-avg', ms / max(steps, 1), 'Gsamples/s', steps * 201 * nchain / ms / 1e6, 'kernel ms / longest trace iters', ms / max(1, int(T.max()) + 1))
