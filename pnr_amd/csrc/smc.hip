@@ -83,9 +83,7 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi)
     const float c = (x < lo) ? lo : x;
     return (c > hi) ? hi : c;
 }
-// same value as clampf for every non-NaN x (lo <= hi); the sign of a zero result may differ, which
-// cannot change an interpolated value (it only multiplies/adds into non-negative image samples)
-__device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
 
 // Tracker::interp, 3-D branch (tracker.cpp:2178-2213)
 __device__ __forceinline__ float interp(const Vol &V, float x, float y, float z)
@@ -254,49 +252,98 @@ __device__ __forceinline__ int cdf_search(const float *__restrict__ cws, int n, 
 
 // The u8 neighbourhood of the current particle cloud, staged in LDS once per SMC iteration:
 // axis-aligned box [o, o+b) chosen from the bounding box of every particle's template.
+typedef __attribute__((address_space(3))) const volatile unsigned char lds_cu8; // LDS-qualified: ds_read_u8, never flat_load
 struct Box {
-    const unsigned char *lds;
+    lds_cu8 *lds;
     int ox, oy, oz, bx, by, bz, sxy, base; // base = -(oz*sxy + oy*bx + ox)
 };
-
-// Tracker::interp with the 8 corners fetched from the LDS box; CHECK: a corner outside the box
-// (box had to be clipped to fit LDS) is fetched from HBM/L2 instead.
-template <bool CHECK>
-__device__ __forceinline__ float interp_box(const Vol &V, const Box &B, float x, float y, float z)
-{
-    const float xc = clamp3(x, 0.f, V.xmax);
-    const int x1 = (int)xc;
-    const float xf = xc - (float)x1;
-    const float yc = clamp3(y, 0.f, V.ymax);
-    const int y1 = (int)yc;
-    const float yf = yc - (float)y1;
-    const float zc = clamp3(z, 0.f, V.zmax);
-    const int z1 = (int)zc;
-    const float zf = zc - (float)z1;
-    float a00, a01, a10, a11, b00, b01, b10, b11;
-    bool in = true;
-    if (CHECK) {
-        const unsigned rx = (unsigned)(x1 - B.ox), ry = (unsigned)(y1 - B.oy), rz = (unsigned)(z1 - B.oz);
-        in = (rx < (unsigned)(B.bx - 1)) && (ry < (unsigned)(B.by - 1)) && (rz < (unsigned)(B.bz - 1));
-    }
-    if (in) {
-        const unsigned char *a = B.lds + (__mul24(z1, B.sxy) + __mul24(y1, B.bx) + x1 + B.base);
-        const unsigned char *a2 = a + B.bx, *b = a + B.sxy, *b2 = b + B.bx;
-        a00 = a[0]; a01 = a[1]; a10 = a2[0]; a11 = a2[1];
-        b00 = b[0]; b01 = b[1]; b10 = b2[0]; b11 = b2[1];
-    } else {
-        const unsigned char *a = V.img + (i64)z1 * V.wh + (i64)y1 * V.w + x1;
-        const unsigned char *b = a + V.wh;
-        a00 = a[0]; a01 = a[1]; a10 = a[V.w]; a11 = a[V.w + 1];
-        b00 = b[0]; b01 = b[1]; b10 = b[V.w]; b11 = b[V.w + 1];
-    }
-    return (1 - zf) * ((1 - yf) * ((1 - xf) * a00 + xf * a01) + (yf) * ((1 - xf) * a10 + xf * a11)) +
-           (zf) * ((1 - yf) * ((1 - xf) * b00 + xf * b01) + (yf) * ((1 - xf) * b10 + xf * b11));
-}
 
 __device__ __forceinline__ float bcast(float v, int lane) // wave-uniform lane index -> SGPR broadcast
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// same value as clampf for every non-NaN x (lo <= hi); the sign of a zero result may differ, which
+// cannot change an interpolated value (it only multiplies/adds into non-negative image samples)
+__device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
+// bytes p[0], p[1] from LDS as TWO ds_read_u8.  Measured on gfx950 (scripts/probes/lds_gather.hip): an
+// unaligned ds_read_u16 costs ~333 cycles per wave-instruction (misaligned lanes are replayed), a
+// ds_read_u8 ~3 -- and hipcc merges adjacent byte loads into ds_read_u16 unless told not to.
+__device__ __forceinline__ unsigned lds_pair(lds_cu8 *q)
+{
+    const unsigned lo = q[0], hi = q[1];
+    return lo | (hi << 8);
+}
+__device__ __forceinline__ unsigned glb_pair(const unsigned char *p)
+{
+    unsigned short v;
+    __builtin_memcpy(&v, p, 2);
+    return v;
+}
+
+// Trilinear samples of G consecutive template points (Tracker::interp, tracker.cpp:2178-2213),
+// corners fetched as four (x1, x1+1) byte pairs from the LDS box.  A corner group outside the box
+// (the bounding box of the whole particle cloud does not always fit the 160 KB LDS) is fetched from
+// HBM/L2 instead; all G*4 loads of a group are issued before the first use, so the memory latency
+// is paid once per group and the G interpolations overlap.
+template <int G>
+struct Samples {
+    float v[G];
+};
+
+template <int G>
+__device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, const float (&x)[G], const float (&y)[G],
+                                                   const float (&z)[G])
+{
+    float xf[G], yf[G], zf[G];
+    unsigned p00[G], p10[G], q00[G], q10[G];
+    int loff[G];
+    bool in[G];
+    bool all_in = true;
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        const float xc = clamp3(x[j], 0.f, V.xmax), yc = clamp3(y[j], 0.f, V.ymax), zc = clamp3(z[j], 0.f, V.zmax);
+        const int x1 = (int)xc, y1 = (int)yc, z1 = (int)zc;
+        xf[j] = xc - (float)x1;
+        yf[j] = yc - (float)y1;
+        zf[j] = zc - (float)z1;
+        const unsigned rx = (unsigned)(x1 - B.ox), ry = (unsigned)(y1 - B.oy), rz = (unsigned)(z1 - B.oz);
+        in[j] = (rx < (unsigned)(B.bx - 1)) && (ry < (unsigned)(B.by - 1)) && (rz < (unsigned)(B.bz - 1));
+        all_in = all_in && in[j];
+        loff[j] = in[j] ? (__mul24(z1, B.sxy) + __mul24(y1, B.bx) + x1 + B.base) : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        lds_cu8 *a = B.lds + loff[j];
+        p00[j] = lds_pair(a);
+        p10[j] = lds_pair(a + B.bx);
+        q00[j] = lds_pair(a + B.sxy);
+        q10[j] = lds_pair(a + B.sxy + B.bx);
+    }
+    if (__builtin_amdgcn_ballot_w64(!all_in) != 0ull) { // wave-uniform: some lane has a corner group outside the box
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            if (!in[j]) { // rare: recompute the voxel index instead of keeping it live for every sample
+                const int x1 = (int)clamp3(x[j], 0.f, V.xmax), y1 = (int)clamp3(y[j], 0.f, V.ymax), z1 = (int)clamp3(z[j], 0.f, V.zmax);
+                const unsigned char *a = V.img + ((i64)z1 * V.wh + (i64)y1 * V.w + x1);
+                p00[j] = glb_pair(a);
+                p10[j] = glb_pair(a + V.w);
+                q00[j] = glb_pair(a + V.wh);
+                q10[j] = glb_pair(a + V.wh + V.w);
+            }
+        }
+    }
+    Samples<G> r;
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        const float a00 = (float)(p00[j] & 255u), a01 = (float)(p00[j] >> 8), a10 = (float)(p10[j] & 255u), a11 = (float)(p10[j] >> 8);
+        const float b00 = (float)(q00[j] & 255u), b01 = (float)(q00[j] >> 8), b10 = (float)(q10[j] & 255u), b11 = (float)(q10[j] >> 8);
+        const float fx = xf[j], fy = yf[j], fz = zf[j];
+        r.v[j] = (1 - fz) * ((1 - fy) * ((1 - fx) * a00 + fx * a01) + (fy) * ((1 - fx) * a10 + fx * a11)) +
+                 (fz) * ((1 - fy) * ((1 - fx) * b00 + fx * b01) + (fy) * ((1 - fx) * b10 + fx * b11));
+    }
+    return r;
 }
 
 // one (pose, sigma) chain on the LDS box.  Same operations in the same order as znccBBB: the
@@ -305,12 +352,15 @@ __device__ __forceinline__ float bcast(float v, int lane) // wave-uniform lane i
 // three axis value lists (vv | uu | ww) of this sigma, `wd` = wgt - avg per sample.
 // The template values are wave-uniform: each is fetched ONCE per wave by a coalesced vector load
 // (lane i holds element i of the row) and broadcast with v_readlane, so the inner loop has no
-// memory access other than the four 16-bit LDS corner-pair reads.  MUST be called with all 64
-// lanes of the wave active (callers give idle lanes a dummy pose).
-template <bool CHECK>
+// memory access other than the corner-pair reads.  Samples are interpolated G at a time (their
+// loads in flight together) and then added in sample order.  MUST be called with all 64 lanes of
+// the wave active (callers give idle lanes a dummy pose).
+constexpr int CHAIN_G = 8;
+
 __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
                                                 const float *__restrict__ ax, const float *__restrict__ wd, float corrc)
 {
+    constexpr int G = CHAIN_G;
     const int lane = threadIdx.x & 63;
     const float r_av = ax[lane < nv ? lane : 0];
     const float r_au = ax[nv + (lane < nu ? lane : 0)];
@@ -322,9 +372,20 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
         for (int iu = 0; iu < nu; ++iu) {
             const float uu = bcast(r_au, iu);
             const float x1 = x0 + uu * f.ux, y1 = y0 + uu * f.uy, z1 = z0 + uu * f.uz;
-            for (int iw = 0; iw < nw; ++iw) {
-                const float ww = bcast(r_aw, iw);
-                ag += interp_box<CHECK>(V, B, x1 + ww * f.wx, y1 + ww * f.wy, z1 + ww * f.wz);
+            for (int iw0 = 0; iw0 < nw; iw0 += G) {
+                float xs[G], ys[G], zs[G];
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    const int iw = (iw0 + j < nw) ? iw0 + j : nw - 1; // wave-uniform
+                    const float ww = bcast(r_aw, iw);
+                    xs[j] = x1 + ww * f.wx;
+                    ys[j] = y1 + ww * f.wy;
+                    zs[j] = z1 + ww * f.wz;
+                }
+                const Samples<G> sm = interp_group<G>(V, B, xs, ys, zs);
+#pragma unroll
+                for (int j = 0; j < G; j++)
+                    if (iw0 + j < nw) ag += sm.v[j];
             }
         }
     }
@@ -343,11 +404,24 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
             const bool more = (iv * nu + iu + 1) < nv * nu;
             const float *nxt = more ? wk : wk - nw; // after the last row: re-read it (stays in range)
             r_wd = nxt[lane < nw ? lane : 0];
-            for (int iw = 0; iw < nw; ++iw) {
-                const float ww = bcast(r_aw, iw);
-                const float di = interp_box<CHECK>(V, B, x1 + ww * f.wx, y1 + ww * f.wy, z1 + ww * f.wz) - ag;
-                corra += di * bcast(r_cur, iw);
-                corrb = (float)((double)corrb + (double)di * (double)di); // corrb += pow(f32,2)
+            for (int iw0 = 0; iw0 < nw; iw0 += G) {
+                float xs[G], ys[G], zs[G];
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    const int iw = (iw0 + j < nw) ? iw0 + j : nw - 1;
+                    const float ww = bcast(r_aw, iw);
+                    xs[j] = x1 + ww * f.wx;
+                    ys[j] = y1 + ww * f.wy;
+                    zs[j] = z1 + ww * f.wz;
+                }
+                const Samples<G> sm = interp_group<G>(V, B, xs, ys, zs);
+#pragma unroll
+                for (int j = 0; j < G; j++)
+                    if (iw0 + j < nw) {
+                        const float di = sm.v[j] - ag;
+                        corra += di * bcast(r_cur, iw0 + j);
+                        corrb = (float)((double)corrb + (double)di * (double)di); // corrb += pow(f32,2)
+                    }
             }
         }
     }
@@ -363,7 +437,7 @@ struct TabX { // extra template tables for the box kernel
     float ext_v, ext_uw; // largest template half-extents (voxels) along v and along u / w
 };
 
-__global__ __launch_bounds__(1024) void smc_trace(Vol V, Tab T, TabX X, const float *__restrict__ seeds6, int np, int np_pad,
+__global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const float *__restrict__ seeds6, int np, int np_pad,
                                                    int ni, float Kc, float znccth, float neff_ratio, int box_cap, TraceOut O)
 {
     extern __shared__ float lds[];
@@ -486,12 +560,11 @@ __global__ __launch_bounds__(1024) void smc_trace(Vol V, Tab T, TabX X, const fl
         }
         __syncthreads();
         Box Bx;
-        Bx.lds = cube;
+        Bx.lds = (lds_cu8 *)cube;
         Bx.ox = sbox[6]; Bx.oy = sbox[7]; Bx.oz = sbox[8];
         Bx.bx = sbox[9]; Bx.by = sbox[10]; Bx.bz = sbox[11];
         Bx.sxy = Bx.bx * Bx.by;
         Bx.base = -(Bx.oz * Bx.sxy + Bx.oy * Bx.bx + Bx.ox);
-        const int clipped = sflag[3];
         { // stage the box: one wave per (z,y) row, lanes along x (coalesced bytes)
             const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6;
             const int rows = Bx.by * Bx.bz;
@@ -539,9 +612,7 @@ __global__ __launch_bounds__(1024) void smc_trace(Vol V, Tab T, TabX X, const fl
             const int nv = __builtin_amdgcn_readfirstlane(g.nv), nu = __builtin_amdgcn_readfirstlane(g.nu);
             const int nw = __builtin_amdgcn_readfirstlane(g.nw), goff = __builtin_amdgcn_readfirstlane(g.off);
             const float *ax = X.axes + __builtin_amdgcn_readfirstlane(X.axes_off[s]);
-            float cv;
-            if (clipped) cv = zncc_chain_box<true>(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s]);
-            else cv = zncc_chain_box<false>(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s]);
+            const float cv = zncc_chain_box(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s]);
             if (valid) corr_ks[s * np_pad + k] = cv;
         }
         __syncthreads();
@@ -737,7 +808,7 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
     const int box_cap = (int)(lds_total - fixed - 64);
     const size_t lds = fixed + (size_t)box_cap;
     int block = S * np_pad;
-    if (block > 1024) block = 1024;
+    if (block > 768) block = 768; // 12 waves = 3 per SIMD: up to 168 VGPRs for the 8-sample groups
     for (int s = 0; s < S; s++)
         PNR_REQUIRE(c->tab.grid[4 * s] <= 64 && c->tab.grid[4 * s + 1] <= 64 && c->tab.grid[4 * s + 2] <= 64, PNR_E_ARG,
                     "template grid axis longer than a wavefront");
