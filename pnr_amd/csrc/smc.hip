@@ -250,12 +250,14 @@ __device__ __forceinline__ int cdf_search(const float *__restrict__ cws, int n, 
     return lo;
 }
 
-// The u8 neighbourhood of the current particle cloud, staged in LDS once per SMC iteration:
-// axis-aligned box [o, o+b) chosen from the bounding box of every particle's template.
-typedef __attribute__((address_space(3))) const volatile unsigned char lds_cu8; // LDS-qualified: ds_read_u8, never flat_load
+// The u8 neighbourhood of the current particle cloud, staged in LDS once per SMC iteration: a
+// CS^3 byte cube (CS compile-time: corner offsets become immediates) centred on the bounding box of
+// every particle's template.  The union of 200 differently oriented 13x37x37 templates does not fit
+// 160 KB in general (~65^3): samples whose corners fall outside the cube are fetched from HBM/L2.
+typedef __attribute__((address_space(3))) const unsigned char lds_cu8; // LDS-qualified: ds_read_u8, never flat_load
 struct Box {
     lds_cu8 *lds;
-    int ox, oy, oz, bx, by, bz, sxy, base; // base = -(oz*sxy + oy*bx + ox)
+    int ox, oy, oz;
 };
 
 __device__ __forceinline__ float bcast(float v, int lane) // wave-uniform lane index -> SGPR broadcast
@@ -267,19 +269,16 @@ __device__ __forceinline__ float bcast(float v, int lane) // wave-uniform lane i
 // cannot change an interpolated value (it only multiplies/adds into non-negative image samples)
 __device__ __forceinline__ float clamp3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
-// bytes p[0], p[1] from LDS as TWO ds_read_u8.  Measured on gfx950 (scripts/probes/lds_gather.hip): an
+// Corner bytes are fetched with ds_read_u8 only.  Measured on gfx950 (scripts/probes/lds_gather.hip): an
 // unaligned ds_read_u16 costs ~333 cycles per wave-instruction (misaligned lanes are replayed), a
-// ds_read_u8 ~3 -- and hipcc merges adjacent byte loads into ds_read_u16 unless told not to.
-__device__ __forceinline__ unsigned lds_pair(lds_cu8 *q)
+// ds_read_u8 ~3 -- and hipcc merges the adjacent loads p[0], p[1] into one ds_read_u16.  The x+1
+// bytes are therefore read through a second base pointer whose relation to the first is hidden
+// from the optimiser (one v_add per sample, no volatile: the 8*G loads of a group stay in flight).
+__device__ __forceinline__ lds_cu8 *lds_plus1_opaque(lds_cu8 *a)
 {
-    const unsigned lo = q[0], hi = q[1];
-    return lo | (hi << 8);
-}
-__device__ __forceinline__ unsigned glb_pair(const unsigned char *p)
-{
-    unsigned short v;
-    __builtin_memcpy(&v, p, 2);
-    return v;
+    unsigned v = (unsigned)(unsigned long long)(a + 1);
+    asm volatile("" : "+v"(v));
+    return (lds_cu8 *)(unsigned long long)v;
 }
 
 // Trilinear samples of G consecutive template points (Tracker::interp, tracker.cpp:2178-2213),
@@ -292,53 +291,56 @@ struct Samples {
     float v[G];
 };
 
-template <int G>
+template <int G, int CS>
 __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, const float (&x)[G], const float (&y)[G],
                                                    const float (&z)[G])
 {
     float xf[G], yf[G], zf[G];
-    unsigned p00[G], p10[G], q00[G], q10[G];
-    int loff[G];
+    unsigned c[G][8]; // corner bytes: a00 a01 a10 a11 b00 b01 b10 b11
+    unsigned loff[G];
     bool in[G];
     bool all_in = true;
 #pragma unroll
     for (int j = 0; j < G; j++) {
         const float xc = clamp3(x[j], 0.f, V.xmax), yc = clamp3(y[j], 0.f, V.ymax), zc = clamp3(z[j], 0.f, V.zmax);
-        const int x1 = (int)xc, y1 = (int)yc, z1 = (int)zc;
-        xf[j] = xc - (float)x1;
-        yf[j] = yc - (float)y1;
-        zf[j] = zc - (float)z1;
-        const unsigned rx = (unsigned)(x1 - B.ox), ry = (unsigned)(y1 - B.oy), rz = (unsigned)(z1 - B.oz);
-        in[j] = (rx < (unsigned)(B.bx - 1)) && (ry < (unsigned)(B.by - 1)) && (rz < (unsigned)(B.bz - 1));
+        // xc - (float)(int)xc of the reference == xc - floor(xc) for xc >= 0, an exact subtraction: v_fract_f32
+        xf[j] = __builtin_amdgcn_fractf(xc);
+        yf[j] = __builtin_amdgcn_fractf(yc);
+        zf[j] = __builtin_amdgcn_fractf(zc);
+        const unsigned rx = (unsigned)((int)xc - B.ox), ry = (unsigned)((int)yc - B.oy), rz = (unsigned)((int)zc - B.oz);
+        const unsigned m = max(max(rx, ry), rz);
+        in[j] = m < (unsigned)(CS - 1);
         all_in = all_in && in[j];
-        loff[j] = in[j] ? (__mul24(z1, B.sxy) + __mul24(y1, B.bx) + x1 + B.base) : 0;
+        const unsigned l = __umul24(rz, CS * CS) + __umul24(ry, CS) + rx;
+        loff[j] = in[j] ? l : 0u;
     }
 #pragma unroll
     for (int j = 0; j < G; j++) {
         lds_cu8 *a = B.lds + loff[j];
-        p00[j] = lds_pair(a);
-        p10[j] = lds_pair(a + B.bx);
-        q00[j] = lds_pair(a + B.sxy);
-        q10[j] = lds_pair(a + B.sxy + B.bx);
+        lds_cu8 *a1 = lds_plus1_opaque(a);
+        c[j][0] = a[0];            c[j][1] = a1[0];
+        c[j][2] = a[CS];           c[j][3] = a1[CS];
+        c[j][4] = a[CS * CS];      c[j][5] = a1[CS * CS];
+        c[j][6] = a[CS * CS + CS]; c[j][7] = a1[CS * CS + CS];
     }
-    if (__builtin_amdgcn_ballot_w64(!all_in) != 0ull) { // wave-uniform: some lane has a corner group outside the box
+    if (__builtin_amdgcn_ballot_w64(!all_in) != 0ull) { // wave-uniform: some lane has a corner group outside the cube
 #pragma unroll
         for (int j = 0; j < G; j++) {
             if (!in[j]) { // rare: recompute the voxel index instead of keeping it live for every sample
                 const int x1 = (int)clamp3(x[j], 0.f, V.xmax), y1 = (int)clamp3(y[j], 0.f, V.ymax), z1 = (int)clamp3(z[j], 0.f, V.zmax);
                 const unsigned char *a = V.img + ((i64)z1 * V.wh + (i64)y1 * V.w + x1);
-                p00[j] = glb_pair(a);
-                p10[j] = glb_pair(a + V.w);
-                q00[j] = glb_pair(a + V.wh);
-                q10[j] = glb_pair(a + V.wh + V.w);
+                c[j][0] = a[0];        c[j][1] = a[1];
+                c[j][2] = a[V.w];      c[j][3] = a[V.w + 1];
+                c[j][4] = a[V.wh];     c[j][5] = a[V.wh + 1];
+                c[j][6] = a[V.wh + V.w]; c[j][7] = a[V.wh + V.w + 1];
             }
         }
     }
     Samples<G> r;
 #pragma unroll
     for (int j = 0; j < G; j++) {
-        const float a00 = (float)(p00[j] & 255u), a01 = (float)(p00[j] >> 8), a10 = (float)(p10[j] & 255u), a11 = (float)(p10[j] >> 8);
-        const float b00 = (float)(q00[j] & 255u), b01 = (float)(q00[j] >> 8), b10 = (float)(q10[j] & 255u), b11 = (float)(q10[j] >> 8);
+        const float a00 = (float)c[j][0], a01 = (float)c[j][1], a10 = (float)c[j][2], a11 = (float)c[j][3];
+        const float b00 = (float)c[j][4], b01 = (float)c[j][5], b10 = (float)c[j][6], b11 = (float)c[j][7];
         const float fx = xf[j], fy = yf[j], fz = zf[j];
         r.v[j] = (1 - fz) * ((1 - fy) * ((1 - fx) * a00 + fx * a01) + (fy) * ((1 - fx) * a10 + fx * a11)) +
                  (fz) * ((1 - fy) * ((1 - fx) * b00 + fx * b01) + (fy) * ((1 - fx) * b10 + fx * b11));
@@ -355,8 +357,9 @@ __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, c
 // memory access other than the corner-pair reads.  Samples are interpolated G at a time (their
 // loads in flight together) and then added in sample order.  MUST be called with all 64 lanes of
 // the wave active (callers give idle lanes a dummy pose).
-constexpr int CHAIN_G = 8;
+constexpr int CHAIN_G = 5; // nw is 25 or 13: groups of 5 leave no / little tail; 40 corner bytes in flight per lane
 
+template <int CS>
 __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
                                                 const float *__restrict__ ax, const float *__restrict__ wd, float corrc)
 {
@@ -382,7 +385,7 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
                     ys[j] = y1 + ww * f.wy;
                     zs[j] = z1 + ww * f.wz;
                 }
-                const Samples<G> sm = interp_group<G>(V, B, xs, ys, zs);
+                const Samples<G> sm = interp_group<G, CS>(V, B, xs, ys, zs);
 #pragma unroll
                 for (int j = 0; j < G; j++)
                     if (iw0 + j < nw) ag += sm.v[j];
@@ -414,7 +417,7 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
                     ys[j] = y1 + ww * f.wy;
                     zs[j] = z1 + ww * f.wz;
                 }
-                const Samples<G> sm = interp_group<G>(V, B, xs, ys, zs);
+                const Samples<G> sm = interp_group<G, CS>(V, B, xs, ys, zs);
 #pragma unroll
                 for (int j = 0; j < G; j++)
                     if (iw0 + j < nw) {
@@ -437,8 +440,9 @@ struct TabX { // extra template tables for the box kernel
     float ext_v, ext_uw; // largest template half-extents (voxels) along v and along u / w
 };
 
+template <int CS>
 __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const float *__restrict__ seeds6, int np, int np_pad,
-                                                   int ni, float Kc, float znccth, float neff_ratio, int box_cap, TraceOut O)
+                                                  int ni, float Kc, float znccth, float neff_ratio, TraceOut O)
 {
     extern __shared__ float lds[];
     const int tr = blockIdx.x, tid = threadIdx.x, B = blockDim.x, S = T.nsig;
@@ -540,58 +544,36 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
         }
         __syncthreads();
         STAMP(1); // P1 prediction
-        if (tid == 0) { // box = bounding box clipped to the volume, then to the LDS capacity
-            int lo[3], hi[3];
+        if (tid == 0) { // cube origin: centred on the bounding box of all templates, kept inside the volume
             const int dim[3] = {V.w, V.h, V.l};
-            for (int a = 0; a < 3; a++) { // box must hold x1 and x1+1 of every sample: at least 2 voxels, inside the volume
-                lo[a] = sbox[a] < 0 ? 0 : (sbox[a] > dim[a] - 2 ? dim[a] - 2 : sbox[a]);
-                hi[a] = sbox[3 + a] > dim[a] - 1 ? dim[a] - 1 : (sbox[3 + a] < lo[a] + 1 ? lo[a] + 1 : sbox[3 + a]);
+            for (int a = 0; a < 3; a++) {
+                const int lo = sbox[a] < 0 ? 0 : (sbox[a] > dim[a] - 1 ? dim[a] - 1 : sbox[a]);
+                const int hi = sbox[3 + a] > dim[a] - 1 ? dim[a] - 1 : (sbox[3 + a] < lo ? lo : sbox[3 + a]);
+                int o = (lo + hi + 1) / 2 - CS / 2;
+                if (o > dim[a] - CS) o = dim[a] - CS;
+                if (o < 0) o = 0;
+                sbox[6 + a] = o;
             }
-            int clipped = sflag[3]; // non-finite pose seen: checked path
-            while ((i64)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1) > box_cap) {
-                int a = 0; // shrink the longest side symmetrically
-                if (hi[1] - lo[1] > hi[a] - lo[a]) a = 1;
-                if (hi[2] - lo[2] > hi[a] - lo[a]) a = 2;
-                lo[a]++; hi[a]--;
-                clipped = 1;
-            }
-            for (int a = 0; a < 3; a++) { sbox[6 + a] = lo[a]; sbox[9 + a] = hi[a] - lo[a] + 1; }
-            sflag[3] = clipped;
         }
         __syncthreads();
         Box Bx;
         Bx.lds = (lds_cu8 *)cube;
         Bx.ox = sbox[6]; Bx.oy = sbox[7]; Bx.oz = sbox[8];
-        Bx.bx = sbox[9]; Bx.by = sbox[10]; Bx.bz = sbox[11];
-        Bx.sxy = Bx.bx * Bx.by;
-        Bx.base = -(Bx.oz * Bx.sxy + Bx.oy * Bx.bx + Bx.ox);
-        { // stage the box: one wave per (z,y) row, lanes along x (coalesced bytes)
+        { // stage the cube: one wave per (z,y) row, lanes along x (coalesced bytes), 4 rows in flight
             const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6;
-            const int rows = Bx.by * Bx.bz;
-            for (int r0 = wv; r0 < rows; r0 += 4 * nwv) { // 4 rows in flight per wave
+            const int xg = Bx.ox + lane < V.w ? Bx.ox + lane : V.w - 1; // beyond the volume: never addressed, load anything valid
+            for (int r0 = wv; r0 < CS * CS; r0 += 4 * nwv) {
                 unsigned char v[4];
-                bool ok[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int r = r0 + j * nwv;
-                    ok[j] = (r < rows) && (lane < Bx.bx);
-                    const int rr = ok[j] ? r : 0;
-                    const int zz = rr / Bx.by, yy = rr - zz * Bx.by;
-                    const unsigned char *src = V.img + (i64)(Bx.oz + zz) * V.wh + (i64)(Bx.oy + yy) * V.w + Bx.ox;
-                    v[j] = ok[j] ? src[lane] : (unsigned char)0;
+                    const int r = r0 + j * nwv < CS * CS ? r0 + j * nwv : CS * CS - 1;
+                    const int zz = r / CS, yy = r - zz * CS;
+                    const int zg = Bx.oz + zz < V.l ? Bx.oz + zz : V.l - 1, yg = Bx.oy + yy < V.h ? Bx.oy + yy : V.h - 1;
+                    v[j] = V.img[(i64)zg * V.wh + (i64)yg * V.w + xg];
                 }
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (ok[j]) cube[(r0 + j * nwv) * Bx.bx + lane] = v[j];
-                for (int xx = lane + 64; xx < Bx.bx; xx += 64) // rows wider than a wave (large sigma sets)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int r = r0 + j * nwv;
-                        if (r < rows) {
-                            const int zz = r / Bx.by, yy = r - zz * Bx.by;
-                            cube[r * Bx.bx + xx] = V.img[(i64)(Bx.oz + zz) * V.wh + (i64)(Bx.oy + yy) * V.w + Bx.ox + xx];
-                        }
-                    }
+                    if (r0 + j * nwv < CS * CS && lane < CS) cube[(r0 + j * nwv) * CS + lane] = v[j];
             }
         }
         __syncthreads();
@@ -612,7 +594,7 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
             const int nv = __builtin_amdgcn_readfirstlane(g.nv), nu = __builtin_amdgcn_readfirstlane(g.nu);
             const int nw = __builtin_amdgcn_readfirstlane(g.nw), goff = __builtin_amdgcn_readfirstlane(g.off);
             const float *ax = X.axes + __builtin_amdgcn_readfirstlane(X.axes_off[s]);
-            const float cv = zncc_chain_box(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s]);
+            const float cv = zncc_chain_box<CS>(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s]);
             if (valid) corr_ks[s * np_pad + k] = cv;
         }
         __syncthreads();
@@ -804,9 +786,14 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
     if (dbg_iters < 0) dbg_iters = 0;
     const size_t fixed = trace_fixed_lds_bytes(np, np_pad, S);
     const size_t lds_total = 160 * 1024;
-    PNR_REQUIRE(fixed + 16 * 1024 <= lds_total, PNR_E_ARG, "np=%d needs %zu B of LDS state: no room for the image box", np, fixed);
-    const int box_cap = (int)(lds_total - fixed - 64);
-    const size_t lds = fixed + (size_t)box_cap;
+    // largest cube that still fits beside the particle state
+    static const int cube_sides[] = {52, 48, 44, 40, 36, 32};
+    int CS = 0;
+    for (int cs : cube_sides)
+        if (fixed + (size_t)cs * cs * cs + 64 <= lds_total) { CS = cs; break; }
+    PNR_REQUIRE(CS > 0, PNR_E_ARG, "np=%d needs %zu B of LDS state: no room for the image cube", np, fixed);
+    PNR_REQUIRE(CS <= 64, PNR_E_ARG, "cube side must fit a wavefront");
+    const size_t lds = fixed + (size_t)CS * CS * CS;
     int block = S * np_pad;
     if (block > 768) block = 768; // 12 waves = 3 per SIMD: up to 168 VGPRs for the 8-sample groups
     for (int s = 0; s < S; s++)
@@ -838,10 +825,22 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
     }
     if (dbg_iters > 0 && neff) PNR_HIP(hipMalloc(&O.neff, (size_t)ntr * dbg_iters * 4));
     PNR_HIP(hipMemcpyAsync(d_s6, s6.data(), s6.size() * 4, hipMemcpyHostToDevice, c->stream));
-    PNR_HIP(hipFuncSetAttribute((const void *)smc_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     c->tic();
-    hipLaunchKernelGGL(smc_trace, dim3((unsigned)ntr), dim3(block), lds, c->stream, V, T, X, d_s6, np, np_pad, ni, c->prm.Kc,
-                       c->prm.znccth, c->prm.neff_ratio, box_cap, O);
+#define PNR_LAUNCH_TRACE(cs)                                                                                                  \
+    case cs:                                                                                                                  \
+        PNR_HIP(hipFuncSetAttribute((const void *)smc_trace<cs>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+        hipLaunchKernelGGL(smc_trace<cs>, dim3((unsigned)ntr), dim3(block), lds, c->stream, V, T, X, d_s6, np, np_pad, ni,   \
+                           c->prm.Kc, c->prm.znccth, c->prm.neff_ratio, O);                                                   \
+        break;
+    switch (CS) {
+        PNR_LAUNCH_TRACE(52)
+        PNR_LAUNCH_TRACE(48)
+        PNR_LAUNCH_TRACE(44)
+        PNR_LAUNCH_TRACE(40)
+        PNR_LAUNCH_TRACE(36)
+        PNR_LAUNCH_TRACE(32)
+    }
+#undef PNR_LAUNCH_TRACE
     c->toc("smc");
     PNR_HIP(hipGetLastError());
     PNR_HIP(hipMemcpyAsync(T_out, O.T, (size_t)ntr * 4, hipMemcpyDeviceToHost, c->stream));
