@@ -84,6 +84,12 @@ struct pnr_ctx {
     float *d_axes = nullptr, *d_wd = nullptr;
     uint32_t *d_rng = nullptr;
 
+    // SMC pass-1 sample stash (HBM scratch, sized at the first trace batch)
+    float *d_stash = nullptr;
+    int *d_slot_busy = nullptr;
+    size_t stash_bytes = 0;
+    int stash_slots = 0;
+
     // seeds
     std::vector<pnr_seed> seeds;
 

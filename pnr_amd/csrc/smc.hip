@@ -21,8 +21,10 @@
 //     CDF walk.  The centroid's own ZNCC is sampled by the whole group into LDS and summed in
 //     order by one lane per sigma.
 #include "ctx.h"
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 typedef long long i64;
@@ -359,9 +361,15 @@ __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, c
 // the wave active (callers give idle lanes a dummy pose).
 constexpr int CHAIN_G = 5; // nw is 25 or 13: groups of 5 leave no / little tail; 40 corner bytes in flight per lane
 
-template <int CS>
+// `stash` (may be null): this wave's scratch region in HBM, [sample][lane] f32.  Pass 1 writes
+// every interpolated sample there (coalesced 256 B per wave-store); pass 2 reads them back in
+// order instead of re-sampling -- same values, same order, so the sums are unchanged, while the
+// second pass drops from ~65 VALU + 8 LDS gathers per sample to one coalesced load and the
+// (di, di*wd, di^2) updates.  19.4 MB of streamed scratch per SMC iteration per work-group.
+template <int CS, bool STASH>
 __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
-                                                const float *__restrict__ ax, const float *__restrict__ wd, float corrc)
+                                                const float *__restrict__ ax, const float *__restrict__ wd, float corrc,
+                                                float *__restrict__ stash)
 {
     constexpr int G = CHAIN_G;
     const int lane = threadIdx.x & 63;
@@ -369,6 +377,7 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
     const float r_au = ax[nv + (lane < nu ? lane : 0)];
     const float r_aw = ax[nv + nu + (lane < nw ? lane : 0)];
     float ag = 0.f;
+    float *sp = stash + lane;
     for (int iv = 0; iv < nv; ++iv) {
         const float vv = bcast(r_av, iv);
         const float x0 = f.px + vv * f.nvx, y0 = f.py + vv * f.nvy, z0 = f.pz + vv * f.nvz;
@@ -388,12 +397,46 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
                 const Samples<G> sm = interp_group<G, CS>(V, B, xs, ys, zs);
 #pragma unroll
                 for (int j = 0; j < G; j++)
-                    if (iw0 + j < nw) ag += sm.v[j];
+                    if (iw0 + j < nw) {
+                        ag += sm.v[j];
+                        if (STASH) sp[(iw0 + j) * 64] = sm.v[j];
+                    }
             }
+            if (STASH) sp += nw * 64;
         }
     }
     ag /= (float)(nv * nu * nw);
     float corra = 0.f, corrb = 0.f;
+    if (STASH) {
+        // pass 2 from the stash: a flat, software-pipelined stream over the M samples.  Chunk c+1 (32
+        // values per lane + the 32 template weights of the wave) is in flight while chunk c is summed.
+        constexpr int CH = 32;
+        const int M = nv * nu * nw;
+        sp = stash + lane;
+        float cur[CH], nxt[CH];
+        float w_cur, w_nxt;
+#pragma unroll
+        for (int j = 0; j < CH; j++) cur[j] = sp[(j < M ? j : M - 1) * 64];
+        w_cur = wd[(lane < CH && lane < M) ? lane : 0];
+        for (int k0 = 0; k0 < M; k0 += CH) {
+            const int k1 = k0 + CH;
+            if (k1 < M) {
+#pragma unroll
+                for (int j = 0; j < CH; j++) nxt[j] = sp[(k1 + j < M ? k1 + j : M - 1) * 64];
+                w_nxt = wd[(lane < CH && k1 + lane < M) ? k1 + lane : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < CH; j++)
+                if (k0 + j < M) { // wave-uniform
+                    const float di = cur[j] - ag;
+                    corra += di * bcast(w_cur, j);
+                    corrb = (float)((double)corrb + (double)di * (double)di); // corrb += pow(f32,2)
+                }
+#pragma unroll
+            for (int j = 0; j < CH; j++) cur[j] = nxt[j];
+            w_cur = w_nxt;
+        }
+    } else {
     const float *wk = wd;
     float r_wd = wk[lane < nw ? lane : 0]; // row 0 of (wgt - avg); next rows are prefetched one row ahead
     for (int iv = 0; iv < nv; ++iv) {
@@ -428,6 +471,7 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
             }
         }
     }
+    }
     const float prod = corrb * corrc;
     return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f; // tracker.cpp:1955
 }
@@ -438,6 +482,10 @@ struct TabX { // extra template tables for the box kernel
     const int *axes_off;
     const float *wd;    // sum(M): wgt - avg
     float ext_v, ext_uw; // largest template half-extents (voxels) along v and along u / w
+    float *stash;        // nslots x waves x Mmax x 64 f32 of HBM scratch (null: re-sample in pass 2)
+    int *slot_busy;      // nslots flags, 0 = free
+    int nslots;
+    long long slot_floats, wave_floats;
 };
 
 template <int CS>
@@ -454,15 +502,29 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
     int *idxres = (int *)(csw + np);           // [np]
     float *sxc = (float *)(idxres + np);       // [2][8] centroid of iteration it (cur) and it-1 (pending)
     int *sflag = (int *)(sxc + 16);            // [0]=resampled(prev) [1]=stop code [2]=T [3]=box clipped
-    int *sbox = sflag + 4;                     // [0..2]=lo xyz, [3..5]=hi xyz (atomics) then [6..11] = o, b
-    float *sneff = (float *)(sbox + 12);       // [2]
+    int *sbox = sflag + 4;                     // [0..2]=lo xyz, [3..5]=hi xyz (atomics), [6..8] = cube origin, [12] = stash slot
+    float *sneff = (float *)(sbox + 16);       // [2]
     unsigned char *cube = (unsigned char *)(sneff + 2);
 
     const float *sd = seeds6 + (i64)tr * 6;
     const float x0 = sd[0], y0 = sd[1], z0 = sd[2], vx0 = sd[3], vy0 = sd[4], vz0 = sd[5];
-    if (tid == 0) { sflag[0] = 0; sflag[1] = 0; sflag[2] = ni; sflag[3] = 0; }
+    if (tid == 0) {
+        sflag[0] = 0; sflag[1] = 0; sflag[2] = ni; sflag[3] = 0;
+        // scratch slot for the pass-1 sample stash: bounded scan of the free flags (one work-group per
+        // CU is resident, the pool is larger than the CU count); no slot -> this trace re-samples in pass 2
+        int slot = -1;
+        if (X.stash) {
+            for (int tries = 0; tries < 2 * X.nslots && slot < 0; tries++) {
+                const int cand = (int)((blockIdx.x + (unsigned)tries) % (unsigned)X.nslots);
+                if (atomicCAS(&X.slot_busy[cand], 0, 1) == 0) slot = cand;
+            }
+        }
+        sbox[12] = slot;
+    }
     int pending = -1; // iteration whose centroid ZNCC has not been evaluated yet (uniform)
     __syncthreads();
+    const int slot = sbox[12];
+    float *const wave_stash = (slot >= 0) ? X.stash + (i64)slot * X.slot_floats + (i64)(tid >> 6) * X.wave_floats : nullptr;
 #ifdef PNR_SMC_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_prev = __builtin_amdgcn_s_memtime();
@@ -594,7 +656,8 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
             const int nv = __builtin_amdgcn_readfirstlane(g.nv), nu = __builtin_amdgcn_readfirstlane(g.nu);
             const int nw = __builtin_amdgcn_readfirstlane(g.nw), goff = __builtin_amdgcn_readfirstlane(g.off);
             const float *ax = X.axes + __builtin_amdgcn_readfirstlane(X.axes_off[s]);
-            const float cv = zncc_chain_box<CS>(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s]);
+            const float cv = wave_stash ? zncc_chain_box<CS, true>(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s], wave_stash)
+                                        : zncc_chain_box<CS, false>(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s], nullptr);
             if (valid) corr_ks[s * np_pad + k] = cv;
         }
         __syncthreads();
@@ -703,6 +766,7 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
     if (tid == 0) {
         O.T[tr] = sflag[2];
         O.stop[tr] = sflag[1];
+        if (slot >= 0) atomicExch(&X.slot_busy[slot], 0); // all waves are past their last stash access (barrier at loop exit)
 #ifdef PNR_SMC_STAMPS
         if (O.neff) // diagnostic build: phase cycle sums replace the neff tap (8 x u64 per trace needs dbg_iters >= 16)
             for (int i = 0; i < 8; i++) ((unsigned long long *)(O.neff + (i64)tr * O.dbg_iters))[i] = st_acc[i];
@@ -712,7 +776,7 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
 
 size_t trace_fixed_lds_bytes(int np, int np_pad, int S)
 {
-    return (size_t)(2 * np * PSTRIDE + S * np_pad + 3 * np + np + 16 + 4 + 12 + 2) * 4;
+    return (size_t)(2 * np * PSTRIDE + S * np_pad + 3 * np + np + 16 + 4 + 16 + 2) * 4;
 }
 
 int make_vol(pnr_ctx *c, Vol &V)
@@ -802,6 +866,29 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
     TabX X;
     X.grid = (const Grid *)c->d_grid; X.axes = c->d_axes; X.axes_off = c->d_axes_off; X.wd = c->d_wd;
     X.ext_v = c->tab.ext_v; X.ext_uw = c->tab.ext_uw;
+    { // pass-1 sample stash: one region per resident work-group (<= 1 per CU: each takes all 160 KB of LDS)
+        int Mmax = 0;
+        for (int s = 0; s < S; s++) Mmax = std::max(Mmax, c->tab.M[s]);
+        hipDeviceProp_t prop;
+        PNR_HIP(hipGetDeviceProperties(&prop, c->device));
+        const int nslots = prop.multiProcessorCount + 64;
+        const long long wave_floats = (long long)Mmax * 64, slot_floats = wave_floats * (block / 64);
+        const size_t need = (size_t)nslots * slot_floats * 4;
+        if (c->stash_bytes < need || c->stash_slots != nslots) {
+            hipFree(c->d_stash); hipFree(c->d_slot_busy);
+            c->d_stash = nullptr; c->d_slot_busy = nullptr; c->stash_bytes = 0;
+            if (!getenv("PNR_NO_STASH") && hipMalloc(&c->d_stash, need) == hipSuccess && hipMalloc(&c->d_slot_busy, nslots * 4) == hipSuccess) {
+                c->stash_bytes = need;
+                c->stash_slots = nslots;
+            } else {
+                (void)hipGetLastError(); // not enough HBM for the stash: the kernel re-samples in pass 2
+                hipFree(c->d_stash); c->d_stash = nullptr;
+            }
+        }
+        if (c->d_stash) PNR_HIP(hipMemsetAsync(c->d_slot_busy, 0, nslots * 4, c->stream));
+        X.stash = c->d_stash; X.slot_busy = c->d_slot_busy; X.nslots = nslots;
+        X.slot_floats = slot_floats; X.wave_floats = wave_floats;
+    }
 
     std::vector<float> s6((size_t)ntr * 6);
     for (i64 i = 0; i < n; i++) {
