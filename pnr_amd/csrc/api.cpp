@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <unordered_map>
 
 namespace pnr {
 static thread_local char g_err[512] = "";
@@ -388,8 +389,13 @@ int pnr_replay_traces(const pnr_params *p, int64_t w, int64_t h, int64_t l, cons
     PNR_REQUIRE(w > 0 && h > 0 && l > 0, PNR_E_ARG, "bad dimensions");
     const int64_t size = w * h * l;
     const int ni = p->ni, W = (int)w, H = (int)h;
-    std::vector<uint8_t> den((size_t)size, 0); // npervol_map
-    std::vector<int32_t> nidx((size_t)size, 0); // nidx_map
+    // npervol_map / nidx_map of the reference are dense N-voxel arrays (5 B/voxel, 5 GiB at 1024^3);
+    // only voxels that received a node are ever non-zero, so a hash map holds the same state
+    (void)size;
+    struct Cell { uint8_t den = 0; int32_t nidx = 0; };
+    std::unordered_map<int64_t, Cell> cells;
+    cells.reserve(1 << 16);
+    auto den_at = [&](int64_t v) -> int { auto it = cells.find(v); return it == cells.end() ? 0 : (int)it->second.den; };
     int64_t nn = 0, nl = 0;
     auto voxel = [&](float x, float y, float z) {
         return (int64_t)(int)std::round(z) * W * H + (int64_t)(int)std::round(y) * W + (int)std::round(x);
@@ -407,7 +413,7 @@ int pnr_replay_traces(const pnr_params *p, int64_t w, int64_t h, int64_t l, cons
     int trace_count = 0;
     const int maxtr = p->max_trace_count > 0 ? p->max_trace_count : 5000;
     for (int64_t s = 0; s < n; s++) {
-        if (!((int)den[(size_t)voxel(seeds[s].x, seeds[s].y, seeds[s].z)] < p->nodepervol)) continue; // :2669-2670
+        if (!(den_at(voxel(seeds[s].x, seeds[s].y, seeds[s].z)) < p->nodepervol)) continue; // :2669-2670
         trace_count++;
         for (int dir = 0; dir < 2; dir++) {
             const int64_t j = 2 * s + dir;
@@ -417,22 +423,26 @@ int pnr_replay_traces(const pnr_params *p, int64_t w, int64_t h, int64_t l, cons
                 if (i >= T[j]) { ti_limit = i; break; } // iter*New returned false
                 const pnr_xest &e = X[i];
                 const int64_t crd = voxel(e.x, e.y, e.z);
-                if ((int)den[(size_t)crd] >= p->nodepervol) { // density limit: link to the node that owns the voxel
-                    if (i > 0) link(nidx[(size_t)crd], nn - 1);
+                if (den_at(crd) >= p->nodepervol) { // density limit: link to the node that owns the voxel
+                    if (i > 0) link(cells[crd].nidx, nn - 1);
                     ti_limit = i;
                     break;
                 }
                 if (nodes && nn < cap_nodes)
                     nodes[nn] = pnr_node{e.x, e.y, e.z, e.vx, e.vy, e.vz, e.corr, e.sig, (i == 0) ? 7 : 2};
                 nn++;
-                den[(size_t)crd] = (uint8_t)((int)den[(size_t)crd] + 1);
-                nidx[(size_t)crd] = (int32_t)(nn - 1);
+                {
+                    Cell &cc = cells[crd];
+                    cc.den = (uint8_t)((int)cc.den + 1);
+                    cc.nidx = (int32_t)(nn - 1);
+                }
                 if (p->vol > 1) {
                     int64_t nb[26];
                     const int cnt = density_neighbours(crd, (int)w, (int)h, (int)l, p->vol, nb);
                     for (int q = 0; q < cnt; q++) {
-                        den[(size_t)nb[q]] = (uint8_t)((int)den[(size_t)nb[q]] + 1);
-                        nidx[(size_t)nb[q]] = (int32_t)(nn - 1);
+                        Cell &cn = cells[nb[q]];
+                        cn.den = (uint8_t)((int)cn.den + 1);
+                        cn.nidx = (int32_t)(nn - 1);
                     }
                 }
                 if (i > 0) link(nn - 1, nn - 2);

@@ -694,41 +694,61 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
         __syncthreads();
         STAMP(4); // P3
 
-        // ---- P4: weights, N_eff, CDF, centroid (sequential sums in particle order, :1035-1071),
-        //          out-of-volume test and systematic resampling (:1075-1090) ----
+        // ---- P4: weights, N_eff, CDF, centroid (:1035-1071), out-of-volume test, systematic resampling
+        //      (:1075-1090).  Every SUM is a sequential f32 (or f64-add) chain in particle order, as in the
+        //      reference; the element-wise parts run on all lanes and the nine independent chains run side
+        //      by side on nine lanes of wave 0. ----
+        const bool carry = (it > 0) && !resampled_prev;
         if (tid == 0) {
-            float wnorm_prior = 0.f;
-            for (int k = 0; k < np; k++) wnorm_prior += prior[k];
-            const bool carry = (it > 0) && !resampled_prev;
-            float wsum = 0.f;
-            for (int k = 0; k < np; k++) {
+            float a = 0.f;
+            for (int k = 0; k < np; k++) a += prior[k];
+            sneff[1] = a; // wnorm_prior
+        }
+        __syncthreads();
+        {
+            const float wnorm_prior = sneff[1];
+            for (int k = tid; k < np; k += B) {
                 const double base = carry ? (double)prv[k * PSTRIDE + PW] : (1.0 / np);
-                const float wk = (float)(base * (double)(prior[k] / wnorm_prior) * (double)lhood[k]);
-                cur[k * PSTRIDE + PW] = wk;
-                wsum += wk;
+                cur[k * PSTRIDE + PW] = (float)(base * (double)(prior[k] / wnorm_prior) * (double)lhood[k]);
             }
-            float neff = 0.f, acc = 0.f;
-            float cx = 0, cy = 0, cz = 0, cvx = 0, cvy = 0, cvz = 0, csig = 0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float a = 0.f;
+            for (int k = 0; k < np; k++) a += cur[k * PSTRIDE + PW];
+            sneff[1] = a; // wnorm_posterior
+        }
+        __syncthreads();
+        {
+            const float wsum = sneff[1];
+            for (int k = tid; k < np; k += B) cur[k * PSTRIDE + PW] = cur[k * PSTRIDE + PW] / wsum;
+        }
+        __syncthreads();
+        if (tid < 7) { // centroid components x,y,z,vx,vy,vz,sig
+            const int comp = (tid < 6) ? tid : PSIG;
+            float a = 0.f;
+            for (int k = 0; k < np; k++) a += cur[k * PSTRIDE + PW] * cur[k * PSTRIDE + comp];
+            xc_cur[tid] = a;
+        } else if (tid == 7) { // N_eff: neff += pow(w,2) is an f64 add stored to f32
+            float neff = 0.f;
             for (int k = 0; k < np; k++) {
-                float *q = cur + k * PSTRIDE;
-                const float wk = q[PW] / wsum;
-                q[PW] = wk;
+                const float wk = cur[k * PSTRIDE + PW];
                 neff = (float)((double)neff + (double)wk * (double)wk);
-                acc = wk + ((k > 0) ? acc : 0.f);
-                csw[k] = acc;
-                cx += wk * q[PX];
-                cy += wk * q[PY];
-                cz += wk * q[PZ];
-                cvx += wk * q[PVX];
-                cvy += wk * q[PVY];
-                cvz += wk * q[PVZ];
-                csig += wk * q[PSIG];
             }
-            neff = (float)(1.0 / (double)neff);
+            sneff[0] = (float)(1.0 / (double)neff);
+        } else if (tid == 8) { // cumulative sum of weights
+            float acc = 0.f;
+            for (int k = 0; k < np; k++) {
+                acc = cur[k * PSTRIDE + PW] + ((k > 0) ? acc : 0.f);
+                csw[k] = acc;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float cx = xc_cur[0], cy = xc_cur[1], cz = xc_cur[2], cvx = xc_cur[3], cvy = xc_cur[4], cvz = xc_cur[5];
+            const float neff = sneff[0];
             const float vnorm = (float)sqrt((double)cvx * (double)cvx + (double)cvy * (double)cvy + (double)cvz * (double)cvz);
-            xc_cur[0] = cx; xc_cur[1] = cy; xc_cur[2] = cz;
             xc_cur[3] = cvx / vnorm; xc_cur[4] = cvy / vnorm; xc_cur[5] = cvz / vnorm;
-            xc_cur[6] = csig;
             if (it < O.dbg_iters && O.neff) O.neff[(i64)tr * O.dbg_iters + it] = neff;
             const int x1 = (int)roundf(cx), y1 = (int)roundf(cy), z1 = (int)roundf(cz);
             int res = 0;
@@ -736,18 +756,25 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
                 sflag[1] = 1; // left the volume: the centroid's corr is still evaluated (tail pass) for the record
                 sflag[2] = it;
             } else if (neff / np < neff_ratio) {
-                // resampling does not depend on the centroid's corr; if that later fails znccth the
-                // trace ends at this iteration and these indices are never used
-                res = 1;
-                const float u1 = (float)((1.0 / np) * (double)((float)T.rng[(it == 0) ? 1 : np] / (float)2147483647));
-                int s = 0;
-                for (int k = 0; k < np; k++) {
-                    const float ui = (float)((double)u1 + k * (1.0 / np));
-                    while (ui > csw[s] && s < np - 1) s++; // clamp: the reference walks unbounded (:1087,:1192)
-                    idxres[k] = s;
-                }
+                res = 1; // resampling does not depend on the centroid's corr; if that later fails znccth the
+                         // trace ends at this iteration and these indices are never used
             }
             sflag[0] = res;
+        }
+        __syncthreads();
+        if (sflag[0]) {
+            // systematic resampling: the reference walks s upward while ui > csw[s] (unbounded, :1087,:1192;
+            // clamped here to np-1).  csw is non-decreasing, so each k finds the same s by bisection.
+            const float u1 = (float)((1.0 / np) * (double)((float)T.rng[(it == 0) ? 1 : np] / (float)2147483647));
+            for (int k = tid; k < np; k += B) {
+                const float ui = (float)((double)u1 + k * (1.0 / np));
+                int lo = 0, hi = np - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (ui > csw[mid]) lo = mid + 1; else hi = mid;
+                }
+                idxres[k] = lo;
+            }
         }
         __syncthreads();
         STAMP(5); // P4 serial
