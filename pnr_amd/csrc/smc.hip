@@ -476,6 +476,95 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
     return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f; // tracker.cpp:1955
 }
 
+// ---- balanced two-phase form of the chains (used when a stash slot is held) ----------------------
+// Phase A: sampling is order-free, so it is cut into work items (sigma, group of 64 particles,
+// v-slice) that the 12 waves pull from a shared counter: the long (sigma >= 4) and short chains
+// no longer pin the iteration time to the longest chain.  Values go to the stash at [sample][lane].
+template <int CS>
+__device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
+                                             const float *__restrict__ ax, int iv, float *__restrict__ stash_lane)
+{
+    constexpr int G = CHAIN_G;
+    const int lane = threadIdx.x & 63;
+    const float r_au = ax[nv + (lane < nu ? lane : 0)];
+    const float r_aw = ax[nv + nu + (lane < nw ? lane : 0)];
+    const float vv = ax[iv]; // wave-uniform
+    const float x0 = f.px + vv * f.nvx, y0 = f.py + vv * f.nvy, z0 = f.pz + vv * f.nvz;
+    float *sp = stash_lane + (i64)iv * nu * nw * 64;
+    for (int iu = 0; iu < nu; ++iu) {
+        const float uu = bcast(r_au, iu);
+        const float x1 = x0 + uu * f.ux, y1 = y0 + uu * f.uy, z1 = z0 + uu * f.uz;
+        for (int iw0 = 0; iw0 < nw; iw0 += G) {
+            float xs[G], ys[G], zs[G];
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                const int iw = (iw0 + j < nw) ? iw0 + j : nw - 1; // wave-uniform
+                const float ww = bcast(r_aw, iw);
+                xs[j] = x1 + ww * f.wx;
+                ys[j] = y1 + ww * f.wy;
+                zs[j] = z1 + ww * f.wz;
+            }
+            const Samples<G> sm = interp_group<G, CS>(V, B, xs, ys, zs);
+#pragma unroll
+            for (int j = 0; j < G; j++)
+                if (iw0 + j < nw) sp[(iw0 + j) * 64] = sm.v[j];
+        }
+        sp += nw * 64;
+    }
+}
+
+// Phase B: the ordered sums of znccBBB (tracker.cpp:1940-1955) for one chain, streamed from the
+// stash: mean in sample order, then corra / corrb in sample order.  Software-pipelined: 32 values
+// per lane in flight.  All 64 lanes of the wave must call it (template weights are broadcast).
+__device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash_lane, int M, const float *__restrict__ wd,
+                                                 float corrc)
+{
+    constexpr int CH = 32;
+    const int lane = threadIdx.x & 63;
+    float cur[CH], nxt[CH];
+    float ag = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; j++) cur[j] = stash_lane[(j < M ? j : M - 1) * 64];
+    for (int k0 = 0; k0 < M; k0 += CH) {
+        const int k1 = k0 + CH;
+        if (k1 < M) {
+#pragma unroll
+            for (int j = 0; j < CH; j++) nxt[j] = stash_lane[(k1 + j < M ? k1 + j : M - 1) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            if (k0 + j < M) ag += cur[j];
+#pragma unroll
+        for (int j = 0; j < CH; j++) cur[j] = nxt[j];
+    }
+    ag /= (float)M;
+    float corra = 0.f, corrb = 0.f;
+    float w_cur, w_nxt = 0.f;
+#pragma unroll
+    for (int j = 0; j < CH; j++) cur[j] = stash_lane[(j < M ? j : M - 1) * 64];
+    w_cur = wd[(lane < CH && lane < M) ? lane : 0];
+    for (int k0 = 0; k0 < M; k0 += CH) {
+        const int k1 = k0 + CH;
+        if (k1 < M) {
+#pragma unroll
+            for (int j = 0; j < CH; j++) nxt[j] = stash_lane[(k1 + j < M ? k1 + j : M - 1) * 64];
+            w_nxt = wd[(lane < CH && k1 + lane < M) ? k1 + lane : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            if (k0 + j < M) { // wave-uniform
+                const float di = cur[j] - ag;
+                corra += di * bcast(w_cur, j);
+                corrb = (float)((double)corrb + (double)di * (double)di); // corrb += pow(f32,2)
+            }
+#pragma unroll
+        for (int j = 0; j < CH; j++) cur[j] = nxt[j];
+        w_cur = w_nxt;
+    }
+    const float prod = corrb * corrc;
+    return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f; // tracker.cpp:1955
+}
+
 struct TabX { // extra template tables for the box kernel
     const Grid *grid;   // per sigma
     const float *axes;  // per sigma: vv[nv] | uu[nu] | ww[nw], at axes_off[s]
@@ -524,7 +613,6 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
     int pending = -1; // iteration whose centroid ZNCC has not been evaluated yet (uniform)
     __syncthreads();
     const int slot = sbox[12];
-    float *const wave_stash = (slot >= 0) ? X.stash + (i64)slot * X.slot_floats + (i64)(tid >> 6) * X.wave_floats : nullptr;
 #ifdef PNR_SMC_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_prev = __builtin_amdgcn_s_memtime();
@@ -539,7 +627,7 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
         const float *xc_pen = sxc + ((it & 1) ^ 1) * 8;
         const int resampled_prev = sflag[0];
         if (tid < 3) { sbox[tid] = 0x7fffffff; sbox[3 + tid] = -0x7fffffff; }
-        if (tid == 3) sflag[3] = 0;
+        if (tid == 3) { sflag[3] = 0; sbox[13] = 0; } // [13]: phase-A work-item counter
         __syncthreads();
         STAMP(0);
 
@@ -642,6 +730,52 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
         STAMP(2); // box staging
 
         // ---- P2: likelihood chains, sigma-major so a wave shares sigma and sample index ----
+        if (slot >= 0) {
+            float *const slot_base = X.stash + (i64)slot * X.slot_floats;
+            const int ngroups = np_pad >> 6;
+            // phase A: balanced sampling.  Items are enumerated largest sigma first: (s, iv, g).
+            for (;;) {
+                int item = 0;
+                if ((tid & 63) == 0) item = atomicAdd(&sbox[13], 1);
+                item = __builtin_amdgcn_readfirstlane(item);
+                int sI = S - 1, rem = item;
+                while (sI >= 0) {
+                    const int cnt = __builtin_amdgcn_readfirstlane(X.grid[sI].nv) * ngroups;
+                    if (rem < cnt) break;
+                    rem -= cnt;
+                    sI--;
+                }
+                if (sI < 0) break; // uniform: all items handed out
+                const int iv = rem / ngroups, g = rem - iv * ngroups;
+                const int k = g * 64 + (tid & 63);
+                const bool is_cen = (k == np) && (pending >= 0);
+                const bool valid = (k < np && !tail) || is_cen;
+                if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+                const float *q = is_cen ? xc_pen : (valid ? cur + k * PSTRIDE : (tail ? xc_pen : cur));
+                const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
+                const Grid gr = X.grid[sI];
+                const int nv = __builtin_amdgcn_readfirstlane(gr.nv), nu = __builtin_amdgcn_readfirstlane(gr.nu);
+                const int nw = __builtin_amdgcn_readfirstlane(gr.nw);
+                const float *ax = X.axes + __builtin_amdgcn_readfirstlane(X.axes_off[sI]);
+                sample_slice<CS>(V, Bx, f, nv, nu, nw, ax, iv, slot_base + (i64)(sI * ngroups + g) * X.wave_floats + (tid & 63));
+            }
+            __syncthreads(); // stash written by other waves of this work-group: same CU, same L1
+            STAMP(6); // phase A (sampling)
+            // phase B: ordered sums, one lane per chain
+            for (int c = tid; c < S * np_pad; c += B) {
+                const int sI = __builtin_amdgcn_readfirstlane(c / np_pad);
+                const int k = c - sI * np_pad;
+                const bool is_cen = (k == np) && (pending >= 0);
+                const bool valid = (k < np && !tail) || is_cen;
+                if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+                const Grid gr = X.grid[sI];
+                const int M = __builtin_amdgcn_readfirstlane(gr.nv) * __builtin_amdgcn_readfirstlane(gr.nu) * __builtin_amdgcn_readfirstlane(gr.nw);
+                const int goff = __builtin_amdgcn_readfirstlane(gr.off);
+                const float cv = zncc_from_stash(slot_base + (i64)(sI * ngroups + (k >> 6)) * X.wave_floats + (k & 63), M,
+                                                 X.wd + goff, T.corrc[sI]);
+                if (valid) corr_ks[sI * np_pad + k] = cv;
+            }
+        } else
         for (int c = tid; c < S * np_pad; c += B) {
             const int s = __builtin_amdgcn_readfirstlane(c / np_pad);
             const int k = c - s * np_pad;
@@ -656,8 +790,7 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
             const int nv = __builtin_amdgcn_readfirstlane(g.nv), nu = __builtin_amdgcn_readfirstlane(g.nu);
             const int nw = __builtin_amdgcn_readfirstlane(g.nw), goff = __builtin_amdgcn_readfirstlane(g.off);
             const float *ax = X.axes + __builtin_amdgcn_readfirstlane(X.axes_off[s]);
-            const float cv = wave_stash ? zncc_chain_box<CS, true>(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s], wave_stash)
-                                        : zncc_chain_box<CS, false>(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s], nullptr);
+            const float cv = zncc_chain_box<CS, false>(V, Bx, f, nv, nu, nw, ax, X.wd + goff, T.corrc[s], nullptr);
             if (valid) corr_ks[s * np_pad + k] = cv;
         }
         __syncthreads();
@@ -899,7 +1032,7 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
         hipDeviceProp_t prop;
         PNR_HIP(hipGetDeviceProperties(&prop, c->device));
         const int nslots = prop.multiProcessorCount + 64;
-        const long long wave_floats = (long long)Mmax * 64, slot_floats = wave_floats * (block / 64);
+        const long long wave_floats = (long long)Mmax * 64, slot_floats = wave_floats * S * (np_pad / 64);
         const size_t need = (size_t)nslots * slot_floats * 4;
         if (c->stash_bytes < need || c->stash_slots != nslots) {
             hipFree(c->d_stash); hipFree(c->d_slot_busy);

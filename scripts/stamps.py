@@ -14,8 +14,8 @@ c.frangi(); s = c.score_filter_sort(c.extract_seeds())[:nseed]
 T, stop, xc, dbg = c.trace_batch(s, dbg_iters=16)
 st = dbg['neff'].view(np.uint64).reshape(len(T), 8).astype(np.float64)
 iters = (T + (T < p.ni)).astype(np.float64)
-names = ['loop-top', 'P1 predict', 'box stage', 'P2 chains', 'P3 pick', 'P4 serial', '-', '-']
+names = ['loop-top', 'P1 predict', 'box stage', 'P2 chains/B', 'P3 pick', 'P4 serial', 'P2 phase A', '-']
 tot = st.sum()
-for i, nm in enumerate(names[:6]):
+for i, nm in enumerate(names[:7]):
     print(f"{nm:12s} share {st[:, i].sum() / tot:6.3f}   cycles/iter {st[:, i].sum() / iters.sum():12.0f}")
 print('total cycles/iter', tot / iters.sum())
