@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--np", type=int, default=200)
     ap.add_argument("--ni", type=int, default=200)
     ap.add_argument("--mode", choices=["stacks", "shard"], default="stacks")
+    ap.add_argument("--one-shot", action="store_true", help="trace every seed to its map-free end + one replay (no early DENSITY stops)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -130,15 +131,19 @@ def main():
         t3 = time.perf_counter()
         if a.mode == "shard" and world > 1:
             nodes, links, T = multigpu.trace_sharded(ctx, s, dist, rank, world)
+            iters = int((T + (T < a.ni)).sum())
         else:
-            T, stop, xc, _ = ctx.trace_batch(s)
-            t4 = time.perf_counter()
-            nodes, links, _ = ctx.replay(s, T, xc)
+            if a.one_shot:
+                T, stop, xc, _ = ctx.trace_batch(s)
+                nodes, links, _ = ctx.replay(s, T, xc)
+                iters = int((T + (T < a.ni)).sum())
+            else:
+                nodes, links, _, iters = ctx.trace_replay(s)
             if world > 1:
                 multigpu.gather_graphs(nodes, links, dist, rank, world, torch.device("cuda", local))
         t5 = time.perf_counter()
         st.update(frangi_ms=1e3 * (t1 - t0), seeds_ms=1e3 * (t2 - t1), score_ms=1e3 * (t3 - t2), trace_replay_gather_ms=1e3 * (t5 - t3),
-                  n_seeds_init=len(s0), n_seeds=len(s), iters=int((T + (T < a.ni)).sum()), nodes=len(nodes) - 1)
+                  n_seeds_init=len(s0), n_seeds=len(s), iters=iters, nodes=len(nodes) - 1)
         return st
 
     def barrier():
@@ -175,7 +180,9 @@ def main():
         Mtot = sum(len(ctx.table(f"model_wgt{s}")) for s in range(len(sigs)))
         smc_ms, smc_n = km["smc"]
         evals = st["iters"] * (a.np + 1)
-        bytes_launch = 8.0 * Mtot * evals
+        # several launches per step (seed-rank batches): bytes per launch / average launch duration
+        # = total bytes of the timed region / total smc_trace device time
+        bytes_launch = 8.0 * Mtot * evals * a.steps / max(smc_n, 1)
         achieved = bytes_launch / (smc_ms / max(smc_n, 1) * 1e-3) / 1e9 if smc_ms > 0 else 0.0
         fr_ms = (km["gauss"][0] + km["hessian_eigen"][0] + km["j8"][0]) / a.steps
         out = {
@@ -187,7 +194,7 @@ def main():
                                    f"first {a.seeds} sorted seeds traced in both directions per stack, tolerance=5, znccth=0.3, step=2, kappa=3",
                        "parallelism": ("1 GPU" if world == 1 else (f"{world} independent stacks, one per GPU; RCCL gather of node graphs" if a.mode == "stacks"
                                        else f"seeds of one stack round-robin over {world} GPUs; RCCL gather of trace records"))},
-            "roofline": {"kernel": "smc_trace", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "smc_trace", "bound": "hbm", "bytes_per_launch": bytes_launch, "avg_launch_ms": smc_ms / max(smc_n, 1), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "note": "algorithmic gather bytes 8*sum(M_sigma)=%d B per particle evaluation; served from L1/L2, see DESIGN.md" % (8 * Mtot)},
             "roofline_frangi": {"kernels": "gauss_x_u8+gauss_axis(y,z)+hessian_eigen+j8", "bound": "hbm", "achieved": (len(sigs) + 12) * nvox / (fr_ms * 1e-3) / 1e9,
@@ -196,7 +203,8 @@ def main():
             "stages_ms": {k: v for k, v in st.items() if k.endswith("_ms")},
             "kernel_ms_per_step": {g: km[g][0] / a.steps for g in km},
             "counts": {k: v for k, v in st.items() if not k.endswith("_ms")},
-            "Mevals_per_s_smc": evals / (smc_ms / max(smc_n, 1)) / 1e3 if smc_ms > 0 else None,
+            "Mevals_per_s_smc": evals * a.steps / smc_ms / 1e3 if smc_ms > 0 else None,
+            "smc_launches_per_step": smc_n / a.steps,
             "Mvox_per_s_frangi": nvox / (fr_ms * 1e-3) / 1e6,
         }
         if not a.no_cpu_baseline and world == 1:

@@ -142,6 +142,16 @@ int pnr_replay_traces(const pnr_params *p, int64_t w, int64_t h, int64_t l, cons
                       int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links,
                       int64_t *n_links, int64_t *n_traces_used);
 
+/* Production form of the trace loop: trace + replay in seed-rank batches (first_batch seeds, doubling up to
+ * 1024; <= 0: default 128).  Before each batch the node-density map produced by the replay of the earlier
+ * batches is pushed to the GPU, which ends a trace at the first iteration whose centroid voxel is already
+ * saturated there (what the reference's DENSITY stop, tracker.cpp:855, would do at the latest), and seeds on
+ * saturated voxels are not launched (Advantra_plugin.cpp:2669-2670).  A stale map only under-counts, so the
+ * node graph is identical to pnr_trace_batch + pnr_replay_traces.  *n_iterations = SMC iterations run. */
+int pnr_trace_replay(pnr_ctx *ctx, const pnr_seed *seeds, int64_t n, int64_t first_batch, pnr_node *nodes,
+                     int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links,
+                     int64_t *n_traces_used, int64_t *n_iterations);
+
 /* Tracker tables for parity tests: name in {"p","u","w0","w0_cws","v","w","w_cws","rng",
  * "model_vuw<s>","model_wgt<s>","model_avg","gauss_xy<s>","gauss_z<s>"}.  Copies up to cap
  * 4-byte words into out; *n receives the element count. */

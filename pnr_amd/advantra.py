@@ -196,7 +196,7 @@ def advantra_func(infiles, paras, device=0, rng_seed=42, image=None, verbose=Tru
     return True
 
 
-def run_pipeline(ctx, img, verbose=False, max_seeds=None):
+def run_pipeline(ctx, img, verbose=False, max_seeds=None, one_shot=False):
     """reconstruction_func's hot path (Advantra_plugin.cpp:2488-2710): Frangi -> J8 -> seeds ->
     score/filter/sort -> trace all seeds on the GPU -> host replay."""
     import time
@@ -207,12 +207,17 @@ def run_pipeline(ctx, img, verbose=False, max_seeds=None):
     seeds = ctx.score_filter_sort(seeds_init); t.append(time.time())
     if max_seeds is not None:
         seeds = seeds[:max_seeds]
-    T, stop, xc, _ = ctx.trace_batch(seeds); t.append(time.time())
-    nodes, links, ntr = ctx.replay(seeds, T, xc); t.append(time.time())
+    if one_shot:  # every seed traced to its map-free end, then one replay (keeps T / xc for inspection)
+        T, stop, xc, _ = ctx.trace_batch(seeds); t.append(time.time())
+        nodes, links, ntr = ctx.replay(seeds, T, xc); t.append(time.time())
+        iters = int((T + (T < ctx.p.ni)).sum())
+    else:         # production form: seed-rank batches with early DENSITY stops (same node graph)
+        T = stop = xc = None
+        nodes, links, ntr, iters = ctx.trace_replay(seeds); t.append(time.time()); t.append(time.time())
     if verbose:
         names = ["frangi", "seed extraction", "seed selection & sorting", "tracing", "replay"]
         for nm, a, b in zip(names, t[:-1], t[1:]):
             print(f"{nm}... {b - a:.3f} sec.")
         print(f"{len(seeds_init) / 1000.0}k seeds -> {len(seeds) / 1000.0}k seeds, {ntr} traces, {len(nodes) - 1} nodes")
     return dict(Jmin=jmin, Jmax=jmax, seeds_init=seeds_init, seeds=seeds, T=T, stop=stop, xc=xc, nodes=nodes, links=links,
-                ntraces=ntr, times=np.diff(t))
+                ntraces=ntr, iters=iters, times=np.diff(t))

@@ -3,9 +3,11 @@
 // seed filter/sort (:2561-2586) and the host replay of the trace bookkeeping
 // (tracker.cpp:825-933 + Advantra_plugin.cpp:2602-2710).
 #include "ctx.h"
+#include "replay.h"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <unordered_map>
@@ -150,7 +152,8 @@ void pnr_destroy(pnr_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    hipFree(c->d_img_owned); hipFree(c->d_stash); hipFree(c->d_slot_busy);
+    for (int k = 0; k < 3; k++) pnr_job_destroy(c->jobs[k]);
+    hipFree(c->d_img_owned); hipFree(c->d_stash); hipFree(c->d_slot_busy); hipFree(c->d_den);
     hipFree(c->d_tmpA); hipFree(c->d_tmpB); hipFree(c->d_J);
     hipFree(c->d_Vx); hipFree(c->d_Vy); hipFree(c->d_Vz); hipFree(c->d_J8); hipFree(c->d_minmax);
     hipFree(c->d_p); hipFree(c->d_u); hipFree(c->d_w0); hipFree(c->d_w0cws); hipFree(c->d_v); hipFree(c->d_w);
@@ -347,113 +350,108 @@ int pnr_trace_batch(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T, in
     PNR_REQUIRE(c && (n == 0 || (seeds && T && stop && xc)), PNR_E_ARG, "null argument");
     PNR_REQUIRE(n >= 0, PNR_E_ARG, "negative count");
     PNR_HIP(hipSetDevice(c->device));
-    return pnr_trace_run(c, seeds, n, T, stop, xc, dbg_iters, xfilt, idxres, neff);
+    return pnr_trace_run(c, seeds, n, T, stop, xc, dbg_iters, xfilt, idxres, neff, /*use_density*/ 0);
 }
 
 // ---- host replay ------------------------------------------------------------------------
-static inline int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
-
-// neighbour voxels of the density pattern `vol` (Advantra_plugin.cpp:2609-2648), computed on the
-// fly instead of the reference's 8 B/voxel pointer table.  The reference clamps y+-1 with N-1
-// (the x extent) in the vol>=19 rows (:2632-2637); reproduced literally.
-static int density_neighbours(int64_t i, int N, int M, int P, int vol, int64_t *out)
-{
-    if (vol == 1) return 0;
-    const int64_t NM = (int64_t)N * M;
-    const int x = (int)(i % N), z = (int)(i / NM), y = (int)(i / N - (int64_t)z * M);
-    auto at = [&](int zz, int yy, int xx) { return (int64_t)zz * NM + (int64_t)yy * N + xx; };
-    const int xm = clampi(x - 1, 0, N - 1), xp = clampi(x + 1, 0, N - 1);
-    const int ym = clampi(y - 1, 0, M - 1), yp = clampi(y + 1, 0, M - 1);
-    const int zm = clampi(z - 1, 0, P - 1), zp = clampi(z + 1, 0, P - 1);
-    const int ymN = clampi(y - 1, 0, N - 1), ypN = clampi(y + 1, 0, N - 1);
-    int n = 0;
-    out[n++] = at(z, y, xm); out[n++] = at(z, y, xp); out[n++] = at(z, ym, x); out[n++] = at(z, yp, x);
-    if (vol >= 9) { out[n++] = at(z, ym, xm); out[n++] = at(z, ym, xp); out[n++] = at(z, yp, xm); out[n++] = at(z, yp, xp); }
-    if (vol >= 11) { out[n++] = at(zm, y, x); out[n++] = at(zp, y, x); }
-    if (vol >= 19) {
-        out[n++] = at(zm, y, xm); out[n++] = at(zm, y, xp); out[n++] = at(zm, ymN, x); out[n++] = at(zm, ypN, x);
-        out[n++] = at(zp, y, xm); out[n++] = at(zp, y, xp); out[n++] = at(zp, ymN, x); out[n++] = at(zp, ypN, x);
-    }
-    if (vol >= 27) {
-        out[n++] = at(zm, ym, xm); out[n++] = at(zm, ym, xp); out[n++] = at(zm, yp, xm); out[n++] = at(zm, yp, xp);
-        out[n++] = at(zp, ym, xm); out[n++] = at(zp, ym, xp); out[n++] = at(zp, yp, xm); out[n++] = at(zp, yp, xp);
-    }
-    return n;
-}
-
 int pnr_replay_traces(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n,
                       const int32_t *T, const pnr_xest *xc, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes,
                       int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used)
 {
     PNR_REQUIRE(p && n_nodes && n_links && (n == 0 || (seeds && T && xc)), PNR_E_ARG, "null argument");
     PNR_REQUIRE(w > 0 && h > 0 && l > 0, PNR_E_ARG, "bad dimensions");
-    const int64_t size = w * h * l;
-    const int ni = p->ni, W = (int)w, H = (int)h;
-    // npervol_map / nidx_map of the reference are dense N-voxel arrays (5 B/voxel, 5 GiB at 1024^3);
-    // only voxels that received a node are ever non-zero, so a hash map holds the same state
-    (void)size;
-    struct Cell { uint8_t den = 0; int32_t nidx = 0; };
-    std::unordered_map<int64_t, Cell> cells;
-    cells.reserve(1 << 16);
-    auto den_at = [&](int64_t v) -> int { auto it = cells.find(v); return it == cells.end() ? 0 : (int)it->second.den; };
-    int64_t nn = 0, nl = 0;
-    auto voxel = [&](float x, float y, float z) {
-        return (int64_t)(int)std::round(z) * W * H + (int64_t)(int)std::round(y) * W + (int)std::round(x);
-    };
-    auto link = [&](int64_t a, int64_t b) {
-        if (links && nl < cap_links) { links[2 * nl] = (int32_t)a; links[2 * nl + 1] = (int32_t)b; }
-        nl++;
-    };
-    if (nodes && cap_nodes > 0) { // n0[0]: dummy Node() (node.cpp:43-54)
-        std::memset(&nodes[0], 0, sizeof(pnr_node));
-        nodes[0].corr = -FLT_MAX;
-        nodes[0].type = 7;
-    }
-    nn = 1;
-    int trace_count = 0;
-    const int maxtr = p->max_trace_count > 0 ? p->max_trace_count : 5000;
-    for (int64_t s = 0; s < n; s++) {
-        if (!(den_at(voxel(seeds[s].x, seeds[s].y, seeds[s].z)) < p->nodepervol)) continue; // :2669-2670
-        trace_count++;
-        for (int dir = 0; dir < 2; dir++) {
-            const int64_t j = 2 * s + dir;
-            const pnr_xest *X = xc + j * ni;
-            int ti_limit = ni;
-            for (int i = 0; i < ni; i++) {
-                if (i >= T[j]) { ti_limit = i; break; } // iter*New returned false
-                const pnr_xest &e = X[i];
-                const int64_t crd = voxel(e.x, e.y, e.z);
-                if (den_at(crd) >= p->nodepervol) { // density limit: link to the node that owns the voxel
-                    if (i > 0) link(cells[crd].nidx, nn - 1);
-                    ti_limit = i;
-                    break;
-                }
-                if (nodes && nn < cap_nodes)
-                    nodes[nn] = pnr_node{e.x, e.y, e.z, e.vx, e.vy, e.vz, e.corr, e.sig, (i == 0) ? 7 : 2};
-                nn++;
-                {
-                    Cell &cc = cells[crd];
-                    cc.den = (uint8_t)((int)cc.den + 1);
-                    cc.nidx = (int32_t)(nn - 1);
-                }
-                if (p->vol > 1) {
-                    int64_t nb[26];
-                    const int cnt = density_neighbours(crd, (int)w, (int)h, (int)l, p->vol, nb);
-                    for (int q = 0; q < cnt; q++) {
-                        Cell &cn = cells[nb[q]];
-                        cn.den = (uint8_t)((int)cn.den + 1);
-                        cn.nidx = (int32_t)(nn - 1);
-                    }
-                }
-                if (i > 0) link(nn - 1, nn - 2);
-            }
-            if (ti_limit > 1 && nodes && nn - 1 < cap_nodes) nodes[nn - 1].type = 6; // END (tracker.cpp:930-931)
+    pnr::Replayer r(*p, w, h, l);
+    r.add(seeds, n, T, xc);
+    *n_nodes = (int64_t)r.nodes.size();
+    *n_links = (int64_t)r.links.size() / 2;
+    if (nodes) std::memcpy(nodes, r.nodes.data(), sizeof(pnr_node) * (size_t)std::min<int64_t>(cap_nodes, *n_nodes));
+    if (links) std::memcpy(links, r.links.data(), 8 * (size_t)std::min<int64_t>(cap_links, *n_links));
+    if (n_traces_used) *n_traces_used = r.trace_count;
+    return PNR_OK;
+}
+
+// Trace + replay in seed-rank batches (the production form of the trace loop, Advantra_plugin.cpp:2658-2710).
+// Tracing every seed to its map-free end wastes most GPU iterations: in the reference a trace stops as
+// soon as it runs into voxels that earlier traces already filled (DENSITY stop, tracker.cpp:855,870-882),
+// and a seed on a filled voxel is never traced (:2669-2670).  Here the density map produced by the
+// replay of batches 0..b-1 is uploaded before batch b; the kernel ends a trace at the first iteration
+// whose centroid voxel is already saturated in that (stale) map.  A stale map only under-counts, so a
+// trace is never cut earlier than the sequential reference would cut it, and the replay -- which applies
+// the true map -- produces exactly the same nodes and links as the one-shot form.
+int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first_batch, pnr_node *nodes, int64_t cap_nodes,
+                     int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used,
+                     int64_t *n_iterations)
+{
+    PNR_REQUIRE(c && n_nodes && n_links && (n == 0 || seeds), PNR_E_ARG, "null argument");
+    PNR_REQUIRE(c->d_img, PNR_E_STATE, "no volume set");
+    PNR_HIP(hipSetDevice(c->device));
+    const int ni = c->prm.ni;
+    pnr::Replayer r(c->prm, c->w, c->h, c->l);
+    int rc = pnr_density_reset(c);
+    if (rc) return rc;
+    int64_t iters = 0;
+    int64_t batch = first_batch > 0 ? first_batch : 128;
+    // Two batches in flight on two streams: while batch b runs, batch b+1 (launched against the map of
+    // batches < b) already occupies the CUs that b leaves idle in its tail; each batch is replayed in rank
+    // order as soon as it completes and its voxels are pushed to the map that later launches read.
+    for (int k = 0; k < 2; k++)
+        if (!c->jobs[k]) {
+            c->jobs[k] = pnr_job_create(c, true);
+            PNR_REQUIRE(c->jobs[k], PNR_E_HIP, "could not create a trace stream");
         }
-        if (trace_count > maxtr) break; // :2702
+    struct Slot {
+        std::vector<pnr_seed> bs;
+        std::vector<int32_t> T, stop;
+        std::vector<pnr_xest> xc;
+        bool live = false;
+    } slots[2];
+    int64_t next = 0; // first seed not yet assigned to a batch
+    auto launch = [&](int k) -> int {
+        Slot &sl = slots[k];
+        sl.live = false;
+        if (next >= n || r.stopped) return PNR_OK;
+        const int64_t i1 = std::min(n, next + batch);
+        sl.bs.clear();
+        // seeds already on a saturated voxel are skipped by the replay whatever their traces are: not launched
+        for (int64_t i = next; i < i1; i++)
+            if (!r.seed_saturated(seeds[i])) sl.bs.push_back(seeds[i]);
+        next = i1;
+        if (batch < 1024) batch *= 2;
+        const int64_t m = (int64_t)sl.bs.size();
+        sl.T.assign((size_t)(2 * m), 0);
+        sl.stop.assign((size_t)(2 * m), 0);
+        sl.xc.resize((size_t)(2 * m) * ni);
+        sl.live = true;
+        return pnr_job_launch(c, c->jobs[k], sl.bs.data(), m, 0, false, false, false, /*use_density*/ 1);
+    };
+    // depth 1 (default): strictly sequential batches -- fewest wasted iterations; depth 2 (PNR_TRACE_DEPTH=2)
+    // overlaps a batch with the tail of its predecessor at the price of a map that is one batch staler
+    const char *dep = getenv("PNR_TRACE_DEPTH");
+    const int depth = (dep && dep[0] == '2') ? 2 : 1;
+    rc = launch(0);
+    if (!rc && depth == 2) rc = launch(1);
+    if (rc) return rc;
+    for (int k = 0; slots[k].live; k = (depth == 2) ? (k ^ 1) : 0) {
+        Slot &sl = slots[k];
+        const int64_t m = (int64_t)sl.bs.size();
+        rc = pnr_job_finish(c, c->jobs[k], sl.T.data(), sl.stop.data(), sl.xc.data(), nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        for (int64_t j = 0; j < 2 * m; j++) iters += std::min<int64_t>(sl.T[(size_t)j] + 1, ni);
+        r.touched.clear();
+        r.add(sl.bs.data(), m, sl.T.data(), sl.xc.data()); // rank order: slot k always holds the older batch
+        rc = pnr_density_update(c, r);
+        if (rc) return rc;
+        rc = launch(k);
+        if (rc) return rc;
     }
-    *n_nodes = nn;
-    *n_links = nl;
-    if (n_traces_used) *n_traces_used = trace_count;
+    for (int k = 0; k < 2; k++) // a batch may still be running when MAX_TRACE_COUNT ended the loop
+        if (slots[k].live) (void)pnr_job_finish(c, c->jobs[k], slots[k].T.data(), slots[k].stop.data(), slots[k].xc.data(), nullptr, nullptr, nullptr);
+    *n_nodes = (int64_t)r.nodes.size();
+    *n_links = (int64_t)r.links.size() / 2;
+    if (nodes) std::memcpy(nodes, r.nodes.data(), sizeof(pnr_node) * (size_t)std::min<int64_t>(cap_nodes, *n_nodes));
+    if (links) std::memcpy(links, r.links.data(), 8 * (size_t)std::min<int64_t>(cap_links, *n_links));
+    if (n_traces_used) *n_traces_used = r.trace_count;
+    if (n_iterations) *n_iterations = iters;
     return PNR_OK;
 }
 

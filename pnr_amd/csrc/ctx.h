@@ -90,6 +90,13 @@ struct pnr_ctx {
     size_t stash_bytes = 0;
     int stash_slots = 0;
 
+    // node-density map of earlier trace batches (u8 per voxel), read by smc_trace for early DENSITY stops
+    uint8_t *d_den = nullptr;
+    int64_t den_cap = 0;
+
+    // trace jobs: [0],[1] own streams (pipelined batches of pnr_trace_replay), [2] on the ctx stream
+    struct pnr_trace_job *jobs[3] = {nullptr, nullptr, nullptr};
+
     // seeds
     std::vector<pnr_seed> seeds;
 
@@ -118,17 +125,17 @@ struct pnr_ctx {
         (void)hipEventCreate(&e);
         return e;
     }
-    void tic()
+    void tic(hipStream_t on = nullptr)
     {
         if (!profiling) return;
         cur_a = get_event();
-        (void)hipEventRecord(cur_a, stream);
+        (void)hipEventRecord(cur_a, on ? on : stream);
     }
-    void toc(const char *group, int launches = 1)
+    void toc(const char *group, int launches = 1, hipStream_t on = nullptr)
     {
         if (!profiling || !cur_a) return;
         hipEvent_t b = get_event();
-        (void)hipEventRecord(b, stream);
+        (void)hipEventRecord(b, on ? on : stream);
         pending.push_back(Pending{group, cur_a, b, launches});
         cur_a = nullptr;
     }
@@ -155,6 +162,15 @@ int pnr_hessian_run(pnr_ctx *c, float sig, float *const d_out[6]);
 int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1);
 int pnr_zncc_run(pnr_ctx *c, const float *h_pos_dir, int64_t n, float *h_corr, float *h_sig);
 int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T, int32_t *stop, pnr_xest *xc,
-                  int dbg_iters, float *xfilt, int32_t *idxres, float *neff);
+                  int dbg_iters, float *xfilt, int32_t *idxres, float *neff, int use_density);
+namespace pnr { struct Replayer; }
+struct pnr_trace_job;
+pnr_trace_job *pnr_job_create(pnr_ctx *c, bool own_stream);
+void pnr_job_destroy(pnr_trace_job *j);
+int pnr_job_launch(pnr_ctx *c, pnr_trace_job *j, const pnr_seed *seeds, int64_t n, int dbg_iters, bool want_xfilt, bool want_idxres,
+                   bool want_neff, int use_density);
+int pnr_job_finish(pnr_ctx *c, pnr_trace_job *j, int32_t *T, int32_t *stop, pnr_xest *xc, float *xfilt, int32_t *idxres, float *neff);
+int pnr_density_reset(pnr_ctx *c);                       // zero the device density map (allocating it on first use)
+int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r); // push the voxels touched by the last replay batch
 int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y);
 int pnr_ensure_frangi_buffers(pnr_ctx *c);

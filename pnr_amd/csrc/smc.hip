@@ -21,6 +21,7 @@
 //     CDF walk.  The centroid's own ZNCC is sampled by the whole group into LDS and summed in
 //     order by one lane per sigma.
 #include "ctx.h"
+#include "replay.h"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -579,7 +580,8 @@ struct TabX { // extra template tables for the box kernel
 
 template <int CS>
 __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const float *__restrict__ seeds6, int np, int np_pad,
-                                                  int ni, float Kc, float znccth, float neff_ratio, TraceOut O)
+                                                  int ni, float Kc, float znccth, float neff_ratio, const unsigned char *__restrict__ den, int nodepervol,
+                                                  TraceOut O)
 {
     extern __shared__ float lds[];
     const int tr = blockIdx.x, tid = threadIdx.x, B = blockDim.x, S = T.nsig;
@@ -807,7 +809,7 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
                 float *xo = O.xc + ((i64)tr * ni + pending) * 8;
                 xo[0] = xc_pen[0]; xo[1] = xc_pen[1]; xo[2] = xc_pen[2]; xo[3] = xc_pen[3]; xo[4] = xc_pen[4]; xo[5] = xc_pen[5];
                 xo[6] = bs; xo[7] = best;
-                if (sflag[1] == 0 && best < znccth) { sflag[1] = 2; sflag[2] = pending; }
+                if ((sflag[1] == 0 || sflag[1] == 3) && best < znccth) { sflag[1] = 2; sflag[2] = pending; }
             }
             __syncthreads();
         }
@@ -888,6 +890,12 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
             if (x1 < 0 || x1 >= V.w || y1 < 0 || y1 >= V.h || z1 < 0 || z1 >= V.l) {
                 sflag[1] = 1; // left the volume: the centroid's corr is still evaluated (tail pass) for the record
                 sflag[2] = it;
+            } else if (den && (int)den[(i64)z1 * V.wh + (i64)y1 * V.w + x1] >= nodepervol) {
+                // the centroid sits on a voxel that EARLIER batches already saturated: the replay will end this
+                // trace here (DENSITY stop, tracker.cpp:855) at the latest.  The iteration itself still has to
+                // pass its corr test for the link to be made, so its centroid ZNCC is evaluated (tail pass).
+                sflag[1] = 3;
+                sflag[2] = it + 1;
             } else if (neff / np < neff_ratio) {
                 res = 1; // resampling does not depend on the centroid's corr; if that later fails znccth the
                          // trace ends at this iteration and these indices are never used
@@ -993,10 +1001,53 @@ int pnr_zncc_run(pnr_ctx *c, const float *h_pos_dir, int64_t n, float *h_corr, f
     return PNR_OK;
 }
 
-int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, int32_t *stop_out, pnr_xest *xc, int dbg_iters,
-                  float *xfilt, int32_t *idxres, float *neff)
+// ---- asynchronous trace jobs: launch on the job's stream, collect later -------------------------------
+struct pnr_trace_job {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0;      // seeds of the launch in flight (0: idle)
+    int dbg_iters = 0;
+    float *d_s6 = nullptr;
+    TraceOut O{};
+    size_t cap_tr = 0, cap_dbg = 0; // capacities (traces; traces*dbg_iters) the device buffers were sized for
+    std::vector<float> s6;
+};
+
+pnr_trace_job *pnr_job_create(pnr_ctx *c, bool own_stream)
 {
+    pnr_trace_job *j = new pnr_trace_job();
+    if (own_stream) {
+        if (hipStreamCreateWithFlags(&j->stream, hipStreamNonBlocking) != hipSuccess) { delete j; return nullptr; }
+        j->own_stream = true;
+    } else {
+        j->stream = c->stream;
+    }
+    return j;
+}
+
+static void job_free_buffers(pnr_trace_job *j)
+{
+    hipFree(j->d_s6); hipFree(j->O.T); hipFree(j->O.stop); hipFree(j->O.xc); hipFree(j->O.xfilt); hipFree(j->O.idxres); hipFree(j->O.neff);
+    j->d_s6 = nullptr;
+    j->O = TraceOut{};
+    j->cap_tr = j->cap_dbg = 0;
+}
+
+void pnr_job_destroy(pnr_trace_job *j)
+{
+    if (!j) return;
+    if (j->stream) (void)hipStreamSynchronize(j->stream);
+    job_free_buffers(j);
+    if (j->own_stream) (void)hipStreamDestroy(j->stream);
+    delete j;
+}
+
+int pnr_job_launch(pnr_ctx *c, pnr_trace_job *j, const pnr_seed *seeds, int64_t n, int dbg_iters, bool want_xfilt,
+                   bool want_idxres, bool want_neff, int use_density)
+{
+    j->n = 0;
     if (n == 0) return PNR_OK;
+    if (!j->own_stream) j->stream = c->stream;
     Vol V;
     int rc = make_vol(c, V);
     if (rc) return rc;
@@ -1016,10 +1067,9 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
     for (int cs : cube_sides)
         if (fixed + (size_t)cs * cs * cs + 64 <= lds_total) { CS = cs; break; }
     PNR_REQUIRE(CS > 0, PNR_E_ARG, "np=%d needs %zu B of LDS state: no room for the image cube", np, fixed);
-    PNR_REQUIRE(CS <= 64, PNR_E_ARG, "cube side must fit a wavefront");
     const size_t lds = fixed + (size_t)CS * CS * CS;
     int block = S * np_pad;
-    if (block > 768) block = 768; // 12 waves = 3 per SIMD: up to 168 VGPRs for the 8-sample groups
+    if (block > 768) block = 768; // 12 waves = 3 per SIMD: up to 168 VGPRs for the sample groups
     for (int s = 0; s < S; s++)
         PNR_REQUIRE(c->tab.grid[4 * s] <= 64 && c->tab.grid[4 * s + 1] <= 64 && c->tab.grid[4 * s + 2] <= 64, PNR_E_ARG,
                     "template grid axis longer than a wavefront");
@@ -1035,49 +1085,59 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
         const long long wave_floats = (long long)Mmax * 64, slot_floats = wave_floats * S * (np_pad / 64);
         const size_t need = (size_t)nslots * slot_floats * 4;
         if (c->stash_bytes < need || c->stash_slots != nslots) {
+            PNR_HIP(hipDeviceSynchronize()); // no trace kernel may still hold a slot
             hipFree(c->d_stash); hipFree(c->d_slot_busy);
             c->d_stash = nullptr; c->d_slot_busy = nullptr; c->stash_bytes = 0;
             if (!getenv("PNR_NO_STASH") && hipMalloc(&c->d_stash, need) == hipSuccess && hipMalloc(&c->d_slot_busy, nslots * 4) == hipSuccess) {
                 c->stash_bytes = need;
                 c->stash_slots = nslots;
+                // flags are cleared once: every work-group releases its slot, also with several launches in flight
+                PNR_HIP(hipMemset(c->d_slot_busy, 0, nslots * 4));
             } else {
                 (void)hipGetLastError(); // not enough HBM for the stash: the kernel re-samples in pass 2
                 hipFree(c->d_stash); c->d_stash = nullptr;
             }
         }
-        if (c->d_stash) PNR_HIP(hipMemsetAsync(c->d_slot_busy, 0, nslots * 4, c->stream));
         X.stash = c->d_stash; X.slot_busy = c->d_slot_busy; X.nslots = nslots;
         X.slot_floats = slot_floats; X.wave_floats = wave_floats;
     }
 
-    std::vector<float> s6((size_t)ntr * 6);
+    j->s6.resize((size_t)ntr * 6);
     for (i64 i = 0; i < n; i++) {
-        float *a = &s6[(size_t)(2 * i) * 6], *b = a + 6;
+        float *a = &j->s6[(size_t)(2 * i) * 6], *b = a + 6;
         a[0] = b[0] = seeds[i].x; a[1] = b[1] = seeds[i].y; a[2] = b[2] = seeds[i].z;
         a[3] = seeds[i].vx; a[4] = seeds[i].vy; a[5] = seeds[i].vz;
         b[3] = -seeds[i].vx; b[4] = -seeds[i].vy; b[5] = -seeds[i].vz; // trackNeg (tracker.cpp:819-823)
     }
-    float *d_s6 = nullptr;
-    TraceOut O{};
-    PNR_HIP(hipMalloc(&d_s6, s6.size() * 4));
-    PNR_HIP(hipMalloc(&O.T, (size_t)ntr * 4));
-    PNR_HIP(hipMalloc(&O.stop, (size_t)ntr * 4));
-    PNR_HIP(hipMalloc(&O.xc, (size_t)ntr * ni * 32));
-    PNR_HIP(hipMemsetAsync(O.xc, 0, (size_t)ntr * ni * 32, c->stream));
-    O.dbg_iters = dbg_iters;
-    if (dbg_iters > 0 && xfilt) PNR_HIP(hipMalloc(&O.xfilt, (size_t)ntr * dbg_iters * np * PSTRIDE * 4));
-    if (dbg_iters > 0 && idxres) {
-        PNR_HIP(hipMalloc(&O.idxres, (size_t)ntr * dbg_iters * np * 4));
-        PNR_HIP(hipMemsetAsync(O.idxres, 0xff, (size_t)ntr * dbg_iters * np * 4, c->stream));
+    const size_t need_dbg = (size_t)ntr * dbg_iters;
+    if (j->cap_tr < (size_t)ntr || j->cap_dbg < need_dbg || (want_xfilt && !j->O.xfilt && dbg_iters) ||
+        (want_idxres && !j->O.idxres && dbg_iters) || (want_neff && !j->O.neff && dbg_iters)) {
+        PNR_HIP(hipStreamSynchronize(j->stream));
+        job_free_buffers(j);
+        PNR_HIP(hipMalloc(&j->d_s6, (size_t)ntr * 24));
+        PNR_HIP(hipMalloc(&j->O.T, (size_t)ntr * 4));
+        PNR_HIP(hipMalloc(&j->O.stop, (size_t)ntr * 4));
+        PNR_HIP(hipMalloc(&j->O.xc, (size_t)ntr * ni * 32));
+        if (dbg_iters > 0 && want_xfilt) PNR_HIP(hipMalloc(&j->O.xfilt, need_dbg * np * PSTRIDE * 4));
+        if (dbg_iters > 0 && want_idxres) PNR_HIP(hipMalloc(&j->O.idxres, need_dbg * np * 4));
+        if (dbg_iters > 0 && want_neff) PNR_HIP(hipMalloc(&j->O.neff, need_dbg * 4));
+        j->cap_tr = (size_t)ntr;
+        j->cap_dbg = need_dbg;
     }
-    if (dbg_iters > 0 && neff) PNR_HIP(hipMalloc(&O.neff, (size_t)ntr * dbg_iters * 4));
-    PNR_HIP(hipMemcpyAsync(d_s6, s6.data(), s6.size() * 4, hipMemcpyHostToDevice, c->stream));
-    c->tic();
-#define PNR_LAUNCH_TRACE(cs)                                                                                                  \
-    case cs:                                                                                                                  \
-        PNR_HIP(hipFuncSetAttribute((const void *)smc_trace<cs>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
-        hipLaunchKernelGGL(smc_trace<cs>, dim3((unsigned)ntr), dim3(block), lds, c->stream, V, T, X, d_s6, np, np_pad, ni,   \
-                           c->prm.Kc, c->prm.znccth, c->prm.neff_ratio, O);                                                   \
+    TraceOut O = j->O;
+    O.dbg_iters = dbg_iters;
+    if (!want_xfilt || !dbg_iters) O.xfilt = nullptr;
+    if (!want_idxres || !dbg_iters) O.idxres = nullptr;
+    if (!want_neff || !dbg_iters) O.neff = nullptr;
+    PNR_HIP(hipMemsetAsync(O.xc, 0, (size_t)ntr * ni * 32, j->stream));
+    if (O.idxres) PNR_HIP(hipMemsetAsync(O.idxres, 0xff, need_dbg * np * 4, j->stream));
+    PNR_HIP(hipMemcpyAsync(j->d_s6, j->s6.data(), j->s6.size() * 4, hipMemcpyHostToDevice, j->stream));
+    c->tic(j->stream);
+#define PNR_LAUNCH_TRACE(cs)                                                                                                   \
+    case cs:                                                                                                                   \
+        PNR_HIP(hipFuncSetAttribute((const void *)smc_trace<cs>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL(smc_trace<cs>, dim3((unsigned)ntr), dim3(block), lds, j->stream, V, T, X, j->d_s6, np, np_pad, ni, \
+                           c->prm.Kc, c->prm.znccth, c->prm.neff_ratio, use_density ? c->d_den : nullptr, c->prm.nodepervol, O); \
         break;
     switch (CS) {
         PNR_LAUNCH_TRACE(52)
@@ -1088,16 +1148,80 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
         PNR_LAUNCH_TRACE(32)
     }
 #undef PNR_LAUNCH_TRACE
-    c->toc("smc");
+    c->toc("smc", 1, j->stream);
     PNR_HIP(hipGetLastError());
-    PNR_HIP(hipMemcpyAsync(T_out, O.T, (size_t)ntr * 4, hipMemcpyDeviceToHost, c->stream));
-    PNR_HIP(hipMemcpyAsync(stop_out, O.stop, (size_t)ntr * 4, hipMemcpyDeviceToHost, c->stream));
-    PNR_HIP(hipMemcpyAsync(xc, O.xc, (size_t)ntr * ni * 32, hipMemcpyDeviceToHost, c->stream));
-    if (O.xfilt) PNR_HIP(hipMemcpyAsync(xfilt, O.xfilt, (size_t)ntr * dbg_iters * np * PSTRIDE * 4, hipMemcpyDeviceToHost, c->stream));
-    if (O.idxres) PNR_HIP(hipMemcpyAsync(idxres, O.idxres, (size_t)ntr * dbg_iters * np * 4, hipMemcpyDeviceToHost, c->stream));
-    if (O.neff) PNR_HIP(hipMemcpyAsync(neff, O.neff, (size_t)ntr * dbg_iters * 4, hipMemcpyDeviceToHost, c->stream));
+    j->n = n;
+    j->dbg_iters = dbg_iters;
+    return PNR_OK;
+}
+
+int pnr_job_finish(pnr_ctx *c, pnr_trace_job *j, int32_t *T_out, int32_t *stop_out, pnr_xest *xc, float *xfilt, int32_t *idxres,
+                   float *neff)
+{
+    if (j->n == 0) return PNR_OK;
+    const i64 ntr = 2 * j->n;
+    const int np = c->prm.np, ni = c->prm.ni, dbg = j->dbg_iters;
+    PNR_HIP(hipMemcpyAsync(T_out, j->O.T, (size_t)ntr * 4, hipMemcpyDeviceToHost, j->stream));
+    PNR_HIP(hipMemcpyAsync(stop_out, j->O.stop, (size_t)ntr * 4, hipMemcpyDeviceToHost, j->stream));
+    PNR_HIP(hipMemcpyAsync(xc, j->O.xc, (size_t)ntr * ni * 32, hipMemcpyDeviceToHost, j->stream));
+    if (dbg && xfilt && j->O.xfilt) PNR_HIP(hipMemcpyAsync(xfilt, j->O.xfilt, (size_t)ntr * dbg * np * PSTRIDE * 4, hipMemcpyDeviceToHost, j->stream));
+    if (dbg && idxres && j->O.idxres) PNR_HIP(hipMemcpyAsync(idxres, j->O.idxres, (size_t)ntr * dbg * np * 4, hipMemcpyDeviceToHost, j->stream));
+    if (dbg && neff && j->O.neff) PNR_HIP(hipMemcpyAsync(neff, j->O.neff, (size_t)ntr * dbg * 4, hipMemcpyDeviceToHost, j->stream));
+    PNR_HIP(hipStreamSynchronize(j->stream));
+    j->n = 0;
+    return PNR_OK;
+}
+
+int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, int32_t *stop_out, pnr_xest *xc, int dbg_iters,
+                  float *xfilt, int32_t *idxres, float *neff, int use_density)
+{
+    if (n == 0) return PNR_OK;
+    if (!c->jobs[2]) c->jobs[2] = pnr_job_create(c, false);
+    PNR_REQUIRE(c->jobs[2], PNR_E_HIP, "could not create a trace job");
+    int rc = pnr_job_launch(c, c->jobs[2], seeds, n, dbg_iters, xfilt != nullptr, idxres != nullptr, neff != nullptr, use_density);
+    if (rc) return rc;
+    return pnr_job_finish(c, c->jobs[2], T_out, stop_out, xc, xfilt, idxres, neff);
+}
+
+namespace {
+__global__ void den_scatter(unsigned char *den, const i64 *idx, const unsigned char *val, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) den[idx[i]] = val[i];
+}
+} // namespace
+
+int pnr_density_reset(pnr_ctx *c)
+{
+    if (c->den_cap < c->N) {
+        hipFree(c->d_den);
+        c->d_den = nullptr;
+        c->den_cap = 0;
+        PNR_HIP(hipMalloc(&c->d_den, (size_t)c->N));
+        c->den_cap = c->N;
+    }
+    PNR_HIP(hipMemsetAsync(c->d_den, 0, (size_t)c->N, c->stream));
+    PNR_HIP(hipStreamSynchronize(c->stream)); // trace jobs run on their own streams
+    return PNR_OK;
+}
+
+int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r)
+{
+    const size_t n = r.touched.size();
+    if (n == 0) return PNR_OK;
+    std::vector<unsigned char> val(n);
+    for (size_t i = 0; i < n; i++) val[i] = (unsigned char)r.den_at(r.touched[i]); // final value: duplicates agree
+    i64 *d_idx = nullptr;
+    unsigned char *d_val = nullptr;
+    PNR_HIP(hipMalloc(&d_idx, n * 8));
+    PNR_HIP(hipMalloc(&d_val, n));
+    PNR_HIP(hipMemcpyAsync(d_idx, r.touched.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+    PNR_HIP(hipMemcpyAsync(d_val, val.data(), n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(den_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_den, d_idx, d_val, (int)n);
+    PNR_HIP(hipGetLastError());
     PNR_HIP(hipStreamSynchronize(c->stream));
-    hipFree(d_s6); hipFree(O.T); hipFree(O.stop); hipFree(O.xc); hipFree(O.xfilt); hipFree(O.idxres); hipFree(O.neff);
+    hipFree(d_idx);
+    hipFree(d_val);
     return PNR_OK;
 }
 

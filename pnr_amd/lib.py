@@ -72,6 +72,7 @@ def load():
     L.pnr_trace_batch.argtypes = [vp, vp, i64, vp, vp, vp, i32, vp, vp, vp]
     L.pnr_replay_traces.argtypes = [C.POINTER(Params), i64, i64, i64, vp, i64, vp, vp, vp, i64, C.POINTER(i64), vp, i64,
                                     C.POINTER(i64), C.POINTER(i64)]
+    L.pnr_trace_replay.argtypes = [vp, vp, i64, i64, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.pnr_get_table.argtypes = [vp, C.c_char_p, vp, i64, C.POINTER(i64)]
     L.pnr_set_profiling.argtypes = [vp, i32]
     L.pnr_get_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
@@ -87,7 +88,7 @@ def load():
 EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", "pnr_set_stream", "pnr_synchronize",
            "pnr_set_volume", "pnr_set_volume_device", "pnr_frangi", "pnr_get_frangi", "pnr_gaussian", "pnr_hessian",
            "pnr_set_j8_v", "pnr_extract_seeds", "pnr_extract_seeds_range", "pnr_zncc_batch",
-           "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_get_table", "pnr_set_profiling",
+           "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_trace_replay", "pnr_get_table", "pnr_set_profiling",
            "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch"]
 
 
@@ -235,6 +236,20 @@ class Context:
 
     def replay(self, seeds, T, xc):
         return replay(self.p, self.shape, seeds, T, xc)
+
+    def trace_replay(self, seeds, first_batch=0, cap_nodes=None):
+        """batched trace + replay (pnr_trace_replay): nodes, links, traces used, SMC iterations run"""
+        s = np.ascontiguousarray(seeds, SEED_DT)
+        cap = int(cap_nodes or (2 * len(s) * self.p.ni + 2))
+        while True:
+            nodes = np.zeros(cap, NODE_DT)
+            links = np.zeros((2 * cap + 2, 2), np.int32)
+            nn, nl, nt, it = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+            check(self.L.pnr_trace_replay(self.h, s.ctypes.data, len(s), first_batch, nodes.ctypes.data, cap, C.byref(nn),
+                                          links.ctypes.data, len(links), C.byref(nl), C.byref(nt), C.byref(it)))
+            if nn.value <= cap and nl.value <= len(links):
+                return nodes[:nn.value].copy(), links[:nl.value].copy(), nt.value, it.value
+            cap = int(nn.value) + 2
 
     def table(self, name):
         n = C.c_int64()

@@ -13,7 +13,7 @@ nchain = sum(Mtot.get(float(x), 5625) for x in sigs)
 c = pnr_amd.Context(p, 0)
 c.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
 c.set_profiling(True)
-for rep in range(2):
+for rep in range(int(os.environ.get('REPS', '2'))):
     c.reset_kernel_ms()
     t = [time.time()]
     print(c.frangi()); t.append(time.time())
@@ -27,4 +27,7 @@ for rep in range(2):
         print('   ', g, c.kernel_ms(g))
     steps = int((T + (T < p.ni)).sum())  # iterations executed incl. the failing one
     ms, _ = c.kernel_ms('smc')
+    for fb in ([int(x) for x in sys.argv[4].split(',')] if len(sys.argv) > 4 else [0]):
+        t0 = time.time(); n2, l2, nt2, it2 = c.trace_replay(s[:nseed], first_batch=fb); t1 = time.time()
+        print('   batched trace_replay first_batch', fb, ': wall', round(t1 - t0, 4), 'iterations', it2, 'nodes', len(n2), 'same graph', len(n2) == len(nodes) and np.array_equal(l2, links))
     print('   trace-iterations', steps, 'evals', steps * 201, 'Mevals/s', steps * 201 / ms / 1e3, 'ms/iter/trace-avg', ms / max(steps, 1), 'Gsamples/s', steps * 201 * nchain / ms / 1e6, 'kernel ms / longest trace iters', ms / max(1, int(T.max()) + 1))

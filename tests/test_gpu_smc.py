@@ -135,7 +135,7 @@ def test_end_to_end_vs_oracle(oracle):
     sigs, np_, ni, zdist = [2.0], 50, 40, 2.0
     p = pnr_amd.make_params(sigmas=sigs, np_=np_, ni=ni, zdist=zdist, nodepervol=4, vol=5)
     c = pnr_amd.Context(p, 0)
-    res = pnr_amd.advantra.run_pipeline(c, img)
+    res = pnr_amd.advantra.run_pipeline(c, img, one_shot=True)
     # oracle pipeline
     J, jmin, jmax, Vx, Vy, Vz = orc.frangi3d(oracle, img, sigs, zdist)
     s = orc.extract_seeds(oracle, 5, orc.j8(oracle, J, jmin, jmax), Vx, Vy, Vz)
@@ -159,3 +159,26 @@ def test_end_to_end_vs_oracle(oracle):
     for k in ("x", "y", "z", "vx", "vy", "vz", "corr", "sig"):
         assert np.allclose(res["nodes"][k], nodes_o[k], rtol=F32_RTOL, atol=F32_ATOL), k
     assert len(nodes_o) > 50
+
+
+@pytest.mark.parametrize("first_batch,vol,npv", [(1, 1, 4), (3, 5, 3), (64, 1, 4), (1000, 27, 4)])
+def test_batched_trace_replay_equals_one_shot(first_batch, vol, npv):
+    """pnr_trace_replay (seed-rank batches, stale density map on the GPU, early DENSITY stops, saturated
+    seeds not launched) must give exactly the node graph of tracing everything + one replay."""
+    img = synth.synth(96, 80, 40, seed=7)
+    p = pnr_amd.make_params(sigmas=[2.0, 3.0], np_=48, ni=60, zdist=2.0, nodepervol=npv, vol=vol)
+    c = pnr_amd.Context(p, 0)
+    c.set_volume(img)
+    c.frangi()
+    seeds = c.score_filter_sort(c.extract_seeds())
+    assert len(seeds) > 40
+    T, stop, xc, _ = c.trace_batch(seeds)
+    n1, l1, nt1 = c.replay(seeds, T, xc)
+    n2, l2, nt2, iters = c.trace_replay(seeds, first_batch=first_batch)
+    assert nt1 == nt2 and len(n1) == len(n2) > 100
+    for k in n1.dtype.names:
+        assert np.array_equal(n1[k], n2[k], equal_nan=True), k
+    assert np.array_equal(l1, l2)
+    full = int((T + (T < p.ni)).sum())
+    print(f"first_batch={first_batch}: iterations {iters} vs one-shot {full}")
+    assert iters <= full
