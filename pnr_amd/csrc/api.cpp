@@ -153,6 +153,7 @@ void pnr_destroy(pnr_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int k = 0; k < 3; k++) pnr_job_destroy(c->jobs[k]);
+    if (c->h_j8) hipHostFree(c->h_j8);
     hipFree(c->d_img_owned); hipFree(c->d_stash); hipFree(c->d_slot_busy); hipFree(c->d_den);
     hipFree(c->d_tmpA); hipFree(c->d_tmpB); hipFree(c->d_J);
     hipFree(c->d_Vx); hipFree(c->d_Vy); hipFree(c->d_Vz); hipFree(c->d_J8); hipFree(c->d_minmax);

@@ -98,6 +98,8 @@ struct pnr_ctx {
     struct pnr_trace_job *jobs[3] = {nullptr, nullptr, nullptr};
 
     // seeds
+    unsigned char *h_j8 = nullptr; // pinned staging buffer for the J8 download
+    size_t h_j8_cap = 0;
     std::vector<pnr_seed> seeds;
 
     // profiling: HIP event pairs recorded on the ctx stream around each kernel group, resolved

@@ -15,6 +15,8 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <chrono>
+#include <cstdlib>
 #include <thread>
 
 namespace {
@@ -198,6 +200,9 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     PNR_REQUIRE(c->have_j8, PNR_E_STATE, "pnr_extract_seeds: run pnr_frangi (or pnr_set_j8_v) first");
     PNR_REQUIRE(z0 >= 0 && z1 <= c->l && z0 <= z1, PNR_E_ARG, "layer range [%lld,%lld) outside [0,%lld)", (long long)z0, (long long)z1, (long long)c->l);
     c->seeds.clear();
+    const bool timing = getenv("PNR_SEED_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
     const int w = (int)c->w, h = (int)c->h;
     const int nl = (int)(z1 - z0);
     if (nl == 0) return PNR_OK;
@@ -218,8 +223,14 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     std::vector<i64> off(nl + 1, 0);
 
     // start the J8 download for the host flood-fill while the kernels run
-    unsigned char *h_j8 = nullptr;
-    PNR_HIP(hipHostMalloc(&h_j8, (size_t)(wh * nl), hipHostMallocDefault));
+    if (c->h_j8_cap < (size_t)(wh * nl)) { // pinned staging buffer, kept across calls (allocating 1 GiB of pinned memory costs ~50 ms)
+        if (c->h_j8) hipHostFree(c->h_j8);
+        c->h_j8 = nullptr;
+        c->h_j8_cap = 0;
+        PNR_HIP(hipHostMalloc(&c->h_j8, (size_t)(wh * nl), hipHostMallocDefault));
+        c->h_j8_cap = (size_t)(wh * nl);
+    }
+    unsigned char *h_j8 = c->h_j8;
     PNR_HIP(hipMemcpyAsync(h_j8, c->d_J8 + z0 * wh, (size_t)(wh * nl), hipMemcpyDeviceToHost, c->stream));
 
     c->tic();
@@ -254,12 +265,13 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     PNR_HIP(hipGetLastError());
     PNR_HIP(hipStreamSynchronize(c->stream));
 
+    const double t_gpu = now();
     // host: per-layer flood-fill on a thread pool; results kept per layer to preserve z-major order
     std::vector<std::vector<int>> acc(nl);
     {
         unsigned nt = std::thread::hardware_concurrency();
         if (nt == 0) nt = 4;
-        if (nt > 32) nt = 32;
+        if (nt > 16) nt = 16; // the GPU box gives one GPU a share of 16 host threads
         if ((int)nt > nl) nt = nl;
         std::atomic<int> next(0);
         const float tol = (float)(double)c->prm.tolerance;
@@ -279,7 +291,7 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
         work();
         for (auto &t : th) t.join();
     }
-    hipHostFree(h_j8);
+    const double t_fill = now();
 
     // directions at the accepted voxels (seed.cpp:767-771)
     std::vector<i64> vox;
@@ -312,5 +324,8 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
         c->seeds[i] = pnr_seed{(float)x, (float)y, (float)z, Ux / Un, Uy / Un, Uz / Un, 0.f, 0.f};
     }
     hipFree(d_min); hipFree(d_max); hipFree(d_cnt); hipFree(d_vf); hipFree(d_off); hipFree(d_keys);
+    if (timing)
+        fprintf(stderr, "[pnr seeds] kernels+download %.1f ms, host fill %.1f ms (%u threads, %lld candidates), dirs+free %.1f ms\n",
+                1e3 * (t_gpu - t_start), 1e3 * (t_fill - t_gpu), std::thread::hardware_concurrency(), (long long)total, 1e3 * (now() - t_fill));
     return PNR_OK;
 }
