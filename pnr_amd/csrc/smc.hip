@@ -3,23 +3,17 @@
 // Replaces Tracker::znccBBB / interp (tracker.cpp:1891-1964, :2138-2215), getdirection
 // (:751-768) and iter0New / iterINew (:1001-1198).  No MFMA: there is no dense contraction.
 //
-// Work decomposition (wave64):
-//   * a "chain" = one (particle, sigma) ZNCC: two sequential passes over the M_sigma template
-//     samples.  The reference sums in sample order in f32 (with f64 adds for the squared
-//     terms), so a chain is kept sequential inside ONE lane and the parallelism comes from
-//     np x S chains per trace and thousands of traces -- this keeps every float bit-identical
-//     to the scalar loop, which the bit-exact node indexing depends on (one flipped resampling
-//     index changes the rest of a trace).
-//   * chains are laid out sigma-major and padded to 64, so a wavefront shares sigma and sample
-//     index: template offsets/weights are wave-uniform (scalar loads), only the 8 trilinear
-//     corner fetches are per-lane gathers (served by L1/L2: the footprint of one SMC step is
-//     ~10^5 bytes).
-//   * one work-group = one trace (seed x direction), iterating to its own stop; the grid is the
-//     batch of traces, so uneven trace lengths are balanced by the hardware dispatcher.
-//   * weight normalisation / N_eff / CDF / centroid are sequential f32 sums in particle order
-//     (tracker.cpp:1140-1177) done by one lane from LDS; systematic resampling is a monotone
-//     CDF walk.  The centroid's own ZNCC is sampled by the whole group into LDS and summed in
-//     order by one lane per sigma.
+// Work decomposition (wave64), details in DESIGN.md section 4:
+//   * a "chain" = one (particle, sigma) ZNCC; its sums run in sample order inside ONE lane (the
+//     reference sums sequentially in f32; any other order changes weights in the last bit and,
+//     sooner or later, a resampling index and the rest of the trace).
+//   * one work-group = one trace (seed x direction) iterating to its own stop; the image
+//     neighbourhood lives in LDS (CS^3 byte cube, ds_read_u8 gathers), particle state in LDS.
+//   * sampling is order-free: it is cut into (sigma, 64-particle group, v-slice) work items pulled
+//     by the 12 waves, values go to an HBM stash [sample][lane]; the ordered sums stream them back.
+//   * template offsets / weights are wave-uniform: one coalesced load per row + v_readlane.
+//   * the centroid's own ZNCC rides along as S extra chains of the next iteration.
+//   * early DENSITY stop against the node-density map of earlier seed batches (pnr_trace_replay).
 #include "ctx.h"
 #include "replay.h"
 #include <algorithm>
@@ -156,22 +150,6 @@ __device__ __forceinline__ float zncc_chain(const Vol &V, const Frame &f, const 
     }
     const float prod = corrb * corrc;
     return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f; // tracker.cpp:1955
-}
-
-// sequential sums over pre-sampled values (centroid ZNCC)
-__device__ __forceinline__ float zncc_from_samples(const float *__restrict__ img, const float4 *__restrict__ tm, int M, float corrc)
-{
-    float ag = 0.f;
-    for (int k = 0; k < M; ++k) ag += img[k];
-    ag /= (float)M;
-    float corra = 0.f, corrb = 0.f;
-    for (int k = 0; k < M; ++k) {
-        const float di = img[k] - ag;
-        corra += di * tm[k].w;
-        corrb = (float)((double)corrb + (double)di * (double)di);
-    }
-    const float prod = corrb * corrc;
-    return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f;
 }
 
 // ----------------------------------------------------------------------------------------

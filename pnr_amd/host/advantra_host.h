@@ -1,0 +1,42 @@
+// advantra_host.h -- C++ host side above the C ABI, mirroring the reference's plugin entry for the
+// accelerated path: Advantra::dofunc("advantra_func", ...) -> reconstruction_func
+// (/root/reference/pnr-vaa3d/Advantra_plugin.cpp:274-337, 2183-2731).  Same contract: input[0] = list of
+// file names, input[1] = the 11 positional parameters as strings; returns false on a usage error
+// (missing image / wrong parameter count, after printing the help), true otherwise (range errors print
+// the reference's v3d_msg text and stop, as `return 0` does there).
+// The Vaa3D/Qt shell itself (V3DPluginInterface2_1, QObject) cannot be built without the Vaa3D SDK;
+// this is the same logic behind a plain C++ signature, driven by advantra_cli.
+#pragma once
+#include "../../include/pnr_hip.h"
+#include <string>
+#include <vector>
+
+namespace advantra {
+
+struct Stack {
+    std::vector<unsigned char> data; // x fastest: i = z*w*h + y*w + x
+    long long w = 0, h = 0, l = 0;
+};
+
+struct Result {
+    float Jmin = 0, Jmax = 0;
+    long long n_seeds_init = 0, n_seeds = 0, n_traces = 0, n_iterations = 0;
+    std::vector<pnr_node> nodes;   // nodes[0] = dummy
+    std::vector<int32_t> links;    // pairs
+    std::string swc_path;
+    double t_frangi = 0, t_seeds = 0, t_select = 0, t_trace = 0;
+};
+
+void print_help();
+// simple_loadimage_wrapper's role (Advantra_plugin.cpp:2241): 8-bit multi-page uncompressed TIFF, or
+// ".raw" (u8, dims from `raw_dims` = "w,h,l").  Returns false with a message in `err`.
+bool load_stack(const std::string &path, const std::string &raw_dims, Stack &out, std::string &err);
+// save_nodelist (Advantra_plugin.cpp:480-523)
+bool save_nodelist(const std::vector<pnr_node> &nodes, const std::vector<int32_t> &links, const std::string &swcname,
+                   int type = -1, float sig2r = 1.f, const std::string &name = "", const std::string &comment = "");
+// 0 = ok, -1 = usage error (dofunc returns false), -2 = range error (dofunc "return 0"), -3 = runtime failure
+int parse_params(const std::vector<std::string> &paras, pnr_params &p, std::string &err);
+bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *> &paras, int device = 0,
+                   const std::string &raw_dims = "", Result *result = nullptr);
+
+} // namespace advantra
