@@ -185,6 +185,15 @@ def main():
         bytes_launch = 8.0 * Mtot * evals * a.steps / max(smc_n, 1)
         achieved = bytes_launch / (smc_ms / max(smc_n, 1) * 1e-3) / 1e9 if smc_ms > 0 else 0.0
         fr_ms = (km["gauss"][0] + km["hessian_eigen"][0] + km["j8"][0]) / a.steps
+        # HBM traffic per launch: PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, calibrated on
+        # a known byte count in the same access pattern: scripts/prof_traffic.sh), collected for THIS workload and
+        # committed under profiles/; null for any other workload
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_1024_s2000.json")
+        if S == 1024 and a.seeds == 2000 and a.np == 200 and a.ni == 200 and not a.one_shot and a.mode == "stacks" and os.path.exists(tpath):
+            tj = json.load(open(tpath)).get("smc_trace", {})
+            if "FETCH_SIZE" in tj and "WRITE_SIZE" in tj:
+                traffic = tj["FETCH_SIZE"]["bytes_per_launch"] + tj["WRITE_SIZE"]["bytes_per_launch"]
         out = {
             "metric": "Mvox/s traced (Frangi+SMC step) on 1024^3 synthetic stack; % HBM roofline" if S == 1024 else f"Mvox/s traced (Frangi+SMC step) on {S}^3 synthetic stack; % HBM roofline",
             "value": value, "unit": "Mvox/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -195,7 +204,7 @@ def main():
                        "parallelism": ("1 GPU" if world == 1 else (f"{world} independent stacks, one per GPU; RCCL gather of node graphs" if a.mode == "stacks"
                                        else f"seeds of one stack round-robin over {world} GPUs; RCCL gather of trace records"))},
             "roofline": {"kernel": "smc_trace", "bound": "hbm", "bytes_per_launch": bytes_launch, "avg_launch_ms": smc_ms / max(smc_n, 1), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "algorithmic gather bytes 8*sum(M_sigma)=%d B per particle evaluation; served from L1/L2, see DESIGN.md" % (8 * Mtot)},
             "roofline_frangi": {"kernels": "gauss_x_u8+gauss_axis(y,z)+hessian_eigen+j8", "bound": "hbm", "achieved": (len(sigs) + 12) * nvox / (fr_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (len(sigs) + 12) * nvox / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
