@@ -437,7 +437,16 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
         const int64_t m = (int64_t)sl.bs.size();
         rc = pnr_job_finish(c, c->jobs[k], sl.T.data(), sl.stop.data(), sl.xc.data(), nullptr, nullptr, nullptr);
         if (rc) return rc;
-        for (int64_t j = 0; j < 2 * m; j++) iters += std::min<int64_t>(sl.T[(size_t)j] + 1, ni);
+        int64_t bi = 0, bmax = 0;
+        for (int64_t j = 0; j < 2 * m; j++) {
+            const int64_t e = std::min<int64_t>(sl.T[(size_t)j] + 1, ni);
+            bi += e;
+            bmax = std::max(bmax, e);
+        }
+        iters += bi;
+        if (getenv("PNR_TRACE_TIMING"))
+            fprintf(stderr, "[pnr trace] batch of %lld seeds launched: %lld iterations, longest trace %lld, nodes so far %zu\n", (long long)m,
+                    (long long)bi, (long long)bmax, r.nodes.size());
         r.touched.clear();
         r.add(sl.bs.data(), m, sl.T.data(), sl.xc.data()); // rank order: slot k always holds the older batch
         rc = pnr_density_update(c, r);

@@ -48,6 +48,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PnrError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback for the PNR hot path)")
+    # A process must not end up with two HIP runtimes (torch wheels bundle their own libamdhip64): if torch is
+    # around, let it load its runtime first so that libpnr_hip.so binds to the same one.
+    if not os.environ.get("PNR_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     L.pnr_last_error.restype = C.c_char_p

@@ -182,3 +182,54 @@ def test_batched_trace_replay_equals_one_shot(first_batch, vol, npv):
     full = int((T + (T < p.ni)).sum())
     print(f"first_batch={first_batch}: iterations {iters} vs one-shot {full}")
     assert iters <= full
+
+
+def test_trace_config5_shape_vs_oracle(oracle):
+    """BASELINE configs[4] parameter shape at a size the oracle finishes in seconds: 4 scales {2,4,6,8},
+    zdist=4 (anisotropic), np=500: chains loop over the work-group twice, the LDS cube shrinks to 44^3."""
+    img = synth.synth(72, 64, 24, seed=5, zdist=4.0)
+    sigs, np_, ni, zdist = [2.0, 4.0, 6.0, 8.0], 500, 6, 4.0
+    so = _seeds_for(oracle, img, sigs, zdist, 2)
+    To = orc.Tracker(oracle, sigs, 2, np_, ni, 3.0, 0.3, zdist=zdist)
+    seeds = np.zeros(len(so), lib.SEED_DT)
+    for i, k in enumerate(lib.SEED_DT.names):
+        seeds[k] = so[:, i]
+    c = pnr_amd.Context(pnr_amd.make_params(sigmas=sigs, np_=np_, ni=ni, zdist=zdist), 0)
+    c.set_volume(img)
+    T, stop, xc, dbg = c.trace_batch(seeds, dbg_iters=ni)
+    for i, sd in enumerate(so):
+        for d, sgn in enumerate((1, -1)):
+            q = sd[:6].copy(); q[3:] *= sgn
+            Tn, st, xco, xf, idx, neff = To.trace(img, q, max_dbg=ni)
+            j = 2 * i + d
+            assert T[j] == Tn and stop[j] == st
+            rows = min(Tn + 1, ni)
+            assert np.allclose(mat(xc[j])[:rows], xco[:rows], rtol=F32_RTOL, atol=F32_ATOL)
+            assert np.allclose(dbg["xfilt"][j, :rows], xf[:rows], rtol=F32_RTOL, atol=F32_ATOL)
+
+
+def test_full_size_properties_512():
+    """BASELINE configs[1] size (512^3, scales {2,4,6}, np=200): properties that do not need the oracle --
+    batched tracing gives the one-shot node graph; links are symmetric pairs of valid nodes; every trace start is
+    UNDEFINED(7), ends are END(6); seeds come out sorted by corr; J8 spans 0..255."""
+    import torch
+    S = 512
+    img = synth.synth_torch(S, S, S, seed=2)
+    p = pnr_amd.make_params(sigmas=(2, 4, 6), np_=200, ni=200, zdist=2)
+    c = pnr_amd.Context(p, 0)
+    c.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
+    jmin, jmax = c.frangi()
+    assert jmin == 0 and 0 < jmax < 1
+    s = c.score_filter_sort(c.extract_seeds())
+    assert len(s) > 1000 and np.all(np.diff(s["corr"]) <= 0) and s["corr"].min() >= p.znccth
+    sb = s[:160]
+    T, stop, xc, _ = c.trace_batch(sb)
+    n1, l1, nt1 = c.replay(sb, T, xc)
+    n2, l2, nt2, iters = c.trace_replay(sb, first_batch=32)
+    assert nt1 == nt2 and np.array_equal(l1, l2) and all(np.array_equal(n1[k], n2[k]) for k in n1.dtype.names)
+    assert iters < int((T + (T < p.ni)).sum())
+    assert l1.min() >= 1 and l1.max() < len(n1)  # (a DENSITY stop may link a node to itself, as in the reference)
+    assert set(np.unique(n1["type"][1:])) <= {2, 6, 7} and (n1["type"][1:] == 7).sum() >= nt1
+    assert np.all((n1["x"][1:] >= -0.5) & (n1["x"][1:] < S - 0.5)) and np.all(n1["corr"][1:] >= p.znccth)
+    del img
+    torch.cuda.empty_cache()
