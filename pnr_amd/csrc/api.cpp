@@ -392,6 +392,7 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
     if (rc) return rc;
     int64_t iters = 0;
     int64_t batch = first_batch > 0 ? first_batch : 128;
+    const int64_t growth_pct = getenv("PNR_BATCH_GROWTH") ? std::max(100, atoi(getenv("PNR_BATCH_GROWTH"))) : 200;
     // Two batches in flight on two streams: while batch b runs, batch b+1 (launched against the map of
     // batches < b) already occupies the CUs that b leaves idle in its tail; each batch is replayed in rank
     // order as soon as it completes and its voxels are pushed to the map that later launches read.
@@ -417,7 +418,7 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
         for (int64_t i = next; i < i1; i++)
             if (!r.seed_saturated(seeds[i])) sl.bs.push_back(seeds[i]);
         next = i1;
-        if (batch < 1024) batch *= 2;
+        if (batch < 1024) batch = std::max<int64_t>(batch + 1, batch * growth_pct / 100);
         const int64_t m = (int64_t)sl.bs.size();
         sl.T.assign((size_t)(2 * m), 0);
         sl.stop.assign((size_t)(2 * m), 0);

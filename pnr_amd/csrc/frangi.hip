@@ -360,6 +360,16 @@ __global__ __launch_bounds__(256) void hessian_eigen(const float *__restrict__ F
     const int z = (int)(row / h), y = (int)(row - (i64)z * h);
     const i64 wh = (i64)w * h;
     unsigned int omin = 0xffffffffu, omax = 0u;
+    // Phase 1 (all lanes): Hessian of the own voxel and the decision whether the eigen-solver is needed.
+    // Phase 2: the surviving voxels of the 256-voxel block are compacted through LDS so that whole
+    // wavefronts drop out instead of idling next to a few busy lanes (the fp64 solver is the cost).
+    __shared__ float s_h[256][6];
+    __shared__ int s_x[256];
+    __shared__ int s_cnt;
+    if (!DUMP) {
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+    }
     if (x < w) {
         const i64 i = row * w + x;
         // six second derivatives, each x sigma^2 (frangi.cpp:319,339,345,368,374,380)
@@ -369,10 +379,34 @@ __global__ __launch_bounds__(256) void hessian_eigen(const float *__restrict__ F
         const float Dxx = d2(F, i, 1, x, w, 1, x, w, 1) * s2;
         const float Dxy = d2(F, i, 1, x, w, w, y, h, 0) * s2;
         const float Dxz = d2(F, i, 1, x, w, wh, z, l, 0) * s2;
+        // Scales after the first only ever write when the response beats J >= 0, i.e. when it is > 0, which
+        // needs lambda2 <= 0 and lambda3 <= 0 (the two largest-magnitude eigenvalues).  Then
+        // trace = l1+l2+l3 <= |l2| + l2 + l3 = l3 <= 0.  So a trace that is positive by a margin far above
+        // the solver's rounding error (1e-9 of the matrix 1-norm vs ~1e-15) proves the response is exactly 0
+        // and the voxel is left untouched -- without running the eigen-solver.  (NaN compares false: no skip.)
+        bool skip = false;
+        if (!DUMP && !first) {
+            const double tr = (double)Dxx + (double)Dyy + (double)Dzz;
+            const double nrm = fabs((double)Dxx) + fabs((double)Dyy) + fabs((double)Dzz) + 2.0 * (fabs((double)Dxy) + fabs((double)Dxz) + fabs((double)Dyz));
+            skip = tr > 1e-9 * nrm;
+        }
         if (DUMP) {
             dump.Dzz[i] = Dzz; dump.Dyy[i] = Dyy; dump.Dyz[i] = Dyz;
             dump.Dxx[i] = Dxx; dump.Dxy[i] = Dxy; dump.Dxz[i] = Dxz;
-        } else {
+        } else if (!skip) {
+            const int slot = atomicAdd(&s_cnt, 1); // order inside the block is irrelevant: voxels are independent
+            s_h[slot][0] = Dxx; s_h[slot][1] = Dxy; s_h[slot][2] = Dxz;
+            s_h[slot][3] = Dyy; s_h[slot][4] = Dyz; s_h[slot][5] = Dzz;
+            s_x[slot] = x;
+        }
+    }
+    if (DUMP) return;
+    __syncthreads();
+    if ((int)threadIdx.x < s_cnt) {
+        const float Dxx = s_h[threadIdx.x][0], Dxy = s_h[threadIdx.x][1], Dxz = s_h[threadIdx.x][2];
+        const float Dyy = s_h[threadIdx.x][3], Dyz = s_h[threadIdx.x][4], Dzz = s_h[threadIdx.x][5];
+        const i64 i = row * w + s_x[threadIdx.x];
+        {
             double V[3][3], d[3];
             V[0][0] = Dxx; V[0][1] = Dxy; V[0][2] = Dxz;
             V[1][0] = Dxy; V[1][1] = Dyy; V[1][2] = Dyz;
@@ -402,23 +436,24 @@ __global__ __launch_bounds__(256) void hessian_eigen(const float *__restrict__ F
             }
         }
     }
-    if (DUMP) return;
-    // Jmin/Jmax are updated only on writes (frangi.cpp:237-238,257-258)
+    // Jmin/Jmax are updated only on writes (frangi.cpp:237-238,257-258).  Reduced per wavefront (two atomics
+    // per solving wave, no block barrier): waves with nothing to solve retire immediately and free their
+    // slots -- the fp64 solver is latency-bound, so resident idle waves would cost as much as busy ones.
+    if ((int)(threadIdx.x & ~63u) >= s_cnt) return; // wave-uniform
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned int m1 = __shfl_xor(omin, o), m2 = __shfl_xor(omax, o);
         omin = m1 < omin ? m1 : omin;
         omax = m2 > omax ? m2 : omax;
     }
-    __shared__ unsigned int s_min[4], s_max[4];
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_min[wv] = omin; s_max[wv] = omax; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int a = s_min[0], c = s_max[0];
-        for (int k = 1; k < 4; k++) { a = s_min[k] < a ? s_min[k] : a; c = s_max[k] > c ? s_max[k] : c; }
-        if (a != 0xffffffffu) atomicMin(&minmax[0], a);
-        if (c != 0u) atomicMax(&minmax[1], c);
+    if ((threadIdx.x & 63) == 0) {
+        // millions of same-address atomics serialise (~30 ns each): first look at the current extremes (a
+        // relaxed device-scope load; a stale value can only cause a redundant atomic, never a missed one --
+        // min only falls, max only rises) and touch them only when this wave improves on them
+        const unsigned int cur_min = __hip_atomic_load(&minmax[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int cur_max = __hip_atomic_load(&minmax[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (omin < cur_min) atomicMin(&minmax[0], omin);
+        if (omax > cur_max) atomicMax(&minmax[1], omax);
     }
 }
 
