@@ -347,8 +347,10 @@ struct HessOut {
     float *Dzz, *Dyy, *Dyz, *Dxx, *Dxy, *Dxz;
 };
 
+constexpr int HE_BLOCK = 256;  // voxels per block along x: the larger the block, the tighter the survivors pack into waves
+
 template <bool DUMP>
-__global__ __launch_bounds__(256) void hessian_eigen(const float *__restrict__ F, float *__restrict__ J,
+__global__ __launch_bounds__(HE_BLOCK) void hessian_eigen(const float *__restrict__ F, float *__restrict__ J,
                                                       unsigned char *__restrict__ Vx, unsigned char *__restrict__ Vy,
                                                       unsigned char *__restrict__ Vz, int w, int h, int l, int tiles_x,
                                                       float s2, float two_a2, float two_b2, float two_c2, int first,
@@ -356,15 +358,15 @@ __global__ __launch_bounds__(256) void hessian_eigen(const float *__restrict__ F
 {
     const i64 b = blockIdx.x;
     const i64 row = b / tiles_x;
-    const int x = (int)(b % tiles_x) * 256 + threadIdx.x;
+    const int x = (int)(b % tiles_x) * HE_BLOCK + threadIdx.x;
     const int z = (int)(row / h), y = (int)(row - (i64)z * h);
     const i64 wh = (i64)w * h;
     unsigned int omin = 0xffffffffu, omax = 0u;
     // Phase 1 (all lanes): Hessian of the own voxel and the decision whether the eigen-solver is needed.
     // Phase 2: the surviving voxels of the 256-voxel block are compacted through LDS so that whole
     // wavefronts drop out instead of idling next to a few busy lanes (the fp64 solver is the cost).
-    __shared__ float s_h[256][6];
-    __shared__ int s_x[256];
+    __shared__ float s_h[HE_BLOCK][6];
+    __shared__ int s_x[HE_BLOCK];
     __shared__ int s_cnt;
     if (!DUMP) {
         if (threadIdx.x == 0) s_cnt = 0;
@@ -584,9 +586,9 @@ int pnr_hessian_run(pnr_ctx *c, float sig, float *const d_out[6])
     int rc = pnr_gaussian_run(c, sig, c->d_tmpA);
     if (rc) return rc;
     const int w = (int)c->w, h = (int)c->h, l = (int)c->l;
-    const int tiles_x = (w + 255) / 256;
+    const int tiles_x = (w + HE_BLOCK - 1) / HE_BLOCK;
     HessOut dump{d_out[0], d_out[1], d_out[2], d_out[3], d_out[4], d_out[5]};
-    hipLaunchKernelGGL(hessian_eigen<true>, dim3((unsigned)((i64)h * l * tiles_x)), dim3(256), 0, c->stream, c->d_tmpA,
+    hipLaunchKernelGGL(hessian_eigen<true>, dim3((unsigned)((i64)h * l * tiles_x)), dim3(HE_BLOCK), 0, c->stream, c->d_tmpA,
                        (float *)nullptr, (unsigned char *)nullptr, (unsigned char *)nullptr, (unsigned char *)nullptr, w, h,
                        l, tiles_x, sig * sig, 0.f, 0.f, 0.f, 1, (unsigned int *)nullptr, dump);
     PNR_HIP(hipGetLastError());
@@ -611,9 +613,9 @@ int pnr_frangi_run(pnr_ctx *c, float *Jmin, float *Jmax)
     for (int s = 0; s < P.nsig; s++) {
         rc = gaussian3d(c, c->tab.gxy[s], c->tab.gz[s], d_taps + (size_t)s * (2 * (2 * MAX_L + 1)), c->d_tmpA);
         if (rc) { hipFree(d_taps); return rc; }
-        const int tiles_x = (w + 255) / 256;
+        const int tiles_x = (w + HE_BLOCK - 1) / HE_BLOCK;
         c->tic();
-        hipLaunchKernelGGL(hessian_eigen<false>, dim3((unsigned)((i64)h * l * tiles_x)), dim3(256), 0, c->stream, c->d_tmpA,
+        hipLaunchKernelGGL(hessian_eigen<false>, dim3((unsigned)((i64)h * l * tiles_x)), dim3(HE_BLOCK), 0, c->stream, c->d_tmpA,
                            c->d_J, c->d_Vx, c->d_Vy, c->d_Vz, w, h, l, tiles_x, P.sig[s] * P.sig[s], two_a2, two_b2, two_c2,
                            s == 0 ? 1 : 0, c->d_minmax, HessOut{});
         c->toc("hessian_eigen");
