@@ -350,7 +350,7 @@ struct HessOut {
 constexpr int HE_BLOCK = 256;  // voxels per block along x: the larger the block, the tighter the survivors pack into waves
 
 template <bool DUMP>
-__global__ __launch_bounds__(HE_BLOCK) void hessian_eigen(const float *__restrict__ F, float *__restrict__ J,
+__global__ __launch_bounds__(HE_BLOCK, 8) void hessian_eigen(const float *__restrict__ F, float *__restrict__ J,
                                                       unsigned char *__restrict__ Vx, unsigned char *__restrict__ Vy,
                                                       unsigned char *__restrict__ Vz, int w, int h, int l, int tiles_x,
                                                       float s2, float two_a2, float two_b2, float two_c2, int first,

@@ -233,3 +233,24 @@ def test_full_size_properties_512():
     assert np.all((n1["x"][1:] >= -0.5) & (n1["x"][1:] < S - 0.5)) and np.all(n1["corr"][1:] >= p.znccth)
     del img
     torch.cuda.empty_cache()
+
+
+def test_trace_without_stash_matches(oracle, monkeypatch):
+    """the in-lane two-pass fallback (no HBM stash slot) must give the same traces as the two-phase form"""
+    img = synth.synth(64, 56, 32, seed=2)
+    so = _seeds_for(oracle, img, [2.0, 4.0], 2.0, 5)
+    seeds = np.zeros(len(so), lib.SEED_DT)
+    for i, k in enumerate(lib.SEED_DT.names):
+        seeds[k] = so[:, i]
+    p = pnr_amd.make_params(sigmas=[2.0, 4.0], np_=70, ni=15, zdist=2.0)
+    a = pnr_amd.Context(p, 0)
+    a.set_volume(img)
+    Ta, sa, xa, _ = a.trace_batch(seeds)
+    monkeypatch.setenv("PNR_NO_STASH", "1")
+    b = pnr_amd.Context(p, 0)
+    b.set_volume(img)
+    Tb, sb, xb, _ = b.trace_batch(seeds)
+    assert np.array_equal(Ta, Tb) and np.array_equal(sa, sb) and Ta.max() > 3
+    for j in range(len(Ta)):
+        rows = min(Ta[j] + 1, 15)
+        assert np.array_equal(mat(xa[j])[:rows], mat(xb[j])[:rows])
