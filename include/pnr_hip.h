@@ -152,6 +152,15 @@ int pnr_trace_replay(pnr_ctx *ctx, const pnr_seed *seeds, int64_t n, int64_t fir
                      int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links,
                      int64_t *n_traces_used, int64_t *n_iterations);
 
+/* reconstruct() chain of the plugin (Advantra_plugin.cpp:2096-2181), pure host: link resampling
+ * (TRACE_RSMPL) -> mean-shift refinement (SIG2RADIUS, REFINE_ITER, EPSILON2) -> sphere grouping (GROUP_RADIUS) ->
+ * BFS trees -> drop trees < TREE_SIZE_MIN -> tree resampling.  Input: the node graph of pnr_trace_replay /
+ * pnr_replay_traces.  Output: the tree list save_nodelist writes (node 0 dummy; parent -1 = root).  Values <= 0
+ * select the plugin constants (1.0, 1.5, 4, 1e-4, 2.0, 10). */
+int pnr_reconstruct(const pnr_node *nodes, int64_t n_nodes, const int32_t *links, int64_t n_links, float trace_rsmpl,
+                    float sig2radius, int refine_iter, float epsilon2, float group_radius, int tree_size_min,
+                    pnr_node *out_nodes, int32_t *out_parent, int64_t cap, int64_t *n_out);
+
 /* Tracker tables for parity tests: name in {"p","u","w0","w0_cws","v","w","w_cws","rng",
  * "model_vuw<s>","model_wgt<s>","model_avg","gauss_xy<s>","gauss_z<s>"}.  Copies up to cap
  * 4-byte words into out; *n receives the element count. */

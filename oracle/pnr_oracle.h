@@ -107,6 +107,11 @@ int64_t orc_replay(const float *seeds, int64_t nseeds, const int *T, const float
                    orc_node *nodes, int64_t cap_nodes, int32_t *links, int64_t cap_links,
                    int64_t *nlinks, int64_t *ntraces_used);
 
+/* ---------- graph post-processing (Advantra_plugin.cpp:2096-2181), pnr_oracle_recon.c ---------- */
+int64_t orc_reconstruct(const orc_node *nodes, int64_t n_nodes, const int32_t *links, int64_t n_links, float trace_rsmpl,
+                        float sig2radius, int refine_iter, float epsilon2, float group_radius, int tree_size_min,
+                        orc_node *out, int32_t *parent, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,4 +3,4 @@ multi-scale Frangi vesselness, seed extraction and the batched SMC particle trac
 hand-written HIP kernels behind a C ABI (include/pnr_hip.h).  See DESIGN.md."""
 from . import lib  # noqa: F401
 from .lib import Context, Params, PnrError, make_params  # noqa: F401
-from .advantra import Frangi, SeedExtractor, Tracker, advantra_func, write_swc  # noqa: F401
+from .advantra import Frangi, SeedExtractor, Tracker, advantra_func, write_swc, write_swc_tree  # noqa: F401

@@ -146,6 +146,20 @@ def write_swc(path, nodes, links, sig2r=1.0, name="Advantra", comment="", type_o
                 f.write(f"{i} {t} {nd['x']:.3f} {nd['y']:.3f} {nd['z']:.3f} {sig2r * nd['sig']:.3f} {par}\n")
 
 
+def write_swc_tree(path, tree, parent, sig2r=1.0, name="Advantra", comment="", type_override=-1):
+    """save_nodelist for a tree list (each node carries 0 or 1 link: its parent)."""
+    with open(path, "w") as f:
+        f.write(f"#name {name}\n")
+        for ln in comment.split("\n"):
+            if ln:
+                f.write(("#comment " if not ln.startswith("#") else "") + ln + "\n")
+        f.write("##n,type,x,y,z,radius,parent\n")
+        for i in range(1, len(tree)):
+            nd = tree[i]
+            t = int(nd["type"]) if type_override == -1 else type_override
+            f.write(f"{i} {t} {nd['x']:.3f} {nd['y']:.3f} {nd['z']:.3f} {sig2r * nd['sig']:.3f} {int(parent[i])}\n")
+
+
 def _comment(paras, channel=1):
     keys = ["neuritesigmas", "somaradius", "tolerance", "znccth", "kappa", "step", "ni", "np", "zdist", "nodepervol", "vol"]
     s = "email: miro@braincadet.com\n#params:\n#channel=%d" % channel
@@ -189,14 +203,14 @@ def advantra_func(infiles, paras, device=0, rng_seed=42, image=None, verbose=Tru
     res = run_pipeline(ctx, img, verbose=verbose)
     if infiles:
         out = f"{infiles[0]}_Advantra{out_suffix}.swc"
-        write_swc(out, res["nodes"], res["links"], comment=_comment(paras) + "\n#stage=n0 (trace graph; reconstruct() refinement is a later row)")
+        write_swc_tree(out, res["tree"], res["parent"], comment=_comment(paras))
         res["swc"] = out
     advantra_func.last = res
     ctx.close()
     return True
 
 
-def run_pipeline(ctx, img, verbose=False, max_seeds=None, one_shot=False):
+def run_pipeline(ctx, img, verbose=False, max_seeds=None, one_shot=False, reconstruct=True):
     """reconstruction_func's hot path (Advantra_plugin.cpp:2488-2710): Frangi -> J8 -> seeds ->
     score/filter/sort -> trace all seeds on the GPU -> host replay."""
     import time
@@ -214,10 +228,12 @@ def run_pipeline(ctx, img, verbose=False, max_seeds=None, one_shot=False):
     else:         # production form: seed-rank batches with early DENSITY stops (same node graph)
         T = stop = xc = None
         nodes, links, ntr, iters = ctx.trace_replay(seeds); t.append(time.time()); t.append(time.time())
+    tree, parent = lib.reconstruct(nodes, links) if reconstruct else (None, None)  # reconstruct(n0, ...) :2729
+    t.append(time.time())
     if verbose:
-        names = ["frangi", "seed extraction", "seed selection & sorting", "tracing", "replay"]
+        names = ["frangi", "seed extraction", "seed selection & sorting", "tracing", "replay", "reconstruct"]
         for nm, a, b in zip(names, t[:-1], t[1:]):
             print(f"{nm}... {b - a:.3f} sec.")
         print(f"{len(seeds_init) / 1000.0}k seeds -> {len(seeds) / 1000.0}k seeds, {ntr} traces, {len(nodes) - 1} nodes")
     return dict(Jmin=jmin, Jmax=jmax, seeds_init=seeds_init, seeds=seeds, T=T, stop=stop, xc=xc, nodes=nodes, links=links,
-                ntraces=ntr, iters=iters, times=np.diff(t))
+                ntraces=ntr, iters=iters, tree=tree, parent=parent, times=np.diff(t))

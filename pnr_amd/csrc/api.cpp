@@ -4,6 +4,7 @@
 // (tracker.cpp:825-933 + Advantra_plugin.cpp:2602-2710).
 #include "ctx.h"
 #include "replay.h"
+#include "../host/reconstruct.h"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -463,6 +464,29 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
     if (links) std::memcpy(links, r.links.data(), 8 * (size_t)std::min<int64_t>(cap_links, *n_links));
     if (n_traces_used) *n_traces_used = r.trace_count;
     if (n_iterations) *n_iterations = iters;
+    return PNR_OK;
+}
+
+int pnr_reconstruct(const pnr_node *nodes, int64_t n_nodes, const int32_t *links, int64_t n_links, float trace_rsmpl,
+                    float sig2radius, int refine_iter, float epsilon2, float group_radius, int tree_size_min,
+                    pnr_node *out_nodes, int32_t *out_parent, int64_t cap, int64_t *n_out)
+{
+    PNR_REQUIRE(nodes && n_nodes >= 1 && n_out && (n_links == 0 || links), PNR_E_ARG, "null argument");
+    for (int64_t k = 0; k < 2 * n_links; k++) PNR_REQUIRE(links[k] >= 0 && links[k] < n_nodes, PNR_E_ARG, "link index out of range");
+    advantra::ReconParams rp;
+    if (trace_rsmpl > 0) rp.trace_rsmpl = trace_rsmpl;
+    if (sig2radius > 0) rp.sig2radius = sig2radius;
+    if (refine_iter > 0) rp.refine_iter = refine_iter;
+    if (epsilon2 > 0) rp.epsilon2 = epsilon2;
+    if (group_radius > 0) rp.group_radius = group_radius;
+    if (tree_size_min > 0) rp.tree_size_min = tree_size_min;
+    std::vector<pnr_node> in(nodes, nodes + n_nodes), out;
+    std::vector<int32_t> lk(links, links + 2 * n_links), par;
+    advantra::reconstruct(in, lk, rp, out, par);
+    *n_out = (int64_t)out.size();
+    const size_t m = (size_t)std::min<int64_t>(cap, *n_out);
+    if (out_nodes) std::memcpy(out_nodes, out.data(), sizeof(pnr_node) * m);
+    if (out_parent) std::memcpy(out_parent, par.data(), 4 * m);
     return PNR_OK;
 }
 

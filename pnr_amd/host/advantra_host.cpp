@@ -172,6 +172,31 @@ bool save_nodelist(const std::vector<pnr_node> &nodes, const std::vector<int32_t
     return true;
 }
 
+bool save_treelist(const std::vector<pnr_node> &tree, const std::vector<int32_t> &parent, const std::string &swcname, int type,
+                   float sig2r, const std::string &name, const std::string &comment)
+{
+    FILE *f = fopen(swcname.c_str(), "w");
+    if (!f) return false;
+    if (!name.empty()) fprintf(f, "#name %s\n", name.c_str());
+    if (!comment.empty()) {
+        std::stringstream ss(comment);
+        std::string ln;
+        bool first = true;
+        while (std::getline(ss, ln)) {
+            if (ln.empty()) continue;
+            fprintf(f, "%s%s\n", (first || ln[0] != '#') ? "#comment " : "", ln.c_str());
+            first = false;
+        }
+    }
+    fprintf(f, "##n,type,x,y,z,radius,parent\n");
+    for (size_t i = 1; i < tree.size(); i++) {
+        const pnr_node &nd = tree[i];
+        fprintf(f, "%zu %d %.3f %.3f %.3f %.3f %d\n", i, (type == -1) ? nd.type : type, nd.x, nd.y, nd.z, sig2r * nd.sig, parent[i]);
+    }
+    fclose(f);
+    return true;
+}
+
 int parse_params(const std::vector<std::string> &paras, pnr_params &p, std::string &err)
 {
     if ((int)paras.size() != nrInputParams) { // Advantra_plugin.cpp:295-299
@@ -224,7 +249,7 @@ static std::string swc_comment(const std::vector<std::string> &paras, const pnr_
     for (int i = 0; i < nrInputParams; i++) c << "\n#" << keys[i] << "=" << paras[i];
     c << "\n#------------------------\n#Kc=" << p.Kc << "\n#neff_ratio=" << p.neff_ratio << "\n#frangi_alfa=" << p.alpha
       << "\n#frangi_beta=" << p.beta << "\n#frangi_C=" << p.C << "\n#MAX_TRACE_COUNT=" << p.max_trace_count
-      << "\n#stage=n0 (trace graph; the reconstruct() refinement chain is a later row, SURVEY.md 8f-1)";
+      << "\n#EPSILON2=0.0001\n#REFINE_ITER=4\n#SIG2RADIUS=1.5\n#TRACE_RSMPL=1\n#GROUP_RADIUS=2\n#ENFORCE_SINGLE_TREE=0\n#TREE_SIZE_MIN=10\n#TAIL_SIZE_MIN=2";
     return c.str();
 }
 
@@ -303,10 +328,31 @@ bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *>
     R.n_seeds_init = nfound; R.n_seeds = nseeds; R.n_traces = used; R.n_iterations = iters;
     R.t_frangi = secs(t0, t1); R.t_seeds = secs(t1, t2); R.t_select = secs(t2, t3); R.t_trace = secs(t3, t4);
     printf("\n-----\n%g%% seeds used \n", nseeds ? 100.0 * used / nseeds : 0.0);
+    { // reconstruct(n0, ...) :2729 -> :2096-2181 (host): refinement, grouping, trees, final resampling
+        int64_t cap = std::max<int64_t>(16, 4 * nn), nt = 0;
+        for (;;) {
+            R.tree.resize((size_t)cap);
+            R.parent.resize((size_t)cap);
+            if (pnr_reconstruct(R.nodes.data(), nn, R.links.data(), nl, 0, 0, 0, 0, 0, 0, R.tree.data(), R.parent.data(), cap, &nt) != PNR_OK) {
+                fprintf(stderr, "%s\n", pnr_last_error());
+                pnr_destroy(ctx);
+                return true;
+            }
+            if (nt <= cap) break;
+            cap = nt;
+        }
+        R.tree.resize((size_t)nt);
+        R.parent.resize((size_t)nt);
+    }
+    auto t5 = clk::now();
+    R.t_recon = secs(t4, t5);
     R.swc_path = std::string(infiles[0]) + "_Advantra.swc"; // :2164
-    save_nodelist(R.nodes, R.links, R.swc_path, -1, 1.f, "Advantra", swc_comment(paras, p));
-    printf("%s\n%lld nodes, %lld traces, %lld SMC iterations | frangi %.3f s, seeds %.3f s, selection %.3f s, tracing %.3f s\n",
-           R.swc_path.c_str(), (long long)nn - 1, (long long)used, (long long)iters, R.t_frangi, R.t_seeds, R.t_select, R.t_trace);
+    save_treelist(R.tree, R.parent, R.swc_path, -1, 1.f, "Advantra", swc_comment(paras, p));
+    if (getenv("PNR_SAVE_MIDRES")) save_nodelist(R.nodes, R.links, std::string(infiles[0]) + "_n0_.swc"); // saveMidres tap (:2099)
+    printf("%s\n%lld trace nodes, %lld traces, %lld SMC iterations, %zu tree nodes | frangi %.3f s, seeds %.3f s, selection %.3f s, "
+           "tracing %.3f s, reconstruct %.3f s\n",
+           R.swc_path.c_str(), (long long)nn - 1, (long long)used, (long long)iters, R.tree.size() - 1, R.t_frangi, R.t_seeds, R.t_select,
+           R.t_trace, R.t_recon);
     pnr_destroy(ctx);
     if (result) *result = R;
     return true;

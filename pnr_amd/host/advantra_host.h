@@ -23,8 +23,10 @@ struct Result {
     long long n_seeds_init = 0, n_seeds = 0, n_traces = 0, n_iterations = 0;
     std::vector<pnr_node> nodes;   // nodes[0] = dummy
     std::vector<int32_t> links;    // pairs
+    std::vector<pnr_node> tree;    // reconstruct() output: tree list, tree[0] = dummy
+    std::vector<int32_t> parent;   // parent index per tree node, -1 = root
     std::string swc_path;
-    double t_frangi = 0, t_seeds = 0, t_select = 0, t_trace = 0;
+    double t_frangi = 0, t_seeds = 0, t_select = 0, t_trace = 0, t_recon = 0;
 };
 
 void print_help();
@@ -34,6 +36,9 @@ bool load_stack(const std::string &path, const std::string &raw_dims, Stack &out
 // save_nodelist (Advantra_plugin.cpp:480-523)
 bool save_nodelist(const std::vector<pnr_node> &nodes, const std::vector<int32_t> &links, const std::string &swcname,
                    int type = -1, float sig2r = 1.f, const std::string &name = "", const std::string &comment = "");
+// the same writer for a tree list (each node has 0 or 1 link: its parent)
+bool save_treelist(const std::vector<pnr_node> &tree, const std::vector<int32_t> &parent, const std::string &swcname, int type = -1,
+                   float sig2r = 1.f, const std::string &name = "", const std::string &comment = "");
 // 0 = ok, -1 = usage error (dofunc returns false), -2 = range error (dofunc "return 0"), -3 = runtime failure
 int parse_params(const std::vector<std::string> &paras, pnr_params &p, std::string &err);
 bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *> &paras, int device = 0,

@@ -1,0 +1,305 @@
+// reconstruct.cpp -- see reconstruct.h.  Pure host code (the reference keeps this stage on the host as well).
+#include "reconstruct.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <numeric>
+#include <unordered_map>
+
+namespace advantra {
+namespace {
+
+struct N {
+    float x, y, z, vx, vy, vz, corr, sig;
+    int type;
+    std::vector<int> nbr;
+};
+typedef std::vector<N> List;
+
+inline float length(const N &a, const N &b)
+{
+    // sqrt(pow(dx,2)+pow(dy,2)+pow(dz,2)) with f32 differences: f64 arithmetic, f32 result
+    const double dx = (double)(b.x - a.x), dy = (double)(b.y - a.y), dz = (double)(b.z - a.z);
+    return (float)std::sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+N between(const N &a, const N &b, int k, int Nseg, float vnorm, float vx, float vy, float vz)
+{
+    N m;
+    m.x = a.x + k * (vnorm / Nseg) * vx;
+    m.y = a.y + k * (vnorm / Nseg) * vy;
+    m.z = a.z + k * (vnorm / Nseg) * vz;
+    m.vx = vx; m.vy = vy; m.vz = vz;
+    m.corr = a.corr + (b.corr - a.corr) * (k / (float)Nseg);
+    m.sig = a.sig + (b.sig - a.sig) * (k / (float)Nseg);
+    m.type = (k <= Nseg / 2) ? a.type : b.type;
+    return m;
+}
+
+// :780-861 -- every bidirectional link longer than `step` gets evenly spaced nodes
+void resample_links(List &g, float step)
+{
+    const size_t init = g.size();
+    std::vector<std::vector<char>> done(init);
+    for (size_t i = 0; i < init; i++) done[i].assign(g[i].nbr.size(), 0);
+    for (size_t i = 1; i < init; i++)
+        for (size_t j = 0; j < g[i].nbr.size(); j++) {
+            if (done[i][j]) continue;
+            const int i1 = g[i].nbr[j];
+            const size_t j1 = std::find(g[i1].nbr.begin(), g[i1].nbr.end(), (int)i) - g[i1].nbr.begin();
+            if (j1 >= g[i1].nbr.size()) continue; // no link back: left alone
+            done[i][j] = 1;
+            done[i1][j1] = 1;
+            const float vnorm = length(g[i], g[i1]);
+            const float vx = (g[i1].x - g[i].x) / vnorm, vy = (g[i1].y - g[i].y) / vnorm, vz = (g[i1].z - g[i].z) / vnorm;
+            const int Nseg = (int)std::ceil(vnorm / step);
+            for (int k = 1; k < Nseg; k++) {
+                g.push_back(between(g[i], g[i1], k, Nseg, vnorm, vx, vy, vz));
+                const int last = (int)g.size() - 1;
+                if (k == 1) { g[last].nbr.push_back((int)i); g[i].nbr[j] = last; }
+                else { g[last].nbr.push_back(last - 1); g[last - 1].nbr.push_back(last); }
+                if (k == Nseg - 1) { g[last].nbr.push_back(i1); g[i1].nbr[j1] = last; }
+            }
+        }
+}
+
+// uniform grid over node positions (indices >= 1); cell lists are ascending by construction
+struct Grid {
+    float cell;
+    std::unordered_map<long long, std::vector<int>> cells;
+    static long long key(int a, int b, int c) { return ((long long)(a + (1 << 20)) << 42) | ((long long)(b + (1 << 20)) << 21) | (long long)(c + (1 << 20)); }
+    Grid(const List &g, float cell_) : cell(cell_)
+    {
+        cells.reserve(g.size());
+        for (size_t i = 1; i < g.size(); i++) cells[key(bin(g[i].x), bin(g[i].y), bin(g[i].z))].push_back((int)i);
+    }
+    int bin(float v) const { return (int)std::floor(v / cell); }
+    // all node indices whose cell intersects the cube of half-width R around (x,y,z), ascending
+    void query(float x, float y, float z, float R, std::vector<int> &out) const
+    {
+        out.clear();
+        for (int a = bin(x - R); a <= bin(x + R); a++)
+            for (int b = bin(y - R); b <= bin(y + R); b++)
+                for (int c = bin(z - R); c <= bin(z + R); c++) {
+                    auto it = cells.find(key(a, b, c));
+                    if (it != cells.end()) out.insert(out.end(), it->second.begin(), it->second.end());
+                }
+        std::sort(out.begin(), out.end());
+    }
+};
+
+// :968-1052 -- non-blurring mean-shift of (x,y,z,sig) with a kernel radius SIG2RAD*sig
+void mean_shift(const List &src, List &dst, float SIG2RAD, int MAXITER, float EPS2)
+{
+    dst = src;
+    float smax = 0;
+    for (size_t i = 1; i < src.size(); i++) smax = std::max(smax, src[i].sig);
+    const Grid grid(src, std::max(4.0f, SIG2RAD * smax));
+    std::vector<int> cand;
+    for (size_t i = 1; i < dst.size(); i++) {
+        float conv[4] = {src[i].x, src[i].y, src[i].z, src[i].sig}, next[4];
+        int iter = 0, cnt;
+        float d2;
+        do {
+            cnt = 0;
+            next[0] = next[1] = next[2] = next[3] = 0;
+            const float r2 = (float)std::pow((double)(SIG2RAD * conv[3]), 2);
+            // candidates in ascending index: the accepted ones are summed in the order of the reference's full scan
+            grid.query(conv[0], conv[1], conv[2], std::sqrt(r2) * 1.0001f + 1e-3f, cand);
+            for (int j : cand) {
+                const float x2 = (float)std::pow((double)(src[j].x - conv[0]), 2);
+                if (x2 <= r2) {
+                    const float y2 = (float)std::pow((double)(src[j].y - conv[1]), 2);
+                    if (x2 + y2 <= r2) {
+                        const float z2 = (float)std::pow((double)(src[j].z - conv[2]), 2);
+                        if (x2 + y2 + z2 <= r2) {
+                            next[0] += src[j].x; next[1] += src[j].y; next[2] += src[j].z; next[3] += src[j].sig;
+                            cnt++;
+                        }
+                    }
+                }
+            }
+            next[0] /= cnt; next[1] /= cnt; next[2] /= cnt; next[3] /= cnt;
+            d2 = (float)(std::pow((double)(next[0] - conv[0]), 2) + std::pow((double)(next[1] - conv[1]), 2) + std::pow((double)(next[2] - conv[2]), 2));
+            for (int q = 0; q < 4; q++) conv[q] = next[q];
+            iter++;
+        } while (iter < MAXITER && d2 > EPS2);
+        dst[i].x = conv[0]; dst[i].y = conv[1]; dst[i].z = conv[2]; dst[i].sig = conv[3];
+    }
+}
+
+// :1532-1564 -- unique neighbour lists, no self links, links made bidirectional
+void tidy_links(List &g)
+{
+    for (size_t i = 1; i < g.size(); i++) {
+        auto &nb = g[i].nbr;
+        std::sort(nb.begin(), nb.end());
+        nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
+        auto self = std::find(nb.begin(), nb.end(), (int)i);
+        if (self != nb.end()) nb.erase(self);
+    }
+    for (size_t i = 1; i < g.size(); i++)
+        for (size_t j = 0; j < g[i].nbr.size(); j++) {
+            auto &other = g[g[i].nbr[j]].nbr;
+            if (std::find(other.begin(), other.end(), (int)i) == other.end()) other.push_back((int)i);
+        }
+}
+
+// :1566-1642 -- greedy sphere grouping in order of decreasing corr; a group is the running mean of its members
+void group_spheres(List &src, List &dst, float rad)
+{
+    const size_t n = src.size();
+    src[0].corr = FLT_MAX;
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    // the reference's std::sort by corr is unstable; equal corr keeps index order here
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return src[a].corr > src[b].corr; });
+    std::vector<int> to(n, -1);
+    to[0] = 0;
+    dst.clear();
+    dst.push_back(src[0]);
+    const Grid grid(src, std::max(2.0f, rad));
+    std::vector<int> cand;
+    const float r2 = rad * rad;
+    for (size_t oi = 1; oi < n; oi++) {
+        const int ci = order[oi];
+        if (to[ci] != -1) continue;
+        to[ci] = (int)dst.size();
+        N grp = src[ci];
+        float members = 1;
+        grid.query(src[ci].x, src[ci].y, src[ci].z, rad * 1.0001f + 1e-3f, cand);
+        for (int j : cand) {
+            if (j == ci || to[j] != -1) continue;
+            float d2 = (float)std::pow((double)(src[j].x - src[ci].x), 2);
+            if (!(d2 <= r2)) continue;
+            d2 = (float)(d2 + std::pow((double)(src[j].y - src[ci].y), 2));
+            if (!(d2 <= r2)) continue;
+            d2 = (float)(d2 + std::pow((double)(src[j].z - src[ci].z), 2));
+            if (!(d2 <= r2)) continue;
+            to[j] = (int)dst.size();
+            grp.nbr.insert(grp.nbr.end(), src[j].nbr.begin(), src[j].nbr.end());
+            members++;
+            const float a = (members - 1) / members;
+            const float b = (float)(1.0 / members);
+            grp.x = a * grp.x + b * src[j].x;
+            grp.y = a * grp.y + b * src[j].y;
+            grp.z = a * grp.z + b * src[j].z;
+            grp.sig = a * grp.sig + b * src[j].sig;
+            grp.corr = a * grp.corr + b * src[j].corr;
+        }
+        grp.type = 2; // Node::AXON
+        dst.push_back(grp);
+    }
+    for (size_t i = 1; i < dst.size(); i++)
+        for (int &v : dst[i].nbr) v = to[v];
+    tidy_links(dst);
+}
+
+// :379-478 -- breadth-first forest: every node keeps at most one link (to its BFS parent); single-node trees dropped
+void bfs_forest(const List &g, List &tree)
+{
+    const size_t n = g.size();
+    std::vector<char> seen(n, 0);
+    std::vector<int> where(n, -1), parent(n, -1), queue;
+    tree.clear();
+    tree.push_back(g[0]);
+    int trees = 0;
+    size_t scan = 1; // first never-discovered index only moves forward
+    for (;;) {
+        while (scan < n && seen[scan]) scan++;
+        if (scan >= n) break;
+        trees++;
+        queue.assign(1, (int)scan);
+        seen[scan] = 1;
+        size_t head = 0;
+        int in_tree = 0;
+        while (head < queue.size()) {
+            const int cur = queue[head++];
+            N t = g[cur];
+            t.nbr.clear();
+            if (t.type != 1) t.type = trees + 2;
+            if (parent[cur] > 0) t.nbr.push_back(where[parent[cur]]);
+            where[cur] = (int)tree.size();
+            tree.push_back(t);
+            in_tree++;
+            for (int adj : g[cur].nbr)
+                if (!seen[adj] && adj != 0) { seen[adj] = 1; parent[adj] = cur; queue.push_back(adj); }
+            if (in_tree == 1 && head == queue.size()) { tree.pop_back(); where[cur] = -1; }
+        }
+    }
+}
+
+// :591-629 -- drop trees with fewer than min_size nodes (a tree = run of nodes starting at a parentless one)
+void drop_small_trees(const List &X, List &Y, int min_size)
+{
+    const size_t n = X.size();
+    std::vector<char> drop(n + 1, 0);
+    size_t root_cur = 1, root_prev = 1;
+    for (size_t i = 1; i <= n; i++)
+        if (i == n || X[i].nbr.empty()) {
+            root_prev = root_cur;
+            root_cur = i;
+            if ((long)(root_cur - root_prev) < (long)min_size)
+                for (size_t j = root_prev; j < root_cur; j++) drop[j] = 1;
+        }
+    std::vector<int> to(n, -1);
+    Y.clear();
+    for (size_t i = 0; i < n; i++)
+        if (!drop[i]) { to[i] = (int)Y.size(); Y.push_back(X[i]); }
+    for (size_t i = 1; i < Y.size(); i++)
+        for (int &v : Y[i].nbr) v = to[v];
+}
+
+// :714-778 -- resample the (one-directional) tree links
+void resample_tree(List &t, float step, int type)
+{
+    const size_t init = t.size();
+    for (size_t i = 1; i < init; i++) {
+        if (type >= 0 && t[i].type != 1) t[i].type = type;
+        for (size_t j = 0; j < t[i].nbr.size(); j++) {
+            const int i1 = t[i].nbr[j];
+            const float vnorm = length(t[i], t[i1]);
+            const float vx = (t[i1].x - t[i].x) / vnorm, vy = (t[i1].y - t[i].y) / vnorm, vz = (t[i1].z - t[i].z) / vnorm;
+            const int Nseg = (int)std::ceil(vnorm / step);
+            for (int k = 1; k < Nseg; k++) {
+                t.push_back(between(t[i], t[i1], k, Nseg, vnorm, vx, vy, vz));
+                const int last = (int)t.size() - 1;
+                if (k == 1) t[i].nbr[j] = last;
+                else t[last - 1].nbr.push_back(last);
+                if (k == Nseg - 1) t[last].nbr.push_back(i1);
+            }
+        }
+    }
+}
+
+} // namespace
+
+void reconstruct(const std::vector<pnr_node> &nodes, const std::vector<int32_t> &links, const ReconParams &rp,
+                 std::vector<pnr_node> &out_nodes, std::vector<int32_t> &out_parent)
+{
+    List n0(nodes.size());
+    for (size_t i = 0; i < nodes.size(); i++) {
+        const pnr_node &s = nodes[i];
+        n0[i] = N{s.x, s.y, s.z, s.vx, s.vy, s.vz, s.corr, s.sig, s.type, {}};
+    }
+    for (size_t k = 0; k + 1 < links.size(); k += 2) {
+        n0[links[k]].nbr.push_back(links[k + 1]);
+        n0[links[k + 1]].nbr.push_back(links[k]);
+    }
+    List n1, n2, forest, kept;
+    resample_links(n0, rp.trace_rsmpl);
+    mean_shift(n0, n1, rp.sig2radius, rp.refine_iter, rp.epsilon2);
+    group_spheres(n1, n2, rp.group_radius);
+    bfs_forest(n2, forest);
+    drop_small_trees(forest, kept, rp.tree_size_min);
+    resample_tree(kept, 1.0f, 2 /* Node::AXON */);
+    out_nodes.resize(kept.size());
+    out_parent.resize(kept.size());
+    for (size_t i = 0; i < kept.size(); i++) {
+        const N &s = kept[i];
+        out_nodes[i] = pnr_node{s.x, s.y, s.z, s.vx, s.vy, s.vz, s.corr, s.sig, s.type};
+        out_parent[i] = (i > 0 && !s.nbr.empty()) ? s.nbr[0] : -1;
+    }
+}
+
+} // namespace advantra

@@ -80,6 +80,7 @@ def load():
     L.pnr_replay_traces.argtypes = [C.POINTER(Params), i64, i64, i64, vp, i64, vp, vp, vp, i64, C.POINTER(i64), vp, i64,
                                     C.POINTER(i64), C.POINTER(i64)]
     L.pnr_trace_replay.argtypes = [vp, vp, i64, i64, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    L.pnr_reconstruct.argtypes = [vp, i64, vp, i64, C.c_float, C.c_float, i32, C.c_float, C.c_float, i32, vp, vp, i64, C.POINTER(i64)]
     L.pnr_get_table.argtypes = [vp, C.c_char_p, vp, i64, C.POINTER(i64)]
     L.pnr_set_profiling.argtypes = [vp, i32]
     L.pnr_get_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
@@ -95,7 +96,7 @@ def load():
 EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", "pnr_set_stream", "pnr_synchronize",
            "pnr_set_volume", "pnr_set_volume_device", "pnr_frangi", "pnr_get_frangi", "pnr_gaussian", "pnr_hessian",
            "pnr_set_j8_v", "pnr_extract_seeds", "pnr_extract_seeds_range", "pnr_zncc_batch",
-           "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_trace_replay", "pnr_get_table", "pnr_set_profiling",
+           "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_trace_replay", "pnr_reconstruct", "pnr_get_table", "pnr_set_profiling",
            "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch"]
 
 
@@ -298,3 +299,20 @@ def replay(params, shape, seeds, T, xc):
     check(L.pnr_replay_traces(C.byref(params), w, h, l, s.ctypes.data, len(s), T.ctypes.data, xc.ctypes.data,
                               nodes.ctypes.data, cap, C.byref(nn), links.ctypes.data, len(links), C.byref(nl), C.byref(nt)))
     return nodes[:nn.value].copy(), links[:nl.value].copy(), nt.value
+
+
+def reconstruct(nodes, links, trace_rsmpl=0.0, sig2radius=0.0, refine_iter=0, epsilon2=0.0, group_radius=0.0, tree_size_min=0):
+    """reconstruct() chain on the host (pnr_reconstruct): tree nodes (index 0 dummy) and parent indices (-1 = root)."""
+    L = load()
+    nodes = np.ascontiguousarray(nodes, NODE_DT)
+    links = np.ascontiguousarray(links, np.int32).reshape(-1, 2)
+    cap = max(16, 4 * len(nodes))
+    while True:
+        out = np.zeros(cap, NODE_DT)
+        par = np.zeros(cap, np.int32)
+        n = C.c_int64()
+        check(L.pnr_reconstruct(nodes.ctypes.data, len(nodes), links.ctypes.data, len(links), trace_rsmpl, sig2radius, refine_iter,
+                                epsilon2, group_radius, tree_size_min, out.ctypes.data, par.ctypes.data, cap, C.byref(n)))
+        if n.value <= cap:
+            return out[:n.value].copy(), par[:n.value].copy()
+        cap = int(n.value)

@@ -62,6 +62,9 @@ def load_oracle():
     L.orc_replay.argtypes = [f32p, C.c_int64, i32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_void_p, C.c_int64, i32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.orc_replay.restype = C.c_int64
+    L.orc_reconstruct.argtypes = [C.c_void_p, C.c_int64, i32p, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int,
+                                  C.c_void_p, i32p, C.c_int64]
+    L.orc_reconstruct.restype = C.c_int64
     return L
 
 
@@ -180,3 +183,17 @@ def replay(L, seeds, T, xc, ni, shape, nodespervol, vol, max_trace_count=5000):
                       np.ascontiguousarray(xc, np.float32), ni, w, h, l, nodespervol, vol, max_trace_count,
                       nodes.ctypes.data, cap, links, len(links), C.byref(nl), C.byref(nt))
     return nodes[:nn].copy(), links[:nl.value].copy(), nt.value
+
+
+def reconstruct(L, nodes, links, trace_rsmpl=1.0, sig2radius=1.5, refine_iter=4, epsilon2=1e-4, group_radius=2.0, tree_size_min=10):
+    nodes = np.ascontiguousarray(nodes, NODE_DT)
+    links = np.ascontiguousarray(links, np.int32).reshape(-1, 2)
+    cap = max(16, 4 * len(nodes))
+    while True:
+        out = np.zeros(cap, NODE_DT)
+        par = np.zeros(cap, np.int32)
+        n = L.orc_reconstruct(nodes.ctypes.data, len(nodes), links, len(links), trace_rsmpl, sig2radius, refine_iter, epsilon2,
+                              group_radius, tree_size_min, out.ctypes.data, par, cap)
+        if n <= cap:
+            return out[:n].copy(), par[:n].copy()
+        cap = int(n)

@@ -48,8 +48,8 @@ def test_cli_matches_python_pipeline(tmp_path):
     ctx = pnr_amd.Context(p, 0)
     res = pnr_amd.advantra.run_pipeline(ctx, img)
     ref = str(tmp_path / "ref.swc")
-    pnr_amd.write_swc(ref, res["nodes"], res["links"])
+    pnr_amd.write_swc_tree(ref, res["tree"], res["parent"])
     want = np.array([[float(v) for v in ln.split()] for ln in open(ref) if ln[0] != "#"])
-    assert rows.shape == want.shape and len(rows) > 100
+    assert rows.shape == want.shape and len(rows) > 50
     assert np.array_equal(rows[:, [0, 1, 6]], want[:, [0, 1, 6]])  # ids, types, parents
     assert np.allclose(rows[:, 2:6], want[:, 2:6], atol=2e-3)      # %.3f text

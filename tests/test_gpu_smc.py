@@ -254,3 +254,15 @@ def test_trace_without_stash_matches(oracle, monkeypatch):
     for j in range(len(Ta)):
         rows = min(Ta[j] + 1, 15)
         assert np.array_equal(mat(xa[j])[:rows], mat(xb[j])[:rows])
+
+
+def test_end_to_end_tree_vs_oracle(oracle):
+    """whole path incl. the reconstruct() chain: final tree list (what _Advantra.swc holds) equals the oracle's"""
+    img = synth.synth(64, 56, 32, seed=2)
+    sigs, np_, ni, zdist = [2.0], 50, 40, 2.0
+    c = pnr_amd.Context(pnr_amd.make_params(sigmas=sigs, np_=np_, ni=ni, zdist=zdist, nodepervol=4, vol=5), 0)
+    res = pnr_amd.advantra.run_pipeline(c, img)
+    want_n, want_p = orc.reconstruct(oracle, res["nodes"], res["links"])
+    assert len(res["tree"]) == len(want_n) > 50 and np.array_equal(res["parent"], want_p)
+    for k in want_n.dtype.names:
+        assert np.array_equal(res["tree"][k], want_n[k], equal_nan=True), k

@@ -99,3 +99,22 @@ def test_replay_matches_oracle(oracle, vol, nodepervol):
         assert np.array_equal(nodes[k], nodes_o[k]), k
     assert np.array_equal(links, links_o)
     assert (nodes["type"][1:] == 6).sum() >= 1  # END markers present
+
+
+@pytest.mark.parametrize("vol,tree_min", [(5, 10), (1, 3)])
+def test_reconstruct_matches_oracle(oracle, vol, tree_min):
+    """reconstruct() chain (Advantra_plugin.cpp:2096-2181): the grid-accelerated host implementation visits
+    neighbours in ascending index, so it must equal the oracle's plain O(n^2) restatement bit for bit."""
+    img = synth.synth(48, 40, 24, seed=1)
+    s, T, xc = _traces_from_oracle(oracle, img, [2.0], 24, 30, 2.0, nseeds=20)
+    nodes, links, _ = orc.replay(oracle, s, T, xc, 30, img.shape, 4, vol)
+    assert len(nodes) > 60 and len(links) > 40
+    want_n, want_p = orc.reconstruct(oracle, nodes, links, tree_size_min=tree_min)
+    got_n, got_p = lib.reconstruct(nodes.astype(lib.NODE_DT), links, tree_size_min=tree_min)
+    assert len(got_n) == len(want_n) > 10
+    assert np.array_equal(got_p, want_p)
+    for k in got_n.dtype.names:
+        assert np.array_equal(got_n[k], want_n[k], equal_nan=True), k
+    # tree-list invariants: one parent per node, parents are valid, roots exist, all types AXON(2) after the final resampling
+    assert got_p[0] == -1 and (got_p[1:] < len(got_n)).all() and (got_p[1:] == -1).sum() >= 1
+    assert set(np.unique(got_n["type"][1:])) == {2}
