@@ -30,4 +30,5 @@ for rep in range(int(os.environ.get('REPS', '2'))):
     for fb in ([int(x) for x in sys.argv[4].split(',')] if len(sys.argv) > 4 else [0]):
         t0 = time.time(); n2, l2, nt2, it2 = c.trace_replay(s[:nseed], first_batch=fb); t1 = time.time()
         print('   batched trace_replay first_batch', fb, ': wall', round(t1 - t0, 4), 'iterations', it2, 'nodes', len(n2), 'same graph', len(n2) == len(nodes) and np.array_equal(l2, links))
+    t0 = time.time(); tree, par = pnr_amd.lib.reconstruct(nodes, links); print('   reconstruct: wall', round(time.time() - t0, 3), 's;', len(nodes), 'trace nodes ->', len(tree), 'tree nodes,', int((par[1:] == -1).sum()), 'trees')
     print('   trace-iterations', steps, 'evals', steps * 201, 'Mevals/s', steps * 201 / ms / 1e3, 'ms/iter/trace-avg', ms / max(steps, 1), 'Gsamples/s', steps * 201 * nchain / ms / 1e6, 'kernel ms / longest trace iters', ms / max(1, int(T.max()) + 1))
