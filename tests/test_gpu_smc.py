@@ -266,3 +266,16 @@ def test_end_to_end_tree_vs_oracle(oracle):
     assert len(res["tree"]) == len(want_n) > 50 and np.array_equal(res["parent"], want_p)
     for k in want_n.dtype.names:
         assert np.array_equal(res["tree"][k], want_n[k], equal_nan=True), k
+
+
+def test_empty_inputs_end_to_end():
+    """flat stack: Frangi response 0 everywhere, J8 all zero, no seeds, no traces, empty tree; n=0 entry points"""
+    img = np.full((16, 24, 24), 9, np.uint8)
+    c = pnr_amd.Context(pnr_amd.make_params(sigmas=[2.0], np_=20, ni=5), 0)
+    res = pnr_amd.advantra.run_pipeline(c, img)
+    assert len(res["seeds_init"]) == 0 and len(res["seeds"]) == 0 and len(res["nodes"]) == 1 and len(res["links"]) == 0
+    assert len(res["tree"]) == 1 and res["ntraces"] == 0 and res["iters"] == 0
+    T, stop, xc, _ = c.trace_batch(np.zeros(0, lib.SEED_DT))
+    assert len(T) == 0 and xc.shape[0] == 0
+    one = pnr_amd.advantra.run_pipeline(c, img, one_shot=True)
+    assert len(one["nodes"]) == 1

@@ -118,3 +118,27 @@ def test_reconstruct_matches_oracle(oracle, vol, tree_min):
     # tree-list invariants: one parent per node, parents are valid, roots exist, all types AXON(2) after the final resampling
     assert got_p[0] == -1 and (got_p[1:] < len(got_n)).all() and (got_p[1:] == -1).sum() >= 1
     assert set(np.unique(got_n["type"][1:])) == {2}
+
+
+def test_reconstruct_degenerate_inputs():
+    """only the dummy node; isolated nodes; a self-link and duplicate links (what a DENSITY stop can produce)"""
+    dummy = np.zeros(1, lib.NODE_DT)
+    t, p = lib.reconstruct(dummy, np.zeros((0, 2), np.int32))
+    assert len(t) == 1 and p[0] == -1
+    nodes = np.zeros(16, lib.NODE_DT)
+    nodes["x"][1:] = np.arange(15) * 3.0
+    nodes["sig"][1:] = 2.0
+    nodes["corr"][1:] = np.linspace(0.9, 0.5, 15)
+    nodes["type"][1:] = 2
+    links = np.array([[i + 1, i] for i in range(1, 15)] + [[5, 5], [3, 2], [3, 2]], np.int32)
+    t1, p1 = lib.reconstruct(nodes, links, tree_size_min=1)
+    import orc as _orc
+    L = _orc.load_oracle()
+    t2, p2 = _orc.reconstruct(L, nodes, links, tree_size_min=1)
+    assert np.array_equal(p1, p2) and all(np.array_equal(t1[k], t2[k], equal_nan=True) for k in t1.dtype.names)
+    assert len(t1) > 15 and (p1[1:] == -1).sum() == 1  # one chain -> one tree, resampled at unit steps
+    iso = nodes.copy()
+    t3, p3 = lib.reconstruct(iso, np.zeros((0, 2), np.int32), tree_size_min=1)
+    assert len(t3) == 1  # single-node trees are dropped by bfs2
+    with pytest.raises(pnr_amd.PnrError, match="link index out of range"):
+        lib.reconstruct(nodes, np.array([[1, 99]], np.int32))
