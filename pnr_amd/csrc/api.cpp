@@ -153,9 +153,9 @@ void pnr_destroy(pnr_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (int k = 0; k < 3; k++) pnr_job_destroy(c->jobs[k]);
+    for (auto *j : c->jobs) pnr_job_destroy(j);
     if (c->h_j8) hipHostFree(c->h_j8);
-    hipFree(c->d_img_owned); hipFree(c->d_stash); hipFree(c->d_slot_busy); hipFree(c->d_den);
+    hipFree(c->d_img_owned); hipFree(c->d_stash); hipFree(c->d_slot_busy); hipFree(c->d_den); hipFree(c->d_den_idx); hipFree(c->d_den_val);
     hipFree(c->d_tmpA); hipFree(c->d_tmpB); hipFree(c->d_J);
     hipFree(c->d_Vx); hipFree(c->d_Vy); hipFree(c->d_Vz); hipFree(c->d_J8); hipFree(c->d_minmax);
     hipFree(c->d_p); hipFree(c->d_u); hipFree(c->d_w0); hipFree(c->d_w0cws); hipFree(c->d_v); hipFree(c->d_w);
@@ -394,10 +394,16 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
     int64_t iters = 0;
     int64_t batch = first_batch > 0 ? first_batch : 128;
     const int64_t growth_pct = getenv("PNR_BATCH_GROWTH") ? std::max(100, atoi(getenv("PNR_BATCH_GROWTH"))) : 200;
-    // Two batches in flight on two streams: while batch b runs, batch b+1 (launched against the map of
-    // batches < b) already occupies the CUs that b leaves idle in its tail; each batch is replayed in rank
-    // order as soon as it completes and its voxels are pushed to the map that later launches read.
-    for (int k = 0; k < 2; k++)
+    // A ring of `depth` batches in flight, each on its own stream.  depth 1: strictly sequential batches (the
+    // freshest map, fewest wasted iterations, but every batch waits for its 200-iteration stragglers while
+    // most CUs idle).  depth > 1: later batches already occupy the CUs that earlier ones leave idle; batches are
+    // collected and replayed strictly in rank order, and each launch sees the map of everything replayed so far.
+    const int max_depth = (int)(sizeof(c->jobs) / sizeof(c->jobs[0])) - 1;
+    const char *dep = getenv("PNR_TRACE_DEPTH");
+    int depth = dep ? atoi(dep) : 1;
+    depth = depth < 1 ? 1 : (depth > max_depth ? max_depth : depth);
+    const int64_t batch_max = getenv("PNR_BATCH_MAX") ? std::max(1, atoi(getenv("PNR_BATCH_MAX"))) : 1024;
+    for (int k = 0; k < depth; k++)
         if (!c->jobs[k]) {
             c->jobs[k] = pnr_job_create(c, true);
             PNR_REQUIRE(c->jobs[k], PNR_E_HIP, "could not create a trace stream");
@@ -407,19 +413,20 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
         std::vector<int32_t> T, stop;
         std::vector<pnr_xest> xc;
         bool live = false;
-    } slots[2];
+    };
+    std::vector<Slot> slots((size_t)depth);
     int64_t next = 0; // first seed not yet assigned to a batch
     auto launch = [&](int k) -> int {
-        Slot &sl = slots[k];
+        Slot &sl = slots[(size_t)k];
         sl.live = false;
         if (next >= n || r.stopped) return PNR_OK;
-        const int64_t i1 = std::min(n, next + batch);
+        const int64_t i1 = std::min(n, next + std::min(batch, batch_max));
         sl.bs.clear();
         // seeds already on a saturated voxel are skipped by the replay whatever their traces are: not launched
         for (int64_t i = next; i < i1; i++)
             if (!r.seed_saturated(seeds[i])) sl.bs.push_back(seeds[i]);
         next = i1;
-        if (batch < 1024) batch = std::max<int64_t>(batch + 1, batch * growth_pct / 100);
+        if (batch < batch_max) batch = std::max<int64_t>(batch + 1, batch * growth_pct / 100);
         const int64_t m = (int64_t)sl.bs.size();
         sl.T.assign((size_t)(2 * m), 0);
         sl.stop.assign((size_t)(2 * m), 0);
@@ -427,15 +434,10 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
         sl.live = true;
         return pnr_job_launch(c, c->jobs[k], sl.bs.data(), m, 0, false, false, false, /*use_density*/ 1);
     };
-    // depth 1 (default): strictly sequential batches -- fewest wasted iterations; depth 2 (PNR_TRACE_DEPTH=2)
-    // overlaps a batch with the tail of its predecessor at the price of a map that is one batch staler
-    const char *dep = getenv("PNR_TRACE_DEPTH");
-    const int depth = (dep && dep[0] == '2') ? 2 : 1;
-    rc = launch(0);
-    if (!rc && depth == 2) rc = launch(1);
+    for (int k = 0; k < depth && !rc; k++) rc = launch(k);
     if (rc) return rc;
-    for (int k = 0; slots[k].live; k = (depth == 2) ? (k ^ 1) : 0) {
-        Slot &sl = slots[k];
+    for (int k = 0; slots[(size_t)k].live; k = (k + 1) % depth) { // slot k always holds the oldest batch in flight
+        Slot &sl = slots[(size_t)k];
         const int64_t m = (int64_t)sl.bs.size();
         rc = pnr_job_finish(c, c->jobs[k], sl.T.data(), sl.stop.data(), sl.xc.data(), nullptr, nullptr, nullptr);
         if (rc) return rc;
@@ -450,14 +452,15 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
             fprintf(stderr, "[pnr trace] batch of %lld seeds launched: %lld iterations, longest trace %lld, nodes so far %zu\n", (long long)m,
                     (long long)bi, (long long)bmax, r.nodes.size());
         r.touched.clear();
-        r.add(sl.bs.data(), m, sl.T.data(), sl.xc.data()); // rank order: slot k always holds the older batch
+        r.add(sl.bs.data(), m, sl.T.data(), sl.xc.data());
         rc = pnr_density_update(c, r);
         if (rc) return rc;
         rc = launch(k);
         if (rc) return rc;
     }
-    for (int k = 0; k < 2; k++) // a batch may still be running when MAX_TRACE_COUNT ended the loop
-        if (slots[k].live) (void)pnr_job_finish(c, c->jobs[k], slots[k].T.data(), slots[k].stop.data(), slots[k].xc.data(), nullptr, nullptr, nullptr);
+    for (int k = 0; k < depth; k++) // batches may still be running when MAX_TRACE_COUNT ended the loop
+        if (slots[(size_t)k].live)
+            (void)pnr_job_finish(c, c->jobs[k], slots[(size_t)k].T.data(), slots[(size_t)k].stop.data(), slots[(size_t)k].xc.data(), nullptr, nullptr, nullptr);
     *n_nodes = (int64_t)r.nodes.size();
     *n_links = (int64_t)r.links.size() / 2;
     if (nodes) std::memcpy(nodes, r.nodes.data(), sizeof(pnr_node) * (size_t)std::min<int64_t>(cap_nodes, *n_nodes));

@@ -93,9 +93,13 @@ struct pnr_ctx {
     // node-density map of earlier trace batches (u8 per voxel), read by smc_trace for early DENSITY stops
     uint8_t *d_den = nullptr;
     int64_t den_cap = 0;
+    long long *d_den_idx = nullptr; // staging for the per-batch scatter of touched voxels
+    uint8_t *d_den_val = nullptr;
+    size_t den_stage_cap = 0;
 
-    // trace jobs: [0],[1] own streams (pipelined batches of pnr_trace_replay), [2] on the ctx stream
-    struct pnr_trace_job *jobs[3] = {nullptr, nullptr, nullptr};
+    // trace jobs: [0..PNR_MAX_DEPTH) own streams (ring of batches in pnr_trace_replay), the last one on the ctx stream
+    static constexpr int PNR_MAX_DEPTH = 16;
+    struct pnr_trace_job *jobs[PNR_MAX_DEPTH + 1] = {};
 
     // seeds
     unsigned char *h_j8 = nullptr; // pinned staging buffer for the J8 download

@@ -1154,11 +1154,12 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
                   float *xfilt, int32_t *idxres, float *neff, int use_density)
 {
     if (n == 0) return PNR_OK;
-    if (!c->jobs[2]) c->jobs[2] = pnr_job_create(c, false);
-    PNR_REQUIRE(c->jobs[2], PNR_E_HIP, "could not create a trace job");
-    int rc = pnr_job_launch(c, c->jobs[2], seeds, n, dbg_iters, xfilt != nullptr, idxres != nullptr, neff != nullptr, use_density);
+    pnr_trace_job *&sj = c->jobs[pnr_ctx::PNR_MAX_DEPTH];
+    if (!sj) sj = pnr_job_create(c, false);
+    PNR_REQUIRE(sj, PNR_E_HIP, "could not create a trace job");
+    int rc = pnr_job_launch(c, sj, seeds, n, dbg_iters, xfilt != nullptr, idxres != nullptr, neff != nullptr, use_density);
     if (rc) return rc;
-    return pnr_job_finish(c, c->jobs[2], T_out, stop_out, xc, xfilt, idxres, neff);
+    return pnr_job_finish(c, sj, T_out, stop_out, xc, xfilt, idxres, neff);
 }
 
 namespace {
@@ -1189,17 +1190,26 @@ int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r)
     if (n == 0) return PNR_OK;
     std::vector<unsigned char> val(n);
     for (size_t i = 0; i < n; i++) val[i] = (unsigned char)r.den_at(r.touched[i]); // final value: duplicates agree
-    i64 *d_idx = nullptr;
-    unsigned char *d_val = nullptr;
-    PNR_HIP(hipMalloc(&d_idx, n * 8));
-    PNR_HIP(hipMalloc(&d_val, n));
-    PNR_HIP(hipMemcpyAsync(d_idx, r.touched.data(), n * 8, hipMemcpyHostToDevice, c->stream));
-    PNR_HIP(hipMemcpyAsync(d_val, val.data(), n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(den_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_den, d_idx, d_val, (int)n);
+    // grow-only staging buffers: hipFree synchronises the whole device and would serialise the trace batches
+    // that are in flight on the other streams
+    if (c->den_stage_cap < n) {
+        PNR_HIP(hipDeviceSynchronize());
+        hipFree(c->d_den_idx);
+        hipFree(c->d_den_val);
+        c->d_den_idx = nullptr;
+        c->d_den_val = nullptr;
+        c->den_stage_cap = 0;
+        const size_t cap = std::max<size_t>(2 * n, 1 << 16);
+        PNR_HIP(hipMalloc(&c->d_den_idx, cap * 8));
+        PNR_HIP(hipMalloc(&c->d_den_val, cap));
+        c->den_stage_cap = cap;
+    }
+    PNR_HIP(hipMemcpyAsync(c->d_den_idx, r.touched.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+    PNR_HIP(hipMemcpyAsync(c->d_den_val, val.data(), n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(den_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_den, (const i64 *)c->d_den_idx,
+                       (const unsigned char *)c->d_den_val, (int)n);
     PNR_HIP(hipGetLastError());
     PNR_HIP(hipStreamSynchronize(c->stream));
-    hipFree(d_idx);
-    hipFree(d_val);
     return PNR_OK;
 }
 
