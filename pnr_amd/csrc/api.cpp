@@ -453,7 +453,7 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
                     (long long)bi, (long long)bmax, r.nodes.size());
         r.touched.clear();
         r.add(sl.bs.data(), m, sl.T.data(), sl.xc.data());
-        rc = pnr_density_update(c, r);
+        rc = pnr_density_update(c, r, c->jobs[k]);
         if (rc) return rc;
         rc = launch(k);
         if (rc) return rc;

@@ -177,6 +177,6 @@ int pnr_job_launch(pnr_ctx *c, pnr_trace_job *j, const pnr_seed *seeds, int64_t 
                    bool want_neff, int use_density);
 int pnr_job_finish(pnr_ctx *c, pnr_trace_job *j, int32_t *T, int32_t *stop, pnr_xest *xc, float *xfilt, int32_t *idxres, float *neff);
 int pnr_density_reset(pnr_ctx *c);                       // zero the device density map (allocating it on first use)
-int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r); // push the voxels touched by the last replay batch
+int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, struct pnr_trace_job *on); // push the voxels touched by the last replay batch
 int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y);
 int pnr_ensure_frangi_buffers(pnr_ctx *c);

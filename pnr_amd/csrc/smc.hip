@@ -1184,8 +1184,11 @@ int pnr_density_reset(pnr_ctx *c)
     return PNR_OK;
 }
 
-int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r)
+int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, pnr_trace_job *on)
 {
+    // runs on the stream of the batch that has just been collected: an extra stream could land on a hardware queue
+    // shared with a batch that is still running (ROCm multiplexes streams onto 4 queues) and wait behind it
+    hipStream_t st = on ? on->stream : c->stream;
     const size_t n = r.touched.size();
     if (n == 0) return PNR_OK;
     std::vector<unsigned char> val(n);
@@ -1204,12 +1207,12 @@ int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r)
         PNR_HIP(hipMalloc(&c->d_den_val, cap));
         c->den_stage_cap = cap;
     }
-    PNR_HIP(hipMemcpyAsync(c->d_den_idx, r.touched.data(), n * 8, hipMemcpyHostToDevice, c->stream));
-    PNR_HIP(hipMemcpyAsync(c->d_den_val, val.data(), n, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(den_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_den, (const i64 *)c->d_den_idx,
+    PNR_HIP(hipMemcpyAsync(c->d_den_idx, r.touched.data(), n * 8, hipMemcpyHostToDevice, st));
+    PNR_HIP(hipMemcpyAsync(c->d_den_val, val.data(), n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(den_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->d_den, (const i64 *)c->d_den_idx,
                        (const unsigned char *)c->d_den_val, (int)n);
     PNR_HIP(hipGetLastError());
-    PNR_HIP(hipStreamSynchronize(c->stream));
+    PNR_HIP(hipStreamSynchronize(st));
     return PNR_OK;
 }
 
