@@ -166,8 +166,13 @@ int pnr_reconstruct(const pnr_node *nodes, int64_t n_nodes, const int32_t *links
  * 4-byte words into out; *n receives the element count. */
 int pnr_get_table(pnr_ctx *ctx, const char *name, void *out, int64_t cap, int64_t *n);
 
+/* How pnr_trace_batch / pnr_trace_replay schedule the particle filter on the GPU (results are bit-identical):
+ * 0 = one launch per SMC phase over all active traces of a batch (default), 1 = one persistent work-group per trace.
+ * The environment variable PNR_SMC_DRIVER=phased|persistent sets the initial choice of a new context. */
+int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
+
 /* Per-kernel-group device time (HIP events on the ctx stream) accumulated since the last reset:
- * groups: "gauss","hessian_eigen","j8","seed_maxima","zncc","smc".  Enabled by set_profiling. */
+ * groups: "gauss","hessian_eigen","j8","seed_maxima","zncc","smc" (sampling kernel),"smc_sums".  Enabled by set_profiling. */
 int pnr_set_profiling(pnr_ctx *ctx, int enable);
 int pnr_get_kernel_ms(pnr_ctx *ctx, const char *group, double *ms, int64_t *launches);
 int pnr_reset_kernel_ms(pnr_ctx *ctx);

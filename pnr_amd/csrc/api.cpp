@@ -116,6 +116,7 @@ int pnr_create(const pnr_params *p, int device, pnr_ctx **out)
         return PNR_E_HIP;
     }
     c->stream = c->own_stream;
+    if (const char *e = getenv("PNR_SMC_DRIVER")) c->smc_driver = (strcmp(e, "persistent") == 0) ? 1 : 0;
     (void)hipEventCreate(&c->ev0);
     (void)hipEventCreate(&c->ev1);
     pnr::build_tables(c->prm, c->tab);
@@ -154,6 +155,7 @@ void pnr_destroy(pnr_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto *j : c->jobs) pnr_job_destroy(j);
+    pnr_phased_destroy(c->phased);
     if (c->h_j8) hipHostFree(c->h_j8);
     hipFree(c->d_img_owned); hipFree(c->d_stash); hipFree(c->d_slot_busy); hipFree(c->d_den); hipFree(c->d_den_idx); hipFree(c->d_den_val);
     hipFree(c->d_tmpA); hipFree(c->d_tmpB); hipFree(c->d_J);
@@ -530,6 +532,14 @@ int pnr_get_table(pnr_ctx *c, const char *name, void *out, int64_t cap, int64_t 
     }
     *n = (int64_t)cnt;
     if (out && cap > 0) std::memcpy(out, src, std::min<size_t>(cnt, (size_t)cap) * 4);
+    return PNR_OK;
+}
+
+int pnr_set_smc_driver(pnr_ctx *c, int driver)
+{
+    PNR_REQUIRE(c, PNR_E_ARG, "null ctx");
+    PNR_REQUIRE(driver == 0 || driver == 1, PNR_E_ARG, "smc driver must be 0 (phased) or 1 (persistent), got %d", driver);
+    c->smc_driver = driver;
     return PNR_OK;
 }
 

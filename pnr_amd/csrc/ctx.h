@@ -100,6 +100,8 @@ struct pnr_ctx {
     // trace jobs: [0..PNR_MAX_DEPTH) own streams (ring of batches in pnr_trace_replay), the last one on the ctx stream
     static constexpr int PNR_MAX_DEPTH = 16;
     struct pnr_trace_job *jobs[PNR_MAX_DEPTH + 1] = {};
+    struct pnr_phased *phased = nullptr; // state of the launch-per-phase SMC driver (smc_phased.hip)
+    int smc_driver = 0;                  // 0: launch per phase (default), 1: one persistent work-group per trace
 
     // seeds
     unsigned char *h_j8 = nullptr; // pinned staging buffer for the J8 download
@@ -176,6 +178,10 @@ void pnr_job_destroy(pnr_trace_job *j);
 int pnr_job_launch(pnr_ctx *c, pnr_trace_job *j, const pnr_seed *seeds, int64_t n, int dbg_iters, bool want_xfilt, bool want_idxres,
                    bool want_neff, int use_density);
 int pnr_job_finish(pnr_ctx *c, pnr_trace_job *j, int32_t *T, int32_t *stop, pnr_xest *xc, float *xfilt, int32_t *idxres, float *neff);
+struct pnr_phased;
+int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T, int32_t *stop, pnr_xest *xc, int dbg_iters,
+                         float *xfilt, int32_t *idxres, float *neff, int use_density);
+void pnr_phased_destroy(pnr_phased *h);
 int pnr_density_reset(pnr_ctx *c);                       // zero the device density map (allocating it on first use)
 int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, struct pnr_trace_job *on); // push the voxels touched by the last replay batch
 int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y);

@@ -1,0 +1,542 @@
+// smc_phased.hip -- the SMC particle filter with ONE LAUNCH PER PHASE, so that a trace is not tied to one CU.
+//
+// smc.hip runs a trace as one persistent work-group: simple, but a batch then lasts as long as its longest trace
+// (200 iterations x ~2.2 ms) while the CUs of finished traces idle, and batches must stay small for the early
+// DENSITY stops to bite.  Here every SMC iteration of a batch is four launches over all still-active traces:
+//
+//   ph_predict  1 WG / trace      P1: parents -> particles, priors, cube origin            (tracker.cpp:1104-1132)
+//   ph_sample   nsplit WG / trace phase A: cube -> LDS, (sigma, group, v-slice) items -> HBM stash  (:1929-1938)
+//   ph_sums     3+ WG / trace     phase B: ordered mean / corra / corrb per chain            (:1940-1955)
+//   ph_update   1 WG / trace      pending centroid + stop tests, weights, N_eff, CDF, centroid, resampling
+//                                                                                            (:1035-1090, :1140-1195)
+// The host picks nsplit from the number of active traces (about two sampling work-groups per CU), so the last
+// stragglers of a batch are sampled by dozens of CUs each instead of one.  Particle state lives in HBM between
+// launches (14 KB per trace).  Every device function is shared with smc.hip (smc_device.h): same operations, same
+// order, bit-identical traces (tests run both drivers against the oracle and against each other).
+#include "ctx.h"
+#include "replay.h"
+#include "smc_device.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_N = 16 };
+
+struct PhState {
+    float *part;   // [NT][2][np][9]
+    float *prior;  // [NT][np]
+    int *idxres;   // [NT][np]
+    float *corr;   // [NT][S][np_pad]
+    float *xcs;    // [NT][2][8]
+    int *flags;    // [NT][FL_N]
+    float *stash;  // [NT][S*ngroups][Mmax*64]
+    long long trace_floats, wave_floats;
+    int *n_done;   // device counter of finished traces
+};
+
+__global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, const float *__restrict__ seeds6, Vol V, int np, int ni, int it,
+                                                   int CS)
+{
+    const int tr = blockIdx.x, tid = threadIdx.x, B = blockDim.x;
+    int *fl = P.flags + (i64)tr * FL_N;
+    if (fl[FL_DONE]) return;
+    __shared__ int sbox[8];
+    const bool tail = (it == ni) || (fl[FL_STOP] != 0);
+    const int pending = it - 1; // the previous iteration's centroid is evaluated with this iteration's chains
+    float *part = P.part + (i64)tr * 2 * np * PSTRIDE;
+    float *cur = part + (it & 1) * np * PSTRIDE;
+    const float *prv = part + ((it & 1) ^ 1) * np * PSTRIDE;
+    const float *xc_pen = P.xcs + (i64)tr * 16 + ((it & 1) ^ 1) * 8;
+    float *prior = P.prior + (i64)tr * np;
+    const int *idxres = P.idxres + (i64)tr * np;
+    const int resampled_prev = fl[FL_RES];
+    const float *sd = seeds6 + (i64)tr * 6;
+    const float x0 = sd[0], y0 = sd[1], z0 = sd[2], vx0 = sd[3], vy0 = sd[4], vz0 = sd[5];
+    if (tid < 3) { sbox[tid] = 0x7fffffff; sbox[3 + tid] = -0x7fffffff; }
+    __syncthreads();
+    for (int k = tid; k <= np; k += B) {
+        float qx, qy, qz, qvx, qvy, qvz;
+        if (k == np) {
+            if (pending < 0) continue;
+            qx = xc_pen[0]; qy = xc_pen[1]; qz = xc_pen[2]; qvx = xc_pen[3]; qvy = xc_pen[4]; qvz = xc_pen[5];
+        } else {
+            if (tail) continue;
+            float *q = cur + k * PSTRIDE;
+            if (it == 0) { // iter0New: systematic sample of the isotropic prior (tracker.cpp:1006-1024)
+                const float stepw = T.w0cws[T.sz - 1] / np;
+                const float u1 = stepw * ((float)T.rng[0] / (float)2147483647);
+                const float ui = u1 + k * stepw;
+                const int s = cdf_search(T.w0cws, T.sz, ui);
+                q[PX] = x0 + T.p[3 * s + 0];
+                q[PY] = y0 + T.p[3 * s + 1];
+                q[PZ] = z0 + T.p[3 * s + 2];
+                q[PVX] = (vx0 != vx0) ? T.u[3 * s + 0] : vx0;
+                q[PVY] = (vy0 != vy0) ? T.u[3 * s + 1] : vy0;
+                q[PVZ] = (vz0 != vz0) ? T.u[3 * s + 2] : vz0;
+                prior[k] = T.w0[s];
+            } else { // iterINew (:1104-1132)
+                const int k1 = resampled_prev ? idxres[k] : k;
+                const float *par = prv + k1 * PSTRIDE;
+                int vi = -1;
+                float best = -FLT_MAX;
+                for (int a = 0; a < T.ndir; a++) {
+                    const float dp = par[PVX] * T.v[3 * a] + par[PVY] * T.v[3 * a + 1] + par[PVZ] * T.v[3 * a + 2];
+                    if (dp > best) { best = dp; vi = a; }
+                }
+                if (vi < 0) vi = 0;
+                const float *cws = T.wcws + (i64)vi * T.sz;
+                const float u1 = cws[T.sz - 1] * ((float)T.rng[k] / (float)2147483647);
+                const int s = cdf_search(cws, T.sz, u1);
+                q[PX] = par[PX] + T.p[3 * s + 0];
+                q[PY] = par[PY] + T.p[3 * s + 1];
+                q[PZ] = par[PZ] + T.p[3 * s + 2];
+                q[PVX] = T.u[3 * s + 0];
+                q[PVY] = T.u[3 * s + 1];
+                q[PVZ] = T.u[3 * s + 2];
+                prior[k] = T.w[(i64)vi * T.sz + s];
+            }
+            qx = q[PX]; qy = q[PY]; qz = q[PZ]; qvx = q[PVX]; qvy = q[PVY]; qvz = q[PVZ];
+        }
+        const Frame f = make_frame(qx, qy, qz, qvx, qvy, qvz);
+        const float ex = X.ext_v * fabsf(qvx) + X.ext_uw * (fabsf(f.ux) + fabsf(f.wx)) + 1.5f;
+        const float ey = X.ext_v * fabsf(qvy) + X.ext_uw * (fabsf(f.uy) + fabsf(f.wy)) + 1.5f;
+        const float ez = X.ext_v * fabsf(qvz) + X.ext_uw * (fabsf(f.uz) + fabsf(f.wz)) + 1.5f;
+        if (qx == qx && qy == qy && qz == qz && ex == ex && ey == ey && ez == ez) {
+            const float big = 1e6f;
+            atomicMin(&sbox[0], (int)floorf(fmaxf(qx - ex, -big)));
+            atomicMin(&sbox[1], (int)floorf(fmaxf(qy - ey, -big)));
+            atomicMin(&sbox[2], (int)floorf(fmaxf(qz - ez, -big)));
+            atomicMax(&sbox[3], (int)floorf(fminf(qx + ex, big)) + 2);
+            atomicMax(&sbox[4], (int)floorf(fminf(qy + ey, big)) + 2);
+            atomicMax(&sbox[5], (int)floorf(fminf(qz + ez, big)) + 2);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { // cube origin: centred on the bounding box of all templates, kept inside the volume
+        const int dim[3] = {V.w, V.h, V.l};
+        for (int a = 0; a < 3; a++) {
+            const int lo = sbox[a] < 0 ? 0 : (sbox[a] > dim[a] - 1 ? dim[a] - 1 : sbox[a]);
+            const int hi = sbox[3 + a] > dim[a] - 1 ? dim[a] - 1 : (sbox[3 + a] < lo ? lo : sbox[3 + a]);
+            int o = (lo + hi + 1) / 2 - CS / 2;
+            if (o > dim[a] - CS) o = dim[a] - CS;
+            if (o < 0) o = 0;
+            fl[FL_OX + a] = o;
+        }
+    }
+}
+
+template <int CS>
+__global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int np_pad, int ni, int it, int nsplit)
+{
+    extern __shared__ unsigned char cube[];
+    const int tr = blockIdx.x / nsplit, part_id = blockIdx.x - tr * nsplit, tid = threadIdx.x, B = blockDim.x, S = T.nsig;
+    const int *fl = P.flags + (i64)tr * FL_N;
+    if (fl[FL_DONE]) return;
+    const bool tail = (it == ni) || (fl[FL_STOP] != 0);
+    const int pending = it - 1;
+    const float *cur = P.part + (i64)tr * 2 * np * PSTRIDE + (it & 1) * np * PSTRIDE;
+    const float *xc_pen = P.xcs + (i64)tr * 16 + ((it & 1) ^ 1) * 8;
+    Box Bx;
+    Bx.lds = (lds_cu8 *)cube;
+    Bx.ox = fl[FL_OX]; Bx.oy = fl[FL_OY]; Bx.oz = fl[FL_OZ];
+    { // stage the cube: one wave per (z,y) row, lanes along x (coalesced bytes), 4 rows in flight
+        const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6;
+        const int xg = Bx.ox + lane < V.w ? Bx.ox + lane : V.w - 1;
+        for (int r0 = wv; r0 < CS * CS; r0 += 4 * nwv) {
+            unsigned char v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = r0 + j * nwv < CS * CS ? r0 + j * nwv : CS * CS - 1;
+                const int zz = r / CS, yy = r - zz * CS;
+                const int zg = Bx.oz + zz < V.l ? Bx.oz + zz : V.l - 1, yg = Bx.oy + yy < V.h ? Bx.oy + yy : V.h - 1;
+                v[j] = V.img[(i64)zg * V.wh + (i64)yg * V.w + xg];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (r0 + j * nwv < CS * CS && lane < CS) cube[(r0 + j * nwv) * CS + lane] = v[j];
+        }
+    }
+    __syncthreads();
+    const int ngroups = np_pad >> 6;
+    int nitems = 0;
+    for (int s = 0; s < S; s++) nitems += __builtin_amdgcn_readfirstlane(X.grid[s].nv) * ngroups;
+    float *const tbase = P.stash + (i64)tr * P.trace_floats;
+    const int nwv = B >> 6;
+    // items (sigma descending, v-slice, group) dealt round-robin over the nsplit work-groups x waves of this trace
+    for (int item = part_id * nwv + (tid >> 6); item < nitems; item += nsplit * nwv) {
+        int sI = S - 1, rem = item;
+        while (sI >= 0) {
+            const int cnt = __builtin_amdgcn_readfirstlane(X.grid[sI].nv) * ngroups;
+            if (rem < cnt) break;
+            rem -= cnt;
+            sI--;
+        }
+        const int iv = rem / ngroups, g = rem - iv * ngroups;
+        const int k = g * 64 + (tid & 63);
+        const bool is_cen = (k == np) && (pending >= 0);
+        const bool valid = (k < np && !tail) || is_cen;
+        if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+        const float *q = is_cen ? xc_pen : (valid ? cur + k * PSTRIDE : (tail ? xc_pen : cur));
+        const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
+        const Grid gr = X.grid[sI];
+        const int nv = __builtin_amdgcn_readfirstlane(gr.nv), nu = __builtin_amdgcn_readfirstlane(gr.nu);
+        const int nw = __builtin_amdgcn_readfirstlane(gr.nw);
+        const float *ax = X.axes + __builtin_amdgcn_readfirstlane(X.axes_off[sI]);
+        sample_slice<CS>(V, Bx, f, nv, nu, nw, ax, iv, tbase + (i64)(sI * ngroups + g) * P.wave_floats + (tid & 63));
+    }
+}
+
+__global__ __launch_bounds__(256) void ph_sums(Tab T, TabX X, PhState P, int np, int np_pad, int ni, int it, int blocks_per_trace)
+{
+    const int tr = blockIdx.x / blocks_per_trace, S = T.nsig;
+    const int *fl = P.flags + (i64)tr * FL_N;
+    if (fl[FL_DONE]) return;
+    const int c = (blockIdx.x - tr * blocks_per_trace) * 256 + threadIdx.x;
+    if (c >= S * np_pad) return; // whole waves: np_pad is a multiple of 64
+    const bool tail = (it == ni) || (fl[FL_STOP] != 0);
+    const int pending = it - 1;
+    const int sI = __builtin_amdgcn_readfirstlane(c / np_pad);
+    const int k = c - sI * np_pad;
+    const bool is_cen = (k == np) && (pending >= 0);
+    const bool valid = (k < np && !tail) || is_cen;
+    if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
+    const int ngroups = np_pad >> 6;
+    const Grid gr = X.grid[sI];
+    const int M = __builtin_amdgcn_readfirstlane(gr.nv) * __builtin_amdgcn_readfirstlane(gr.nu) * __builtin_amdgcn_readfirstlane(gr.nw);
+    const int goff = __builtin_amdgcn_readfirstlane(gr.off);
+    const float *col = P.stash + (i64)tr * P.trace_floats + (i64)(sI * ngroups + (k >> 6)) * P.wave_floats + (k & 63);
+    const float cv = zncc_from_stash(col, M, X.wd + goff, T.corrc[sI]);
+    if (valid) P.corr[((i64)tr * S + sI) * np_pad + k] = cv;
+}
+
+__global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np, int np_pad, int ni, int it, float Kc, float znccth,
+                                                  float neff_ratio, const unsigned char *__restrict__ den, int nodepervol, TraceOut O)
+{
+    extern __shared__ float lds[];
+    const int tr = blockIdx.x, tid = threadIdx.x, B = blockDim.x, S = T.nsig;
+    int *fl = P.flags + (i64)tr * FL_N;
+    if (fl[FL_DONE]) return;
+    float *cur = lds;                 // [np][9]
+    float *prvw = cur + np * PSTRIDE; // [np] weights of the previous iteration
+    float *prior = prvw + np;         // [np]
+    float *lhood = prior + np;        // [np]
+    float *csw = lhood + np;          // [np]
+    float *corr_ks = csw + np;        // [S][np_pad]
+    float *sneff = corr_ks + S * np_pad; // [2]
+    int *sres = (int *)(sneff + 2);   // [0] resample, [1] stop code after the pending centroid
+    float *sxc = (float *)(sres + 2); // [8] centroid of this iteration
+    const bool tail = (it == ni) || (fl[FL_STOP] != 0);
+    const int pending = it - 1;
+    const int resampled_prev = fl[FL_RES];
+    float *gpart = P.part + (i64)tr * 2 * np * PSTRIDE;
+    float *gcur = gpart + (it & 1) * np * PSTRIDE;
+    const float *gprv = gpart + ((it & 1) ^ 1) * np * PSTRIDE;
+    float *xc_cur = P.xcs + (i64)tr * 16 + (it & 1) * 8;
+    const float *xc_pen = P.xcs + (i64)tr * 16 + ((it & 1) ^ 1) * 8;
+    int *gidx = P.idxres + (i64)tr * np;
+    for (int e = tid; e < S * np_pad; e += B) corr_ks[e] = P.corr[(i64)tr * S * np_pad + e];
+    if (!tail) {
+        for (int e = tid; e < np * PSTRIDE; e += B) cur[e] = gcur[e];
+        for (int k = tid; k < np; k += B) { prvw[k] = gprv[k * PSTRIDE + PW]; prior[k] = P.prior[(i64)tr * np + k]; }
+    }
+    __syncthreads();
+
+    // ---- finish the pending centroid: corr, stop tests of that iteration (tracker.cpp:1072-1079) ----
+    if (pending >= 0 && tid == 0) {
+        float best = -FLT_MAX, bs = xc_pen[6];
+        for (int s = 0; s < S; s++) {
+            const float cv = corr_ks[s * np_pad + np];
+            if (cv > best) { best = cv; bs = T.sig[s]; }
+        }
+        float *xo = O.xc + ((i64)tr * ni + pending) * 8;
+        xo[0] = xc_pen[0]; xo[1] = xc_pen[1]; xo[2] = xc_pen[2]; xo[3] = xc_pen[3]; xo[4] = xc_pen[4]; xo[5] = xc_pen[5];
+        xo[6] = bs; xo[7] = best;
+        if ((fl[FL_STOP] == 0 || fl[FL_STOP] == 3) && best < znccth) { fl[FL_STOP] = 2; fl[FL_T] = pending; }
+    }
+    if (tid == 0) sres[1] = fl[FL_STOP];
+    __syncthreads();
+    if (tail || sres[1] != 0) {
+        if (tid == 0) {
+            O.T[tr] = fl[FL_T];
+            O.stop[tr] = fl[FL_STOP];
+            fl[FL_DONE] = 1;
+            atomicAdd(P.n_done, 1);
+        }
+        return;
+    }
+
+    // ---- max over sigma, likelihood exp(Kc*corr) (:1028-1029) ----
+    for (int k = tid; k < np; k += B) {
+        float best = -FLT_MAX, bs = 0.f;
+        for (int s = 0; s < S; s++) {
+            const float cv = corr_ks[s * np_pad + k];
+            if (cv > best) { best = cv; bs = T.sig[s]; }
+        }
+        cur[k * PSTRIDE + PCORR] = best;
+        cur[k * PSTRIDE + PSIG] = bs;
+        lhood[k] = expf_libm(Kc * best);
+    }
+    __syncthreads();
+
+    // ---- weights, N_eff, CDF, centroid: sequential sums in particle order (:1035-1071) ----
+    const bool carry = (it > 0) && !resampled_prev;
+    if (tid == 0) {
+        float a = 0.f;
+        for (int k = 0; k < np; k++) a += prior[k];
+        sneff[1] = a;
+    }
+    __syncthreads();
+    {
+        const float wnorm_prior = sneff[1];
+        for (int k = tid; k < np; k += B) {
+            const double base = carry ? (double)prvw[k] : (1.0 / np);
+            cur[k * PSTRIDE + PW] = (float)(base * (double)(prior[k] / wnorm_prior) * (double)lhood[k]);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float a = 0.f;
+        for (int k = 0; k < np; k++) a += cur[k * PSTRIDE + PW];
+        sneff[1] = a;
+    }
+    __syncthreads();
+    {
+        const float wsum = sneff[1];
+        for (int k = tid; k < np; k += B) cur[k * PSTRIDE + PW] = cur[k * PSTRIDE + PW] / wsum;
+    }
+    __syncthreads();
+    if (tid < 7) {
+        const int comp = (tid < 6) ? tid : PSIG;
+        float a = 0.f;
+        for (int k = 0; k < np; k++) a += cur[k * PSTRIDE + PW] * cur[k * PSTRIDE + comp];
+        sxc[tid] = a;
+    } else if (tid == 7) {
+        float neff = 0.f;
+        for (int k = 0; k < np; k++) {
+            const float wk = cur[k * PSTRIDE + PW];
+            neff = (float)((double)neff + (double)wk * (double)wk);
+        }
+        sneff[0] = (float)(1.0 / (double)neff);
+    } else if (tid == 8) {
+        float acc = 0.f;
+        for (int k = 0; k < np; k++) {
+            acc = cur[k * PSTRIDE + PW] + ((k > 0) ? acc : 0.f);
+            csw[k] = acc;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float cx = sxc[0], cy = sxc[1], cz = sxc[2], cvx = sxc[3], cvy = sxc[4], cvz = sxc[5];
+        const float neff = sneff[0];
+        const float vnorm = (float)sqrt((double)cvx * (double)cvx + (double)cvy * (double)cvy + (double)cvz * (double)cvz);
+        sxc[3] = cvx / vnorm; sxc[4] = cvy / vnorm; sxc[5] = cvz / vnorm;
+        if (it < O.dbg_iters && O.neff) O.neff[(i64)tr * O.dbg_iters + it] = neff;
+        const int x1 = (int)roundf(cx), y1 = (int)roundf(cy), z1 = (int)roundf(cz);
+        int res = 0;
+        if (x1 < 0 || x1 >= V.w || y1 < 0 || y1 >= V.h || z1 < 0 || z1 >= V.l) {
+            fl[FL_STOP] = 1;
+            fl[FL_T] = it;
+        } else if (den && (int)den[(i64)z1 * V.wh + (i64)y1 * V.w + x1] >= nodepervol) {
+            fl[FL_STOP] = 3; // saturated by earlier batches: DENSITY stop at the latest here (tracker.cpp:855)
+            fl[FL_T] = it + 1;
+        } else if (neff / np < neff_ratio) {
+            res = 1;
+        }
+        fl[FL_RES] = res;
+        sres[0] = res;
+    }
+    __syncthreads();
+    if (tid < 7) xc_cur[tid] = sxc[tid];
+    if (sres[0]) { // systematic resampling by bisection on the monotone CDF (clamped; :1082-1090)
+        const float u1 = (float)((1.0 / np) * (double)((float)T.rng[(it == 0) ? 1 : np] / (float)2147483647));
+        for (int k = tid; k < np; k += B) {
+            const float ui = (float)((double)u1 + k * (1.0 / np));
+            int lo = 0, hi = np - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (ui > csw[mid]) lo = mid + 1; else hi = mid;
+            }
+            gidx[k] = lo;
+            if (it < O.dbg_iters && O.idxres) O.idxres[((i64)tr * O.dbg_iters + it) * np + k] = lo;
+        }
+    }
+    for (int e = tid; e < np * PSTRIDE; e += B) gcur[e] = cur[e];
+    if (it < O.dbg_iters && O.xfilt) {
+        float *dst = O.xfilt + ((i64)tr * O.dbg_iters + it) * np * PSTRIDE;
+        for (int e = tid; e < np * PSTRIDE; e += B) dst[e] = cur[e];
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// host driver: one wave of at most PH_MAX_TRACES traces at a time
+// ---------------------------------------------------------------------------------------------------------
+struct pnr_phased {
+    int64_t cap_traces = 0, cap_dbg = 0;
+    int np = 0, np_pad = 0, S = 0, ni = 0;
+    PhState P{};
+    float *d_s6 = nullptr;
+    TraceOut O{};
+};
+
+static void phased_free(pnr_phased *h)
+{
+    hipFree(h->P.part); hipFree(h->P.prior); hipFree(h->P.idxres); hipFree(h->P.corr); hipFree(h->P.xcs); hipFree(h->P.flags);
+    hipFree(h->P.stash); hipFree(h->P.n_done); hipFree(h->d_s6);
+    hipFree(h->O.T); hipFree(h->O.stop); hipFree(h->O.xc); hipFree(h->O.xfilt); hipFree(h->O.idxres); hipFree(h->O.neff);
+    h->P = PhState{};
+    h->O = TraceOut{};
+    h->d_s6 = nullptr;
+    h->cap_traces = h->cap_dbg = 0;
+}
+
+void pnr_phased_destroy(pnr_phased *h)
+{
+    if (!h) return;
+    phased_free(h);
+    delete h;
+}
+
+static const int PH_MAX_TRACES = 512; // 8.9 GB of stash at np = 200, 3 scales
+
+int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, int32_t *stop_out, pnr_xest *xc, int dbg_iters,
+                         float *xfilt, int32_t *idxres, float *neff, int use_density)
+{
+    if (n == 0) return PNR_OK;
+    Vol V;
+    int rc = make_vol(c, V);
+    if (rc) return rc;
+    Tab T;
+    make_tab(c, T);
+    const int np = c->prm.np, ni = c->prm.ni, S = T.nsig;
+    const int np_pad = (np + 1 + 63) / 64 * 64;
+    if (dbg_iters > ni) dbg_iters = ni;
+    if (dbg_iters < 0) dbg_iters = 0;
+    static const int cube_sides[] = {52, 48, 44, 40, 36, 32};
+    // same cube side as the persistent driver picks for this np (identical fallbacks to HBM, identical numerics anyway)
+    const size_t fixed = trace_fixed_lds_bytes(np, np_pad, S);
+    int CS = 0;
+    for (int cs : cube_sides)
+        if (fixed + (size_t)cs * cs * cs + 64 <= 160 * 1024) { CS = cs; break; }
+    PNR_REQUIRE(CS > 0, PNR_E_ARG, "np=%d: no room for the image cube", np);
+    for (int s = 0; s < S; s++)
+        PNR_REQUIRE(c->tab.grid[4 * s] <= 64 && c->tab.grid[4 * s + 1] <= 64 && c->tab.grid[4 * s + 2] <= 64, PNR_E_ARG,
+                    "template grid axis longer than a wavefront");
+    if (!c->phased) c->phased = new pnr_phased();
+    pnr_phased *h = c->phased;
+    int Mmax = 0;
+    for (int s = 0; s < S; s++) Mmax = std::max(Mmax, c->tab.M[s]);
+    const long long wave_floats = (long long)Mmax * 64, trace_floats = wave_floats * S * (np_pad / 64);
+    const int64_t ntr_all = 2 * n;
+    const int64_t NT = std::min<int64_t>(ntr_all, PH_MAX_TRACES);
+    const int64_t need_dbg = NT * dbg_iters;
+    if (h->cap_traces < NT || h->np != np || h->np_pad != np_pad || h->S != S || h->ni != ni || h->cap_dbg < need_dbg ||
+        (xfilt && dbg_iters && !h->O.xfilt) || (idxres && dbg_iters && !h->O.idxres) || (neff && dbg_iters && !h->O.neff)) {
+        PNR_HIP(hipDeviceSynchronize());
+        phased_free(h);
+        const int64_t cap = std::max<int64_t>(NT, std::min<int64_t>(PH_MAX_TRACES, 256));
+        PNR_HIP(hipMalloc(&h->P.part, (size_t)cap * 2 * np * PSTRIDE * 4));
+        PNR_HIP(hipMalloc(&h->P.prior, (size_t)cap * np * 4));
+        PNR_HIP(hipMalloc(&h->P.idxres, (size_t)cap * np * 4));
+        PNR_HIP(hipMalloc(&h->P.corr, (size_t)cap * S * np_pad * 4));
+        PNR_HIP(hipMalloc(&h->P.xcs, (size_t)cap * 16 * 4));
+        PNR_HIP(hipMalloc(&h->P.flags, (size_t)cap * FL_N * 4));
+        PNR_HIP(hipMalloc(&h->P.stash, (size_t)cap * trace_floats * 4));
+        PNR_HIP(hipMalloc(&h->P.n_done, 4));
+        PNR_HIP(hipMalloc(&h->d_s6, (size_t)cap * 24));
+        PNR_HIP(hipMalloc(&h->O.T, (size_t)cap * 4));
+        PNR_HIP(hipMalloc(&h->O.stop, (size_t)cap * 4));
+        PNR_HIP(hipMalloc(&h->O.xc, (size_t)cap * ni * 32));
+        const size_t dbg_cap = (size_t)cap * dbg_iters;
+        if (dbg_iters && xfilt) PNR_HIP(hipMalloc(&h->O.xfilt, dbg_cap * np * PSTRIDE * 4));
+        if (dbg_iters && idxres) PNR_HIP(hipMalloc(&h->O.idxres, dbg_cap * np * 4));
+        if (dbg_iters && neff) PNR_HIP(hipMalloc(&h->O.neff, dbg_cap * 4));
+        h->cap_traces = cap; h->cap_dbg = (int64_t)dbg_cap;
+        h->np = np; h->np_pad = np_pad; h->S = S; h->ni = ni;
+    }
+    h->P.trace_floats = trace_floats;
+    h->P.wave_floats = wave_floats;
+    TabX X;
+    X.grid = (const Grid *)c->d_grid; X.axes = c->d_axes; X.axes_off = c->d_axes_off; X.wd = c->d_wd;
+    X.ext_v = c->tab.ext_v; X.ext_uw = c->tab.ext_uw;
+    X.stash = nullptr; X.slot_busy = nullptr; X.nslots = 0; X.slot_floats = 0; X.wave_floats = wave_floats;
+    hipDeviceProp_t prop;
+    PNR_HIP(hipGetDeviceProperties(&prop, c->device));
+    const int ncu = prop.multiProcessorCount;
+    hipStream_t st = c->stream;
+    const size_t cube_bytes = (size_t)CS * CS * CS;
+    const size_t upd_lds = ((size_t)np * PSTRIDE + 4 * (size_t)np + (size_t)S * np_pad + 2 + 2 + 8) * 4;
+    const int sum_blocks = (S * np_pad + 255) / 256;
+
+    std::vector<float> s6;
+    std::vector<int> flags;
+    for (int64_t t0 = 0; t0 < ntr_all; t0 += PH_MAX_TRACES) {
+        const int nt = (int)std::min<int64_t>(PH_MAX_TRACES, ntr_all - t0);
+        s6.resize((size_t)nt * 6);
+        for (int j = 0; j < nt; j++) {
+            const pnr_seed &sd = seeds[(t0 + j) / 2];
+            const float sgn = ((t0 + j) & 1) ? -1.f : 1.f; // odd trace: trackNeg (tracker.cpp:819-823)
+            float *a = &s6[(size_t)j * 6];
+            a[0] = sd.x; a[1] = sd.y; a[2] = sd.z;
+            a[3] = sgn < 0 ? -sd.vx : sd.vx; a[4] = sgn < 0 ? -sd.vy : sd.vy; a[5] = sgn < 0 ? -sd.vz : sd.vz;
+        }
+        flags.assign((size_t)nt * FL_N, 0);
+        for (int j = 0; j < nt; j++) flags[(size_t)j * FL_N + FL_T] = ni;
+        PNR_HIP(hipMemcpyAsync(h->d_s6, s6.data(), s6.size() * 4, hipMemcpyHostToDevice, st));
+        PNR_HIP(hipMemcpyAsync(h->P.flags, flags.data(), flags.size() * 4, hipMemcpyHostToDevice, st));
+        PNR_HIP(hipMemsetAsync(h->P.n_done, 0, 4, st));
+        PNR_HIP(hipMemsetAsync(h->O.xc, 0, (size_t)nt * ni * 32, st));
+        PNR_HIP(hipMemsetAsync(h->P.xcs, 0, (size_t)nt * 16 * 4, st));
+        TraceOut O = h->O;
+        O.dbg_iters = dbg_iters;
+        if (!xfilt || !dbg_iters) O.xfilt = nullptr;
+        if (!idxres || !dbg_iters) O.idxres = nullptr;
+        if (!neff || !dbg_iters) O.neff = nullptr;
+        if (O.idxres) PNR_HIP(hipMemsetAsync(O.idxres, 0xff, (size_t)nt * dbg_iters * np * 4, st));
+        PNR_HIP(hipStreamSynchronize(st)); // s6 / flags are pageable host vectors reused below
+        int active = nt, done = 0;
+        for (int it = 0; it <= ni && active > 0; it++) {
+            // about two sampling work-groups per CU: the fewer traces are left, the more CUs each one gets
+            int nsplit = (2 * ncu) / active;
+            nsplit = nsplit < 1 ? 1 : (nsplit > 12 ? 12 : nsplit);
+            hipLaunchKernelGGL(ph_predict, dim3(nt), dim3(256), 0, st, T, X, h->P, h->d_s6, V, np, ni, it, CS);
+            c->tic(st);
+#define PNR_LAUNCH_SAMPLE(cs)                                                                                                  \
+    case cs:                                                                                                                   \
+        if (it == 0 && t0 == 0) PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<cs>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cube_bytes)); \
+        hipLaunchKernelGGL(ph_sample<cs>, dim3((unsigned)(nt * nsplit)), dim3(768), cube_bytes, st, V, T, X, h->P, np, np_pad, ni, it, nsplit); \
+        break;
+            switch (CS) {
+                PNR_LAUNCH_SAMPLE(52)
+                PNR_LAUNCH_SAMPLE(48)
+                PNR_LAUNCH_SAMPLE(44)
+                PNR_LAUNCH_SAMPLE(40)
+                PNR_LAUNCH_SAMPLE(36)
+                PNR_LAUNCH_SAMPLE(32)
+            }
+#undef PNR_LAUNCH_SAMPLE
+            c->toc("smc", 1, st);
+            c->tic(st);
+            hipLaunchKernelGGL(ph_sums, dim3((unsigned)(nt * sum_blocks)), dim3(256), 0, st, T, X, h->P, np, np_pad, ni, it, sum_blocks);
+            c->toc("smc_sums", 1, st);
+            hipLaunchKernelGGL(ph_update, dim3(nt), dim3(256), upd_lds, st, V, T, h->P, np, np_pad, ni, it, c->prm.Kc, c->prm.znccth,
+                               c->prm.neff_ratio, use_density ? c->d_den : nullptr, c->prm.nodepervol, O);
+            if ((it & 3) == 3 || it == ni) { // refresh the active count (drives nsplit and the early exit)
+                PNR_HIP(hipMemcpyAsync(&done, h->P.n_done, 4, hipMemcpyDeviceToHost, st));
+                PNR_HIP(hipStreamSynchronize(st));
+                active = nt - done;
+            }
+        }
+        PNR_HIP(hipGetLastError());
+        PNR_HIP(hipMemcpyAsync(T_out + t0, h->O.T, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+        PNR_HIP(hipMemcpyAsync(stop_out + t0, h->O.stop, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+        PNR_HIP(hipMemcpyAsync(xc + t0 * ni, h->O.xc, (size_t)nt * ni * 32, hipMemcpyDeviceToHost, st));
+        if (O.xfilt) PNR_HIP(hipMemcpyAsync(xfilt + t0 * dbg_iters * np * PSTRIDE, O.xfilt, (size_t)nt * dbg_iters * np * PSTRIDE * 4, hipMemcpyDeviceToHost, st));
+        if (O.idxres) PNR_HIP(hipMemcpyAsync(idxres + t0 * dbg_iters * np, O.idxres, (size_t)nt * dbg_iters * np * 4, hipMemcpyDeviceToHost, st));
+        if (O.neff) PNR_HIP(hipMemcpyAsync(neff + t0 * dbg_iters, O.neff, (size_t)nt * dbg_iters * 4, hipMemcpyDeviceToHost, st));
+        PNR_HIP(hipStreamSynchronize(st));
+    }
+    return PNR_OK;
+}

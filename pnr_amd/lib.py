@@ -83,6 +83,7 @@ def load():
     L.pnr_reconstruct.argtypes = [vp, i64, vp, i64, C.c_float, C.c_float, i32, C.c_float, C.c_float, i32, vp, vp, i64, C.POINTER(i64)]
     L.pnr_get_table.argtypes = [vp, C.c_char_p, vp, i64, C.POINTER(i64)]
     L.pnr_set_profiling.argtypes = [vp, i32]
+    L.pnr_set_smc_driver.argtypes = [vp, i32]
     L.pnr_get_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
     L.pnr_reset_kernel_ms.argtypes = [vp]
     L.pnr_expf_batch.argtypes = [vp, vp, i64, vp]
@@ -96,7 +97,7 @@ def load():
 EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", "pnr_set_stream", "pnr_synchronize",
            "pnr_set_volume", "pnr_set_volume_device", "pnr_frangi", "pnr_get_frangi", "pnr_gaussian", "pnr_hessian",
            "pnr_set_j8_v", "pnr_extract_seeds", "pnr_extract_seeds_range", "pnr_zncc_batch",
-           "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_trace_replay", "pnr_reconstruct", "pnr_get_table", "pnr_set_profiling",
+           "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_trace_replay", "pnr_reconstruct", "pnr_get_table", "pnr_set_profiling", "pnr_set_smc_driver",
            "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch"]
 
 
@@ -265,6 +266,11 @@ class Context:
         out = np.empty(n.value, np.uint32 if name == "rng" else np.float32)
         check(self.L.pnr_get_table(self.h, name.encode(), out.ctypes.data, n.value, C.byref(n)))
         return out
+
+    def set_smc_driver(self, driver):
+        """'phased' (0, default) or 'persistent' (1): how the particle filter is scheduled; results are identical."""
+        d = {"phased": 0, "persistent": 1}.get(driver, driver)
+        check(self.L.pnr_set_smc_driver(self.h, int(d)))
 
     # ---- profiling ----
     def set_profiling(self, on=True):

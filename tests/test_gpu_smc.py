@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 F32_RTOL, F32_ATOL = 1e-5, 1e-6
 
 
+@pytest.fixture(autouse=True, params=["phased", "persistent"])
+def smc_driver(request, monkeypatch):
+    """every test of this module runs with both schedulers of the particle filter (include/pnr_hip.h:
+    pnr_set_smc_driver); a new context takes its initial driver from PNR_SMC_DRIVER"""
+    monkeypatch.setenv("PNR_SMC_DRIVER", request.param)
+    return request.param
+
+
 def mat(a):
     return np.stack([a[k] for k in a.dtype.names], -1)
 
@@ -248,6 +256,7 @@ def test_trace_without_stash_matches(oracle, monkeypatch):
     Ta, sa, xa, _ = a.trace_batch(seeds)
     monkeypatch.setenv("PNR_NO_STASH", "1")
     b = pnr_amd.Context(p, 0)
+    b.set_smc_driver("persistent")  # the fallback belongs to the persistent driver: also a cross-driver comparison
     b.set_volume(img)
     Tb, sb, xb, _ = b.trace_batch(seeds)
     assert np.array_equal(Ta, Tb) and np.array_equal(sa, sb) and Ta.max() > 3
