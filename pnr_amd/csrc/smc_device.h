@@ -427,9 +427,51 @@ __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const F
     }
 }
 
+// The last, partly filled group of chains (np + 1 is rarely a multiple of 64): its `cnt` chains are spread over the
+// wave `parts` = 64 / cnt times, copy p of chain j taking the template rows iu = p, p + parts, ... of the v-slice.
+// Sampling is order-free, so the values are the same as in sample_slice; they go to a narrow [sample][stride] region
+// (stride = cnt rounded up to 16 floats).  The per-lane uu comes from the row register by ds_bpermute.
+template <int CS>
+__device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
+                                                    const float *__restrict__ ax, int iv, int parts, int p, bool active,
+                                                    float *__restrict__ stash_col, int stride)
+{
+    constexpr int G = CHAIN_G;
+    const int lane = threadIdx.x & 63;
+    const float r_au = ax[nv + (lane < nu ? lane : 0)];
+    const float r_aw = ax[nv + nu + (lane < nw ? lane : 0)];
+    const float vv = ax[iv]; // wave-uniform
+    const float x0 = f.px + vv * f.nvx, y0 = f.py + vv * f.nvy, z0 = f.pz + vv * f.nvz;
+    const int rows = (nu + parts - 1) / parts;
+    for (int r = 0; r < rows; ++r) {
+        const int iu = r * parts + p;
+        const bool ok = active && iu < nu;
+        const int iuc = iu < nu ? iu : nu - 1;
+        const float uu = __shfl(r_au, iuc);
+        const float x1 = x0 + uu * f.ux, y1 = y0 + uu * f.uy, z1 = z0 + uu * f.uz;
+        float *sp = stash_col + ((i64)(iv * nu + iuc) * nw) * stride;
+        for (int iw0 = 0; iw0 < nw; iw0 += G) {
+            float xs[G], ys[G], zs[G];
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                const int iw = (iw0 + j < nw) ? iw0 + j : nw - 1; // wave-uniform
+                const float ww = bcast(r_aw, iw);
+                xs[j] = x1 + ww * f.wx;
+                ys[j] = y1 + ww * f.wy;
+                zs[j] = z1 + ww * f.wz;
+            }
+            const Samples<G> sm = interp_group<G, CS>(V, B, xs, ys, zs);
+#pragma unroll
+            for (int j = 0; j < G; j++)
+                if (ok && iw0 + j < nw) sp[(iw0 + j) * stride] = sm.v[j];
+        }
+    }
+}
+
 // Phase B: the ordered sums of znccBBB (tracker.cpp:1940-1955) for one chain, streamed from the
 // stash: mean in sample order, then corra / corrb in sample order.  Software-pipelined: 32 values
 // per lane in flight.  All 64 lanes of the wave must call it (template weights are broadcast).
+template <int STRIDE = 64>
 __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash_lane, int M, const float *__restrict__ wd,
                                                  float corrc)
 {
@@ -438,12 +480,12 @@ __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash
     float cur[CH], nxt[CH];
     float ag = 0.f;
 #pragma unroll
-    for (int j = 0; j < CH; j++) cur[j] = stash_lane[(j < M ? j : M - 1) * 64];
+    for (int j = 0; j < CH; j++) cur[j] = stash_lane[(j < M ? j : M - 1) * STRIDE];
     for (int k0 = 0; k0 < M; k0 += CH) {
         const int k1 = k0 + CH;
         if (k1 < M) {
 #pragma unroll
-            for (int j = 0; j < CH; j++) nxt[j] = stash_lane[(k1 + j < M ? k1 + j : M - 1) * 64];
+            for (int j = 0; j < CH; j++) nxt[j] = stash_lane[(k1 + j < M ? k1 + j : M - 1) * STRIDE];
         }
 #pragma unroll
         for (int j = 0; j < CH; j++)
@@ -455,13 +497,13 @@ __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash
     float corra = 0.f, corrb = 0.f;
     float w_cur, w_nxt = 0.f;
 #pragma unroll
-    for (int j = 0; j < CH; j++) cur[j] = stash_lane[(j < M ? j : M - 1) * 64];
+    for (int j = 0; j < CH; j++) cur[j] = stash_lane[(j < M ? j : M - 1) * STRIDE];
     w_cur = wd[(lane < CH && lane < M) ? lane : 0];
     for (int k0 = 0; k0 < M; k0 += CH) {
         const int k1 = k0 + CH;
         if (k1 < M) {
 #pragma unroll
-            for (int j = 0; j < CH; j++) nxt[j] = stash_lane[(k1 + j < M ? k1 + j : M - 1) * 64];
+            for (int j = 0; j < CH; j++) nxt[j] = stash_lane[(k1 + j < M ? k1 + j : M - 1) * STRIDE];
             w_nxt = wd[(lane < CH && k1 + lane < M) ? k1 + lane : 0];
         }
 #pragma unroll

@@ -21,7 +21,8 @@
 
 namespace {
 
-enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_N = 16 };
+enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_N = 16 };
+constexpr int PH_CS = 54; // the sampling kernel holds nothing but the cube in LDS: 54^3 = 157 464 B of the 160 KB
 
 struct PhState {
     float *part;   // [NT][2][np][9]
@@ -30,17 +31,22 @@ struct PhState {
     float *corr;   // [NT][S][np_pad]
     float *xcs;    // [NT][2][8]
     int *flags;    // [NT][FL_N]
-    float *stash;  // [NT][S*ngroups][Mmax*64]
-    long long trace_floats, wave_floats;
-    int *n_done;   // device counter of finished traces
+    float *stash;  // [NT][trace_floats]: per sigma, ngf regions [M][64] of the full chain groups, then [M][R] of the last one
+    long long trace_floats;
+    int *list;     // [2][cap]: traces still running in iteration it: list[it & 1][0 .. cnt[it & 1])
+    int *cnt;      // [2]
+    int cap;
+    int ngf, rem, R, W; // full groups of 64 chains, chains in the last group, its row stride, floats per sample row
 };
 
 __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, const float *__restrict__ seeds6, Vol V, int np, int ni, int it,
                                                    int CS)
 {
-    const int tr = blockIdx.x, tid = threadIdx.x, B = blockDim.x;
+    const int tid = threadIdx.x, B = blockDim.x;
+    if (blockIdx.x == 0 && tid == 0) P.cnt[(it + 1) & 1] = 0; // filled by ph_update of this iteration
+    if ((int)blockIdx.x >= P.cnt[it & 1]) return;
+    const int tr = P.list[(it & 1) * P.cap + blockIdx.x];
     int *fl = P.flags + (i64)tr * FL_N;
-    if (fl[FL_DONE]) return;
     __shared__ int sbox[8];
     const bool tail = (it == ni) || (fl[FL_STOP] != 0);
     const int pending = it - 1; // the previous iteration's centroid is evaluated with this iteration's chains
@@ -127,12 +133,13 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
 }
 
 template <int CS>
-__global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int np_pad, int ni, int it, int nsplit)
+__global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it, int nsplit)
 {
     extern __shared__ unsigned char cube[];
-    const int tr = blockIdx.x / nsplit, part_id = blockIdx.x - tr * nsplit, tid = threadIdx.x, B = blockDim.x, S = T.nsig;
+    const int slot = blockIdx.x / nsplit, part_id = blockIdx.x - slot * nsplit, tid = threadIdx.x, B = blockDim.x, S = T.nsig;
+    if (slot >= P.cnt[it & 1]) return;
+    const int tr = P.list[(it & 1) * P.cap + slot];
     const int *fl = P.flags + (i64)tr * FL_N;
-    if (fl[FL_DONE]) return;
     const bool tail = (it == ni) || (fl[FL_STOP] != 0);
     const int pending = it - 1;
     const float *cur = P.part + (i64)tr * 2 * np * PSTRIDE + (it & 1) * np * PSTRIDE;
@@ -158,55 +165,86 @@ __global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P
         }
     }
     __syncthreads();
-    const int ngroups = np_pad >> 6;
-    int nitems = 0;
-    for (int s = 0; s < S; s++) nitems += __builtin_amdgcn_readfirstlane(X.grid[s].nv) * ngroups;
+    const int ngf = P.ngf, rem = P.rem;
+    int nvsum = 0;
+    for (int s = 0; s < S; s++) nvsum += __builtin_amdgcn_readfirstlane(X.grid[s].nv);
+    const int nfull = nvsum * ngf, nitems = nfull + (rem > 0 ? nvsum : 0);
     float *const tbase = P.stash + (i64)tr * P.trace_floats;
-    const int nwv = B >> 6;
-    // items (sigma descending, v-slice, group) dealt round-robin over the nsplit work-groups x waves of this trace
-    for (int item = part_id * nwv + (tid >> 6); item < nitems; item += nsplit * nwv) {
-        int sI = S - 1, rem = item;
-        while (sI >= 0) {
-            const int cnt = __builtin_amdgcn_readfirstlane(X.grid[sI].nv) * ngroups;
-            if (rem < cnt) break;
-            rem -= cnt;
+    const int nwv = B >> 6, lane = tid & 63;
+    // Items in descending cost: (sigma descending, v-slice, full group), then the packed last group per (sigma, v-slice);
+    // dealt round-robin over the nsplit work-groups x waves that share this trace.  A tail pass only has the centroid.
+    const int first = (tail && rem > 0) ? nfull : 0;
+    for (int item = first + part_id * nwv + (tid >> 6); item < nitems; item += nsplit * nwv) {
+        const bool packed = item >= nfull;
+        const int per = packed ? 1 : ngf;
+        int sI = S - 1, r = packed ? item - nfull : item;
+        while (sI > 0) {
+            const int c = __builtin_amdgcn_readfirstlane(X.grid[sI].nv) * per;
+            if (r < c) break;
+            r -= c;
             sI--;
         }
-        const int iv = rem / ngroups, g = rem - iv * ngroups;
-        const int k = g * 64 + (tid & 63);
-        const bool is_cen = (k == np) && (pending >= 0);
-        const bool valid = (k < np && !tail) || is_cen;
-        if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
-        const float *q = is_cen ? xc_pen : (valid ? cur + k * PSTRIDE : (tail ? xc_pen : cur));
-        const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
+        const int iv = r / per, g = r - iv * per;
         const Grid gr = X.grid[sI];
         const int nv = __builtin_amdgcn_readfirstlane(gr.nv), nu = __builtin_amdgcn_readfirstlane(gr.nu);
-        const int nw = __builtin_amdgcn_readfirstlane(gr.nw);
+        const int nw = __builtin_amdgcn_readfirstlane(gr.nw), goff = __builtin_amdgcn_readfirstlane(gr.off);
+        const int Ms = nv * nu * nw;
         const float *ax = X.axes + __builtin_amdgcn_readfirstlane(X.axes_off[sI]);
-        sample_slice<CS>(V, Bx, f, nv, nu, nw, ax, iv, tbase + (i64)(sI * ngroups + g) * P.wave_floats + (tid & 63));
+        float *const sbase = tbase + (i64)goff * P.W;
+        if (!packed) {
+            const int k = g * 64 + lane;
+            const bool is_cen = (k == np) && (pending >= 0);
+            const bool valid = (k < np && !tail) || is_cen;
+            if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+            const float *q = is_cen ? xc_pen : (valid ? cur + k * PSTRIDE : (tail ? xc_pen : cur));
+            const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
+            sample_slice<CS>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane);
+        } else {
+            const int cnt = tail ? 1 : rem, jbase = tail ? rem - 1 : 0; // tail: the centroid's chains only
+            const int parts = 64 / cnt;
+            const bool act = lane < parts * cnt;
+            const int pp = act ? lane / cnt : 0, j = jbase + (act ? lane - pp * cnt : 0);
+            const int k = ngf * 64 + j;
+            const float *q = (k == np) ? xc_pen : cur + k * PSTRIDE; // k == np before the first centroid: zeros, discarded
+            const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
+            sample_slice_packed<CS>(V, Bx, f, nv, nu, nw, ax, iv, parts, pp, act, sbase + (i64)ngf * Ms * 64 + j, P.R);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void ph_sums(Tab T, TabX X, PhState P, int np, int np_pad, int ni, int it, int blocks_per_trace)
+// one wave per (trace, sigma, chain group): the ordered sums of the chains from the stash
+__global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, int np_pad, int ni, int it)
 {
-    const int tr = blockIdx.x / blocks_per_trace, S = T.nsig;
+    const int S = T.nsig, ng = P.ngf + (P.rem > 0 ? 1 : 0), lane = threadIdx.x;
+    const int slot = blockIdx.x / (S * ng);
+    if (slot >= P.cnt[it & 1]) return;
+    const int tr = P.list[(it & 1) * P.cap + slot];
     const int *fl = P.flags + (i64)tr * FL_N;
-    if (fl[FL_DONE]) return;
-    const int c = (blockIdx.x - tr * blocks_per_trace) * 256 + threadIdx.x;
-    if (c >= S * np_pad) return; // whole waves: np_pad is a multiple of 64
+    const int r = blockIdx.x - slot * (S * ng);
+    const int sI = r / ng, g = r - sI * ng;
     const bool tail = (it == ni) || (fl[FL_STOP] != 0);
     const int pending = it - 1;
-    const int sI = __builtin_amdgcn_readfirstlane(c / np_pad);
-    const int k = c - sI * np_pad;
+    const int k = g * 64 + lane;
     const bool is_cen = (k == np) && (pending >= 0);
     const bool valid = (k < np && !tail) || is_cen;
     if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
-    const int ngroups = np_pad >> 6;
     const Grid gr = X.grid[sI];
-    const int M = __builtin_amdgcn_readfirstlane(gr.nv) * __builtin_amdgcn_readfirstlane(gr.nu) * __builtin_amdgcn_readfirstlane(gr.nw);
-    const int goff = __builtin_amdgcn_readfirstlane(gr.off);
-    const float *col = P.stash + (i64)tr * P.trace_floats + (i64)(sI * ngroups + (k >> 6)) * P.wave_floats + (k & 63);
-    const float cv = zncc_from_stash(col, M, X.wd + goff, T.corrc[sI]);
+    const int M = gr.nv * gr.nu * gr.nw;
+    const float *sbase = P.stash + (i64)tr * P.trace_floats + (i64)gr.off * P.W;
+    const float *wd = X.wd + gr.off;
+    float cv;
+    if (g < P.ngf) {
+        cv = zncc_from_stash<64>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI]);
+    } else { // last group: narrow rows; lanes without a chain re-read a valid column (same 64 B granules)
+        const int j = tail ? P.rem - 1 : (lane < P.rem ? lane : P.rem - 1);
+        const float *col = sbase + (i64)P.ngf * M * 64 + j;
+        switch (P.R) {
+        case 16: cv = zncc_from_stash<16>(col, M, wd, T.corrc[sI]); break;
+        case 32: cv = zncc_from_stash<32>(col, M, wd, T.corrc[sI]); break;
+        case 48: cv = zncc_from_stash<48>(col, M, wd, T.corrc[sI]); break;
+        default: cv = zncc_from_stash<64>(col, M, wd, T.corrc[sI]); break;
+        }
+    }
     if (valid) P.corr[((i64)tr * S + sI) * np_pad + k] = cv;
 }
 
@@ -214,9 +252,10 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
                                                   float neff_ratio, const unsigned char *__restrict__ den, int nodepervol, TraceOut O)
 {
     extern __shared__ float lds[];
-    const int tr = blockIdx.x, tid = threadIdx.x, B = blockDim.x, S = T.nsig;
+    const int tid = threadIdx.x, B = blockDim.x, S = T.nsig;
+    if ((int)blockIdx.x >= P.cnt[it & 1]) return;
+    const int tr = P.list[(it & 1) * P.cap + blockIdx.x];
     int *fl = P.flags + (i64)tr * FL_N;
-    if (fl[FL_DONE]) return;
     float *cur = lds;                 // [np][9]
     float *prvw = cur + np * PSTRIDE; // [np] weights of the previous iteration
     float *prior = prvw + np;         // [np]
@@ -260,8 +299,6 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
         if (tid == 0) {
             O.T[tr] = fl[FL_T];
             O.stop[tr] = fl[FL_STOP];
-            fl[FL_DONE] = 1;
-            atomicAdd(P.n_done, 1);
         }
         return;
     }
@@ -361,6 +398,7 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
             if (it < O.dbg_iters && O.idxres) O.idxres[((i64)tr * O.dbg_iters + it) * np + k] = lo;
         }
     }
+    if (tid == 0) P.list[((it + 1) & 1) * P.cap + atomicAdd(&P.cnt[(it + 1) & 1], 1)] = tr; // still running
     for (int e = tid; e < np * PSTRIDE; e += B) gcur[e] = cur[e];
     if (it < O.dbg_iters && O.xfilt) {
         float *dst = O.xfilt + ((i64)tr * O.dbg_iters + it) * np * PSTRIDE;
@@ -371,20 +409,22 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------
-// host driver: one wave of at most PH_MAX_TRACES traces at a time
+// host driver
 // ---------------------------------------------------------------------------------------------------------
 struct pnr_phased {
     int64_t cap_traces = 0, cap_dbg = 0;
     int np = 0, np_pad = 0, S = 0, ni = 0;
+    long long trace_floats = 0;
     PhState P{};
     float *d_s6 = nullptr;
     TraceOut O{};
+    int *h_cnt = nullptr; // pinned
 };
 
 static void phased_free(pnr_phased *h)
 {
     hipFree(h->P.part); hipFree(h->P.prior); hipFree(h->P.idxres); hipFree(h->P.corr); hipFree(h->P.xcs); hipFree(h->P.flags);
-    hipFree(h->P.stash); hipFree(h->P.n_done); hipFree(h->d_s6);
+    hipFree(h->P.stash); hipFree(h->P.list); hipFree(h->P.cnt); hipFree(h->d_s6);
     hipFree(h->O.T); hipFree(h->O.stop); hipFree(h->O.xc); hipFree(h->O.xfilt); hipFree(h->O.idxres); hipFree(h->O.neff);
     h->P = PhState{};
     h->O = TraceOut{};
@@ -396,10 +436,24 @@ void pnr_phased_destroy(pnr_phased *h)
 {
     if (!h) return;
     phased_free(h);
+    if (h->h_cnt) hipHostFree(h->h_cnt);
     delete h;
 }
 
-static const int PH_MAX_TRACES = 512; // 8.9 GB of stash at np = 200, 3 scales
+// Work-groups per trace for the sampling launch.  One work-group per CU is resident (the cube fills the LDS), each
+// costs the cube staging plus its share of the trace's sampling; the launch lasts ceil(blocks / CUs) such rounds.
+static int pick_nsplit(int active, int ncu, int max_split)
+{
+    const double t_stage = 0.07, t_work = 1.0; // relative: staging ~7 % of a whole trace's sampling (measured)
+    int best = 1;
+    double best_t = 1e30;
+    for (int ns = 1; ns <= max_split; ns++) {
+        const double rounds = (double)(((long long)active * ns + ncu - 1) / ncu);
+        const double t = rounds * (t_stage + t_work / ns);
+        if (t < best_t - 1e-12) { best_t = t; best = ns; }
+    }
+    return best;
+}
 
 int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, int32_t *stop_out, pnr_xest *xc, int dbg_iters,
                          float *xfilt, int32_t *idxres, float *neff, int use_density)
@@ -411,32 +465,38 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
     Tab T;
     make_tab(c, T);
     const int np = c->prm.np, ni = c->prm.ni, S = T.nsig;
-    const int np_pad = (np + 1 + 63) / 64 * 64;
+    const int np_pad = (np + 1 + 63) / 64 * 64; // slot np = the pending centroid
     if (dbg_iters > ni) dbg_iters = ni;
     if (dbg_iters < 0) dbg_iters = 0;
-    static const int cube_sides[] = {52, 48, 44, 40, 36, 32};
-    // same cube side as the persistent driver picks for this np (identical fallbacks to HBM, identical numerics anyway)
-    const size_t fixed = trace_fixed_lds_bytes(np, np_pad, S);
-    int CS = 0;
-    for (int cs : cube_sides)
-        if (fixed + (size_t)cs * cs * cs + 64 <= 160 * 1024) { CS = cs; break; }
-    PNR_REQUIRE(CS > 0, PNR_E_ARG, "np=%d: no room for the image cube", np);
+    PNR_REQUIRE(2 * n < (1LL << 30), PNR_E_ARG, "too many traces in one batch");
     for (int s = 0; s < S; s++)
         PNR_REQUIRE(c->tab.grid[4 * s] <= 64 && c->tab.grid[4 * s + 1] <= 64 && c->tab.grid[4 * s + 2] <= 64, PNR_E_ARG,
                     "template grid axis longer than a wavefront");
     if (!c->phased) c->phased = new pnr_phased();
     pnr_phased *h = c->phased;
-    int Mmax = 0;
-    for (int s = 0; s < S; s++) Mmax = std::max(Mmax, c->tab.M[s]);
-    const long long wave_floats = (long long)Mmax * 64, trace_floats = wave_floats * S * (np_pad / 64);
+    if (!h->h_cnt) PNR_HIP(hipHostMalloc(&h->h_cnt, 64));
+    const int ngf = (np + 1) / 64, rem = (np + 1) - 64 * ngf, R = (rem + 15) / 16 * 16, W = 64 * ngf + R;
+    const long long Mtot = T.Mtot, trace_floats = Mtot * W;
     const int64_t ntr_all = 2 * n;
-    const int64_t NT = std::min<int64_t>(ntr_all, PH_MAX_TRACES);
+    // traces per wave: the whole batch when its stash fits the budget (HBM is 288 GB; default budget 64 GB or half of
+    // what is free), else equal slices
+    size_t free_b = 0, total_b = 0;
+    PNR_HIP(hipMemGetInfo(&free_b, &total_b));
+    size_t budget = (size_t)64 << 30;
+    if (const char *e = getenv("PNR_STASH_GB")) budget = (size_t)std::max(1, atoi(e)) << 30;
+    const size_t have = (size_t)h->cap_traces * (size_t)h->trace_floats * 4; // our own stash counts as free
+    budget = std::min(budget, (free_b + have) / 2);
+    int64_t nt_max = (int64_t)(budget / ((size_t)trace_floats * 4));
+    PNR_REQUIRE(nt_max >= 1, PNR_E_HIP, "not enough device memory for one trace's sample stash (%lld B)", trace_floats * 4);
+    const int64_t nwaves = (ntr_all + nt_max - 1) / nt_max;
+    const int64_t NT = (ntr_all + nwaves - 1) / nwaves;
     const int64_t need_dbg = NT * dbg_iters;
-    if (h->cap_traces < NT || h->np != np || h->np_pad != np_pad || h->S != S || h->ni != ni || h->cap_dbg < need_dbg ||
-        (xfilt && dbg_iters && !h->O.xfilt) || (idxres && dbg_iters && !h->O.idxres) || (neff && dbg_iters && !h->O.neff)) {
+    if (h->cap_traces < NT || h->np != np || h->np_pad != np_pad || h->S != S || h->ni != ni || h->trace_floats != trace_floats ||
+        h->cap_dbg < need_dbg || (xfilt && dbg_iters && !h->O.xfilt) || (idxres && dbg_iters && !h->O.idxres) ||
+        (neff && dbg_iters && !h->O.neff)) {
         PNR_HIP(hipDeviceSynchronize());
         phased_free(h);
-        const int64_t cap = std::max<int64_t>(NT, std::min<int64_t>(PH_MAX_TRACES, 256));
+        const int64_t cap = NT;
         PNR_HIP(hipMalloc(&h->P.part, (size_t)cap * 2 * np * PSTRIDE * 4));
         PNR_HIP(hipMalloc(&h->P.prior, (size_t)cap * np * 4));
         PNR_HIP(hipMalloc(&h->P.idxres, (size_t)cap * np * 4));
@@ -444,7 +504,8 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
         PNR_HIP(hipMalloc(&h->P.xcs, (size_t)cap * 16 * 4));
         PNR_HIP(hipMalloc(&h->P.flags, (size_t)cap * FL_N * 4));
         PNR_HIP(hipMalloc(&h->P.stash, (size_t)cap * trace_floats * 4));
-        PNR_HIP(hipMalloc(&h->P.n_done, 4));
+        PNR_HIP(hipMalloc(&h->P.list, (size_t)cap * 2 * 4));
+        PNR_HIP(hipMalloc(&h->P.cnt, 2 * 4));
         PNR_HIP(hipMalloc(&h->d_s6, (size_t)cap * 24));
         PNR_HIP(hipMalloc(&h->O.T, (size_t)cap * 4));
         PNR_HIP(hipMalloc(&h->O.stop, (size_t)cap * 4));
@@ -454,79 +515,76 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
         if (dbg_iters && idxres) PNR_HIP(hipMalloc(&h->O.idxres, dbg_cap * np * 4));
         if (dbg_iters && neff) PNR_HIP(hipMalloc(&h->O.neff, dbg_cap * 4));
         h->cap_traces = cap; h->cap_dbg = (int64_t)dbg_cap;
-        h->np = np; h->np_pad = np_pad; h->S = S; h->ni = ni;
+        h->np = np; h->np_pad = np_pad; h->S = S; h->ni = ni; h->trace_floats = trace_floats;
+        // a stale stash value is only ever read for a chain whose result is discarded, but keep it finite
+        PNR_HIP(hipMemsetAsync(h->P.stash, 0, (size_t)cap * trace_floats * 4, c->stream));
+        PNR_HIP(hipMemsetAsync(h->P.part, 0, (size_t)cap * 2 * np * PSTRIDE * 4, c->stream));
     }
-    h->P.trace_floats = trace_floats;
-    h->P.wave_floats = wave_floats;
+    PhState P = h->P;
+    P.trace_floats = trace_floats;
+    P.cap = (int)h->cap_traces;
+    P.ngf = ngf; P.rem = rem; P.R = R; P.W = W;
     TabX X;
     X.grid = (const Grid *)c->d_grid; X.axes = c->d_axes; X.axes_off = c->d_axes_off; X.wd = c->d_wd;
     X.ext_v = c->tab.ext_v; X.ext_uw = c->tab.ext_uw;
-    X.stash = nullptr; X.slot_busy = nullptr; X.nslots = 0; X.slot_floats = 0; X.wave_floats = wave_floats;
+    X.stash = nullptr; X.slot_busy = nullptr; X.nslots = 0; X.slot_floats = 0; X.wave_floats = 0;
     hipDeviceProp_t prop;
     PNR_HIP(hipGetDeviceProperties(&prop, c->device));
     const int ncu = prop.multiProcessorCount;
     hipStream_t st = c->stream;
+    constexpr int CS = PH_CS;
     const size_t cube_bytes = (size_t)CS * CS * CS;
     const size_t upd_lds = ((size_t)np * PSTRIDE + 4 * (size_t)np + (size_t)S * np_pad + 2 + 2 + 8) * 4;
-    const int sum_blocks = (S * np_pad + 255) / 256;
+    const int ng = ngf + (rem > 0 ? 1 : 0);
+    int max_split = 24;
+    if (const char *e = getenv("PNR_MAX_SPLIT")) max_split = std::max(1, atoi(e));
+    PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cube_bytes));
 
     std::vector<float> s6;
-    std::vector<int> flags;
-    for (int64_t t0 = 0; t0 < ntr_all; t0 += PH_MAX_TRACES) {
-        const int nt = (int)std::min<int64_t>(PH_MAX_TRACES, ntr_all - t0);
+    std::vector<int> flags, list0;
+    for (int64_t t0 = 0; t0 < ntr_all; t0 += NT) {
+        const int nt = (int)std::min<int64_t>(NT, ntr_all - t0);
         s6.resize((size_t)nt * 6);
         for (int j = 0; j < nt; j++) {
             const pnr_seed &sd = seeds[(t0 + j) / 2];
-            const float sgn = ((t0 + j) & 1) ? -1.f : 1.f; // odd trace: trackNeg (tracker.cpp:819-823)
+            const bool neg = ((t0 + j) & 1) != 0; // odd trace: trackNeg (tracker.cpp:819-823)
             float *a = &s6[(size_t)j * 6];
             a[0] = sd.x; a[1] = sd.y; a[2] = sd.z;
-            a[3] = sgn < 0 ? -sd.vx : sd.vx; a[4] = sgn < 0 ? -sd.vy : sd.vy; a[5] = sgn < 0 ? -sd.vz : sd.vz;
+            a[3] = neg ? -sd.vx : sd.vx; a[4] = neg ? -sd.vy : sd.vy; a[5] = neg ? -sd.vz : sd.vz;
         }
         flags.assign((size_t)nt * FL_N, 0);
-        for (int j = 0; j < nt; j++) flags[(size_t)j * FL_N + FL_T] = ni;
+        list0.resize((size_t)nt);
+        for (int j = 0; j < nt; j++) { flags[(size_t)j * FL_N + FL_T] = ni; list0[(size_t)j] = j; }
+        const int cnt0[2] = {nt, 0};
         PNR_HIP(hipMemcpyAsync(h->d_s6, s6.data(), s6.size() * 4, hipMemcpyHostToDevice, st));
-        PNR_HIP(hipMemcpyAsync(h->P.flags, flags.data(), flags.size() * 4, hipMemcpyHostToDevice, st));
-        PNR_HIP(hipMemsetAsync(h->P.n_done, 0, 4, st));
+        PNR_HIP(hipMemcpyAsync(P.flags, flags.data(), flags.size() * 4, hipMemcpyHostToDevice, st));
+        PNR_HIP(hipMemcpyAsync(P.list, list0.data(), list0.size() * 4, hipMemcpyHostToDevice, st));
+        PNR_HIP(hipMemcpyAsync(P.cnt, cnt0, 8, hipMemcpyHostToDevice, st));
         PNR_HIP(hipMemsetAsync(h->O.xc, 0, (size_t)nt * ni * 32, st));
-        PNR_HIP(hipMemsetAsync(h->P.xcs, 0, (size_t)nt * 16 * 4, st));
+        PNR_HIP(hipMemsetAsync(P.xcs, 0, (size_t)nt * 16 * 4, st));
         TraceOut O = h->O;
         O.dbg_iters = dbg_iters;
         if (!xfilt || !dbg_iters) O.xfilt = nullptr;
         if (!idxres || !dbg_iters) O.idxres = nullptr;
         if (!neff || !dbg_iters) O.neff = nullptr;
         if (O.idxres) PNR_HIP(hipMemsetAsync(O.idxres, 0xff, (size_t)nt * dbg_iters * np * 4, st));
-        PNR_HIP(hipStreamSynchronize(st)); // s6 / flags are pageable host vectors reused below
-        int active = nt, done = 0;
+        PNR_HIP(hipStreamSynchronize(st)); // the uploads above come from pageable host vectors reused below
+        int active = nt; // upper bound of the traces still running (refreshed every few iterations)
         for (int it = 0; it <= ni && active > 0; it++) {
-            // about two sampling work-groups per CU: the fewer traces are left, the more CUs each one gets
-            int nsplit = (2 * ncu) / active;
-            nsplit = nsplit < 1 ? 1 : (nsplit > 12 ? 12 : nsplit);
-            hipLaunchKernelGGL(ph_predict, dim3(nt), dim3(256), 0, st, T, X, h->P, h->d_s6, V, np, ni, it, CS);
+            const int nsplit = pick_nsplit(active, ncu, max_split);
+            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, T, X, P, h->d_s6, V, np, ni, it, CS);
             c->tic(st);
-#define PNR_LAUNCH_SAMPLE(cs)                                                                                                  \
-    case cs:                                                                                                                   \
-        if (it == 0 && t0 == 0) PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<cs>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cube_bytes)); \
-        hipLaunchKernelGGL(ph_sample<cs>, dim3((unsigned)(nt * nsplit)), dim3(768), cube_bytes, st, V, T, X, h->P, np, np_pad, ni, it, nsplit); \
-        break;
-            switch (CS) {
-                PNR_LAUNCH_SAMPLE(52)
-                PNR_LAUNCH_SAMPLE(48)
-                PNR_LAUNCH_SAMPLE(44)
-                PNR_LAUNCH_SAMPLE(40)
-                PNR_LAUNCH_SAMPLE(36)
-                PNR_LAUNCH_SAMPLE(32)
-            }
-#undef PNR_LAUNCH_SAMPLE
+            hipLaunchKernelGGL(ph_sample<CS>, dim3((unsigned)(active * nsplit)), dim3(768), cube_bytes, st, V, T, X, P, np, ni, it, nsplit);
             c->toc("smc", 1, st);
             c->tic(st);
-            hipLaunchKernelGGL(ph_sums, dim3((unsigned)(nt * sum_blocks)), dim3(256), 0, st, T, X, h->P, np, np_pad, ni, it, sum_blocks);
+            hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it);
             c->toc("smc_sums", 1, st);
-            hipLaunchKernelGGL(ph_update, dim3(nt), dim3(256), upd_lds, st, V, T, h->P, np, np_pad, ni, it, c->prm.Kc, c->prm.znccth,
+            hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), upd_lds, st, V, T, P, np, np_pad, ni, it, c->prm.Kc, c->prm.znccth,
                                c->prm.neff_ratio, use_density ? c->d_den : nullptr, c->prm.nodepervol, O);
-            if ((it & 3) == 3 || it == ni) { // refresh the active count (drives nsplit and the early exit)
-                PNR_HIP(hipMemcpyAsync(&done, h->P.n_done, 4, hipMemcpyDeviceToHost, st));
+            if ((it & 3) == 3 || it == ni) {
+                PNR_HIP(hipMemcpyAsync(h->h_cnt, P.cnt + ((it + 1) & 1), 4, hipMemcpyDeviceToHost, st));
                 PNR_HIP(hipStreamSynchronize(st));
-                active = nt - done;
+                active = h->h_cnt[0];
             }
         }
         PNR_HIP(hipGetLastError());
