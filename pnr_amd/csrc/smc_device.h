@@ -396,7 +396,8 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
 // no longer pin the iteration time to the longest chain.  Values go to the stash at [sample][lane].
 template <int CS>
 __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
-                                             const float *__restrict__ ax, int iv, float *__restrict__ stash_lane)
+                                             const float *__restrict__ ax, int iv, float *__restrict__ stash_lane, int iu0 = 0,
+                                             int iu1 = 1 << 30)
 {
     constexpr int G = CHAIN_G;
     const int lane = threadIdx.x & 63;
@@ -404,8 +405,9 @@ __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const F
     const float r_aw = ax[nv + nu + (lane < nw ? lane : 0)];
     const float vv = ax[iv]; // wave-uniform
     const float x0 = f.px + vv * f.nvx, y0 = f.py + vv * f.nvy, z0 = f.pz + vv * f.nvz;
-    float *sp = stash_lane + (i64)iv * nu * nw * 64;
-    for (int iu = 0; iu < nu; ++iu) {
+    if (iu1 > nu) iu1 = nu; // rows [iu0, iu1) of the v-slice (default: all)
+    float *sp = stash_lane + ((i64)iv * nu + iu0) * nw * 64;
+    for (int iu = iu0; iu < iu1; ++iu) {
         const float uu = bcast(r_au, iu);
         const float x1 = x0 + uu * f.ux, y1 = y0 + uu * f.uy, z1 = z0 + uu * f.uz;
         for (int iw0 = 0; iw0 < nw; iw0 += G) {
@@ -471,11 +473,11 @@ __device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, 
 // Phase B: the ordered sums of znccBBB (tracker.cpp:1940-1955) for one chain, streamed from the
 // stash: mean in sample order, then corra / corrb in sample order.  Software-pipelined: 32 values
 // per lane in flight.  All 64 lanes of the wave must call it (template weights are broadcast).
-template <int STRIDE = 64>
+template <int STRIDE = 64, int CH = 32>
 __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash_lane, int M, const float *__restrict__ wd,
                                                  float corrc)
 {
-    constexpr int CH = 32;
+    static_assert(CH <= 64, "one template weight per lane and chunk");
     const int lane = threadIdx.x & 63;
     float cur[CH], nxt[CH];
     float ag = 0.f;

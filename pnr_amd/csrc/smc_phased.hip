@@ -21,7 +21,8 @@
 
 namespace {
 
-enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_N = 16 };
+enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_N = 16 };
+constexpr int PH_CH = 32; // stash values in flight per lane in ph_sums
 constexpr int PH_CS = 54; // the sampling kernel holds nothing but the cube in LDS: 54^3 = 157 464 B of the 160 KB
 
 struct PhState {
@@ -35,6 +36,7 @@ struct PhState {
     long long trace_floats;
     int *list;     // [2][cap]: traces still running in iteration it: list[it & 1][0 .. cnt[it & 1])
     int *cnt;      // [2]
+    int *ctr;      // [NT] sampling work-item counter of the current iteration
     int cap;
     int ngf, rem, R, W; // full groups of 64 chains, chains in the last group, its row stride, floats per sample row
 };
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     const float *sd = seeds6 + (i64)tr * 6;
     const float x0 = sd[0], y0 = sd[1], z0 = sd[2], vx0 = sd[3], vy0 = sd[4], vz0 = sd[5];
     if (tid < 3) { sbox[tid] = 0x7fffffff; sbox[3 + tid] = -0x7fffffff; }
+    if (tid == 3) { P.ctr[tr] = 0; sbox[6] = 0; }
     __syncthreads();
     for (int k = tid; k <= np; k += B) {
         float qx, qy, qz, qvx, qvy, qvz;
@@ -116,6 +119,8 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
             atomicMax(&sbox[3], (int)floorf(fminf(qx + ex, big)) + 2);
             atomicMax(&sbox[4], (int)floorf(fminf(qy + ey, big)) + 2);
             atomicMax(&sbox[5], (int)floorf(fminf(qz + ez, big)) + 2);
+        } else {
+            sbox[6] = 1; // NaN / inf pose: its clamped samples may land anywhere in the cube
         }
     }
     __syncthreads();
@@ -128,15 +133,24 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
             if (o > dim[a] - CS) o = dim[a] - CS;
             if (o < 0) o = 0;
             fl[FL_OX + a] = o;
+            if (a > 0) { // rows of the cube that can be sampled at all: only those are staged
+                int r0 = lo - o, r1 = hi - o + 1;
+                if (r0 < 0) r0 = 0;
+                if (r1 > CS) r1 = CS;
+                if (sbox[6] || r1 <= r0) { r0 = 0; r1 = CS; }
+                fl[FL_Y0 + 2 * (a - 1)] = r0;
+                fl[FL_Y0 + 2 * (a - 1) + 1] = r1;
+            }
         }
     }
 }
 
 template <int CS>
-__global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it, int nsplit)
+__global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it, int nslots)
 {
     extern __shared__ unsigned char cube[];
-    const int slot = blockIdx.x / nsplit, part_id = blockIdx.x - slot * nsplit, tid = threadIdx.x, B = blockDim.x, S = T.nsig;
+    // part-major: the first nslots work-groups are one per trace, the later ones join whatever is left of their trace
+    const int slot = blockIdx.x % nslots, tid = threadIdx.x, B = blockDim.x, S = T.nsig;
     if (slot >= P.cnt[it & 1]) return;
     const int tr = P.list[(it & 1) * P.cap + slot];
     const int *fl = P.flags + (i64)tr * FL_N;
@@ -147,50 +161,81 @@ __global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P
     Box Bx;
     Bx.lds = (lds_cu8 *)cube;
     Bx.ox = fl[FL_OX]; Bx.oy = fl[FL_OY]; Bx.oz = fl[FL_OZ];
-    { // stage the cube: one wave per (z,y) row, lanes along x (coalesced bytes), 4 rows in flight
-        const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6;
-        const int xg = Bx.ox + lane < V.w ? Bx.ox + lane : V.w - 1;
-        for (int r0 = wv; r0 < CS * CS; r0 += 4 * nwv) {
-            unsigned char v[4];
+    { // stage the rows of the cube the templates can reach.  The staging is latency-bound: a wave-load fetches four
+      // (z,y) rows, 16 lanes x 4 bytes each (unaligned dwords; lanes past the row end are not stored), NR loads in flight.
+        constexpr int NR = 8;
+        typedef unsigned __attribute__((aligned(1))) u32u;
+        const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6, sub = lane >> 4, l4 = (lane & 15) * 4;
+        const int y0 = fl[FL_Y0], ny = fl[FL_Y1] - y0, z0 = fl[FL_Z0], nrows = (fl[FL_Z1] - z0) * ny;
+        const i64 nvox = V.wh * V.l;
+        for (int r0 = wv * 4 + sub; r0 < nrows + sub; r0 += NR * nwv * 4) { // wave-uniform trip count
+            unsigned v[NR];
+            int at[NR];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int r = r0 + j * nwv < CS * CS ? r0 + j * nwv : CS * CS - 1;
-                const int zz = r / CS, yy = r - zz * CS;
+            for (int j = 0; j < NR; j++) {
+                const int r = r0 + j * nwv * 4 < nrows ? r0 + j * nwv * 4 : nrows - 1;
+                const int zz = z0 + r / ny, yy = y0 + (r - (r / ny) * ny);
                 const int zg = Bx.oz + zz < V.l ? Bx.oz + zz : V.l - 1, yg = Bx.oy + yy < V.h ? Bx.oy + yy : V.h - 1;
-                v[j] = V.img[(i64)zg * V.wh + (i64)yg * V.w + xg];
+                const i64 idx = (i64)zg * V.wh + (i64)yg * V.w + Bx.ox + l4;
+                if (idx + 3 < nvox) {
+                    v[j] = *(const u32u *)(V.img + idx);
+                } else { // the last bytes of the volume: byte loads, clamped (values past the row end are never addressed)
+                    v[j] = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) v[j] |= (unsigned)V.img[idx + b < nvox ? idx + b : nvox - 1] << (8 * b);
+                }
+                at[j] = (zz * CS + yy) * CS + l4;
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (r0 + j * nwv < CS * CS && lane < CS) cube[(r0 + j * nwv) * CS + lane] = v[j];
+            for (int j = 0; j < NR; j++)
+                if (r0 + j * nwv * 4 < nrows) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (l4 + b < CS) cube[at[j] + b] = (unsigned char)(v[j] >> (8 * b));
+                }
         }
     }
     __syncthreads();
     const int ngf = P.ngf, rem = P.rem;
-    int nvsum = 0;
-    for (int s = 0; s < S; s++) nvsum += __builtin_amdgcn_readfirstlane(X.grid[s].nv);
-    const int nfull = nvsum * ngf, nitems = nfull + (rem > 0 ? nvsum : 0);
+    // work items: a full group's item is ROWS template rows (iu) of one v-slice, the packed last group's a whole v-slice
+    constexpr int ROWS = 5;
+    int nvsum = 0, nchsum = 0;
+    for (int s = 0; s < S; s++) {
+        const int nv_s = __builtin_amdgcn_readfirstlane(X.grid[s].nv), nu_s = __builtin_amdgcn_readfirstlane(X.grid[s].nu);
+        nvsum += nv_s;
+        nchsum += nv_s * ((nu_s + ROWS - 1) / ROWS);
+    }
+    const int nfull = nchsum * ngf, nitems = nfull + (rem > 0 ? nvsum : 0);
     float *const tbase = P.stash + (i64)tr * P.trace_floats;
-    const int nwv = B >> 6, lane = tid & 63;
-    // Items in descending cost: (sigma descending, v-slice, full group), then the packed last group per (sigma, v-slice);
-    // dealt round-robin over the nsplit work-groups x waves that share this trace.  A tail pass only has the centroid.
+    const int lane = tid & 63;
+    // Items in descending cost: (sigma descending, v-slice, row chunk, full group), then the packed last group per
+    // (sigma, v-slice); every wave of the work-groups that share this trace pulls the next one from the trace's counter,
+    // so the waves finish within one item of each other.  A tail pass only has the centroid.
     const int first = (tail && rem > 0) ? nfull : 0;
-    for (int item = first + part_id * nwv + (tid >> 6); item < nitems; item += nsplit * nwv) {
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(&P.ctr[tr], 1);
+        item = first + __builtin_amdgcn_readfirstlane(item);
+        if (item >= nitems) break;
         const bool packed = item >= nfull;
-        const int per = packed ? 1 : ngf;
         int sI = S - 1, r = packed ? item - nfull : item;
         while (sI > 0) {
-            const int c = __builtin_amdgcn_readfirstlane(X.grid[sI].nv) * per;
+            const int nv_s = __builtin_amdgcn_readfirstlane(X.grid[sI].nv), nu_s = __builtin_amdgcn_readfirstlane(X.grid[sI].nu);
+            const int c = packed ? nv_s : nv_s * ((nu_s + ROWS - 1) / ROWS) * ngf;
             if (r < c) break;
             r -= c;
             sI--;
         }
-        const int iv = r / per, g = r - iv * per;
         const Grid gr = X.grid[sI];
         const int nv = __builtin_amdgcn_readfirstlane(gr.nv), nu = __builtin_amdgcn_readfirstlane(gr.nu);
         const int nw = __builtin_amdgcn_readfirstlane(gr.nw), goff = __builtin_amdgcn_readfirstlane(gr.off);
         const int Ms = nv * nu * nw;
         const float *ax = X.axes + __builtin_amdgcn_readfirstlane(X.axes_off[sI]);
         float *const sbase = tbase + (i64)goff * P.W;
+        const int nch = (nu + ROWS - 1) / ROWS;
+        const int per = packed ? 1 : nch * ngf;
+        const int iv = r / per, r2 = r - iv * per;
+        const int ch = packed ? 0 : r2 / ngf, g = packed ? 0 : r2 - ch * ngf;
         if (!packed) {
             const int k = g * 64 + lane;
             const bool is_cen = (k == np) && (pending >= 0);
@@ -198,7 +243,7 @@ __global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
             const float *q = is_cen ? xc_pen : (valid ? cur + k * PSTRIDE : (tail ? xc_pen : cur));
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
-            sample_slice<CS>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane);
+            sample_slice<CS>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
         } else {
             const int cnt = tail ? 1 : rem, jbase = tail ? rem - 1 : 0; // tail: the centroid's chains only
             const int parts = 64 / cnt;
@@ -234,15 +279,15 @@ __global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, 
     const float *wd = X.wd + gr.off;
     float cv;
     if (g < P.ngf) {
-        cv = zncc_from_stash<64>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI]);
+        cv = zncc_from_stash<64, PH_CH>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI]);
     } else { // last group: narrow rows; lanes without a chain re-read a valid column (same 64 B granules)
         const int j = tail ? P.rem - 1 : (lane < P.rem ? lane : P.rem - 1);
         const float *col = sbase + (i64)P.ngf * M * 64 + j;
         switch (P.R) {
-        case 16: cv = zncc_from_stash<16>(col, M, wd, T.corrc[sI]); break;
-        case 32: cv = zncc_from_stash<32>(col, M, wd, T.corrc[sI]); break;
-        case 48: cv = zncc_from_stash<48>(col, M, wd, T.corrc[sI]); break;
-        default: cv = zncc_from_stash<64>(col, M, wd, T.corrc[sI]); break;
+        case 16: cv = zncc_from_stash<16, PH_CH>(col, M, wd, T.corrc[sI]); break;
+        case 32: cv = zncc_from_stash<32, PH_CH>(col, M, wd, T.corrc[sI]); break;
+        case 48: cv = zncc_from_stash<48, PH_CH>(col, M, wd, T.corrc[sI]); break;
+        default: cv = zncc_from_stash<64, PH_CH>(col, M, wd, T.corrc[sI]); break;
         }
     }
     if (valid) P.corr[((i64)tr * S + sI) * np_pad + k] = cv;
@@ -412,19 +457,24 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
 // host driver
 // ---------------------------------------------------------------------------------------------------------
 struct pnr_phased {
+    static constexpr int MAX_GROUPS = 4, RING = 8;
     int64_t cap_traces = 0, cap_dbg = 0;
     int np = 0, np_pad = 0, S = 0, ni = 0;
     long long trace_floats = 0;
     PhState P{};
     float *d_s6 = nullptr;
     TraceOut O{};
-    int *h_cnt = nullptr; // pinned
+    int *h_cnt = nullptr;                        // pinned [MAX_GROUPS][RING]
+    hipStream_t streams[MAX_GROUPS] = {};        // [0] unused: group 0 runs on the ctx stream
+    hipEvent_t ev[MAX_GROUPS][RING] = {};      // counters of iteration it have been copied back
+    hipEvent_t ev_samp[MAX_GROUPS][RING] = {}; // the sampling launch of iteration it has finished
+    hipEvent_t ev_start = nullptr, ev_done[MAX_GROUPS] = {};
 };
 
 static void phased_free(pnr_phased *h)
 {
     hipFree(h->P.part); hipFree(h->P.prior); hipFree(h->P.idxres); hipFree(h->P.corr); hipFree(h->P.xcs); hipFree(h->P.flags);
-    hipFree(h->P.stash); hipFree(h->P.list); hipFree(h->P.cnt); hipFree(h->d_s6);
+    hipFree(h->P.stash); hipFree(h->P.list); hipFree(h->P.cnt); hipFree(h->P.ctr); hipFree(h->d_s6);
     hipFree(h->O.T); hipFree(h->O.stop); hipFree(h->O.xc); hipFree(h->O.xfilt); hipFree(h->O.idxres); hipFree(h->O.neff);
     h->P = PhState{};
     h->O = TraceOut{};
@@ -437,22 +487,26 @@ void pnr_phased_destroy(pnr_phased *h)
     if (!h) return;
     phased_free(h);
     if (h->h_cnt) hipHostFree(h->h_cnt);
+    for (int g = 0; g < pnr_phased::MAX_GROUPS; g++) {
+        if (h->streams[g]) (void)hipStreamDestroy(h->streams[g]);
+        if (h->ev_done[g]) (void)hipEventDestroy(h->ev_done[g]);
+        for (int r = 0; r < pnr_phased::RING; r++)
+            if (h->ev[g][r]) (void)hipEventDestroy(h->ev[g][r]);
+        for (int r = 0; r < pnr_phased::RING; r++)
+            if (h->ev_samp[g][r]) (void)hipEventDestroy(h->ev_samp[g][r]);
+    }
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     delete h;
 }
 
-// Work-groups per trace for the sampling launch.  One work-group per CU is resident (the cube fills the LDS), each
-// costs the cube staging plus its share of the trace's sampling; the launch lasts ceil(blocks / CUs) such rounds.
+// Work-groups per trace for the sampling launch.  One work-group per CU is resident (the cube fills the LDS); all
+// work-groups of a trace pull items from its counter, so what matters is that there are a few times more work-groups
+// than CUs (the dispatcher keeps every CU busy until the items run out) without paying the cube staging too often.
 static int pick_nsplit(int active, int ncu, int max_split)
 {
-    const double t_stage = 0.07, t_work = 1.0; // relative: staging ~7 % of a whole trace's sampling (measured)
-    int best = 1;
-    double best_t = 1e30;
-    for (int ns = 1; ns <= max_split; ns++) {
-        const double rounds = (double)(((long long)active * ns + ncu - 1) / ncu);
-        const double t = rounds * (t_stage + t_work / ns);
-        if (t < best_t - 1e-12) { best_t = t; best = ns; }
-    }
-    return best;
+    static const int x10 = getenv("PNR_SPLIT_X10") ? std::max(1, atoi(getenv("PNR_SPLIT_X10"))) : 40; // work-groups per CU x 10
+    int ns = (int)(((long long)x10 * ncu / 10 + active - 1) / active);
+    return ns < 1 ? 1 : (ns > max_split ? max_split : ns);
 }
 
 int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, int32_t *stop_out, pnr_xest *xc, int dbg_iters,
@@ -474,7 +528,16 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
                     "template grid axis longer than a wavefront");
     if (!c->phased) c->phased = new pnr_phased();
     pnr_phased *h = c->phased;
-    if (!h->h_cnt) PNR_HIP(hipHostMalloc(&h->h_cnt, 64));
+    if (!h->h_cnt) {
+        PNR_HIP(hipHostMalloc(&h->h_cnt, sizeof(int) * pnr_phased::MAX_GROUPS * pnr_phased::RING));
+        PNR_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
+        for (int g = 0; g < pnr_phased::MAX_GROUPS; g++) {
+            if (g > 0) PNR_HIP(hipStreamCreateWithFlags(&h->streams[g], hipStreamNonBlocking));
+            PNR_HIP(hipEventCreateWithFlags(&h->ev_done[g], hipEventDisableTiming));
+            for (int r = 0; r < pnr_phased::RING; r++) PNR_HIP(hipEventCreateWithFlags(&h->ev[g][r], hipEventDisableTiming));
+            for (int r = 0; r < pnr_phased::RING; r++) PNR_HIP(hipEventCreateWithFlags(&h->ev_samp[g][r], hipEventDisableTiming));
+        }
+    }
     const int ngf = (np + 1) / 64, rem = (np + 1) - 64 * ngf, R = (rem + 15) / 16 * 16, W = 64 * ngf + R;
     const long long Mtot = T.Mtot, trace_floats = Mtot * W;
     const int64_t ntr_all = 2 * n;
@@ -504,8 +567,9 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
         PNR_HIP(hipMalloc(&h->P.xcs, (size_t)cap * 16 * 4));
         PNR_HIP(hipMalloc(&h->P.flags, (size_t)cap * FL_N * 4));
         PNR_HIP(hipMalloc(&h->P.stash, (size_t)cap * trace_floats * 4));
-        PNR_HIP(hipMalloc(&h->P.list, (size_t)cap * 2 * 4));
-        PNR_HIP(hipMalloc(&h->P.cnt, 2 * 4));
+        PNR_HIP(hipMalloc(&h->P.list, (size_t)cap * 2 * 4 * pnr_phased::MAX_GROUPS));
+        PNR_HIP(hipMalloc(&h->P.cnt, 2 * 4 * pnr_phased::MAX_GROUPS));
+        PNR_HIP(hipMalloc(&h->P.ctr, (size_t)cap * 4));
         PNR_HIP(hipMalloc(&h->d_s6, (size_t)cap * 24));
         PNR_HIP(hipMalloc(&h->O.T, (size_t)cap * 4));
         PNR_HIP(hipMalloc(&h->O.stop, (size_t)cap * 4));
@@ -540,6 +604,15 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
     if (const char *e = getenv("PNR_MAX_SPLIT")) max_split = std::max(1, atoi(e));
     PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cube_bytes));
 
+    // A wave's traces are cut into `ngrp` groups that iterate independently on their own streams: while one group
+    // samples (VALU / LDS bound, one work-group per CU) another streams its sums from HBM, and the sampling launches of
+    // a group fill the CUs the other group's last round leaves idle.  Results do not depend on the grouping.
+    int ngrp = 1;
+    if (const char *e = getenv("PNR_PHASED_GROUPS")) ngrp = std::min(std::max(1, atoi(e)), (int)pnr_phased::MAX_GROUPS);
+    constexpr int LAG = 3, RING = pnr_phased::RING; // the host runs at most LAG iterations ahead of a group's counters
+    struct Grp {
+        PhState P; TraceOut O; const float *s6; int start, nt, active; hipStream_t st; bool running;
+    };
     std::vector<float> s6;
     std::vector<int> flags, list0;
     for (int64_t t0 = 0; t0 < ntr_all; t0 += NT) {
@@ -552,42 +625,84 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
             a[0] = sd.x; a[1] = sd.y; a[2] = sd.z;
             a[3] = neg ? -sd.vx : sd.vx; a[4] = neg ? -sd.vy : sd.vy; a[5] = neg ? -sd.vz : sd.vz;
         }
+        const int G = std::max(1, std::min(ngrp, nt));
         flags.assign((size_t)nt * FL_N, 0);
-        list0.resize((size_t)nt);
-        for (int j = 0; j < nt; j++) { flags[(size_t)j * FL_N + FL_T] = ni; list0[(size_t)j] = j; }
-        const int cnt0[2] = {nt, 0};
-        PNR_HIP(hipMemcpyAsync(h->d_s6, s6.data(), s6.size() * 4, hipMemcpyHostToDevice, st));
-        PNR_HIP(hipMemcpyAsync(P.flags, flags.data(), flags.size() * 4, hipMemcpyHostToDevice, st));
-        PNR_HIP(hipMemcpyAsync(P.list, list0.data(), list0.size() * 4, hipMemcpyHostToDevice, st));
-        PNR_HIP(hipMemcpyAsync(P.cnt, cnt0, 8, hipMemcpyHostToDevice, st));
-        PNR_HIP(hipMemsetAsync(h->O.xc, 0, (size_t)nt * ni * 32, st));
-        PNR_HIP(hipMemsetAsync(P.xcs, 0, (size_t)nt * 16 * 4, st));
+        for (int j = 0; j < nt; j++) flags[(size_t)j * FL_N + FL_T] = ni;
+        list0.assign((size_t)pnr_phased::MAX_GROUPS * 2 * P.cap, 0);
+        int cnt0[2 * pnr_phased::MAX_GROUPS] = {};
+        Grp grp[pnr_phased::MAX_GROUPS];
         TraceOut O = h->O;
         O.dbg_iters = dbg_iters;
         if (!xfilt || !dbg_iters) O.xfilt = nullptr;
         if (!idxres || !dbg_iters) O.idxres = nullptr;
         if (!neff || !dbg_iters) O.neff = nullptr;
+        for (int g = 0; g < G; g++) {
+            Grp &q = grp[g];
+            q.start = (int)((int64_t)nt * g / G);
+            q.nt = (int)((int64_t)nt * (g + 1) / G) - q.start;
+            q.active = q.nt;
+            q.running = q.nt > 0;
+            q.st = g == 0 ? st : h->streams[g];
+            const size_t o = (size_t)q.start;
+            q.P = P;
+            q.P.part += o * 2 * np * PSTRIDE; q.P.prior += o * np; q.P.idxres += o * np; q.P.corr += o * S * np_pad;
+            q.P.xcs += o * 16; q.P.flags += o * FL_N; q.P.stash += o * (size_t)trace_floats; q.P.ctr += o;
+            q.P.list += (size_t)g * 2 * P.cap; q.P.cnt += 2 * g;
+            q.s6 = h->d_s6 + o * 6;
+            q.O = O;
+            q.O.T += o; q.O.stop += o; q.O.xc += o * ni * 8;
+            if (q.O.xfilt) q.O.xfilt += o * dbg_iters * np * PSTRIDE;
+            if (q.O.idxres) q.O.idxres += o * dbg_iters * np;
+            if (q.O.neff) q.O.neff += o * dbg_iters;
+            for (int j = 0; j < q.nt; j++) list0[(size_t)g * 2 * P.cap + j] = j;
+            cnt0[2 * g] = q.nt;
+        }
+        PNR_HIP(hipMemcpyAsync(h->d_s6, s6.data(), s6.size() * 4, hipMemcpyHostToDevice, st));
+        PNR_HIP(hipMemcpyAsync(P.flags, flags.data(), flags.size() * 4, hipMemcpyHostToDevice, st));
+        PNR_HIP(hipMemcpyAsync(P.list, list0.data(), list0.size() * 4, hipMemcpyHostToDevice, st));
+        PNR_HIP(hipMemcpyAsync(P.cnt, cnt0, sizeof(cnt0), hipMemcpyHostToDevice, st));
+        PNR_HIP(hipMemsetAsync(h->O.xc, 0, (size_t)nt * ni * 32, st));
+        PNR_HIP(hipMemsetAsync(P.xcs, 0, (size_t)nt * 16 * 4, st));
         if (O.idxres) PNR_HIP(hipMemsetAsync(O.idxres, 0xff, (size_t)nt * dbg_iters * np * 4, st));
         PNR_HIP(hipStreamSynchronize(st)); // the uploads above come from pageable host vectors reused below
-        int active = nt; // upper bound of the traces still running (refreshed every few iterations)
-        for (int it = 0; it <= ni && active > 0; it++) {
-            const int nsplit = pick_nsplit(active, ncu, max_split);
-            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, T, X, P, h->d_s6, V, np, ni, it, CS);
-            c->tic(st);
-            hipLaunchKernelGGL(ph_sample<CS>, dim3((unsigned)(active * nsplit)), dim3(768), cube_bytes, st, V, T, X, P, np, ni, it, nsplit);
-            c->toc("smc", 1, st);
-            c->tic(st);
-            hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it);
-            c->toc("smc_sums", 1, st);
-            hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), upd_lds, st, V, T, P, np, np_pad, ni, it, c->prm.Kc, c->prm.znccth,
-                               c->prm.neff_ratio, use_density ? c->d_den : nullptr, c->prm.nodepervol, O);
-            if ((it & 3) == 3 || it == ni) {
-                PNR_HIP(hipMemcpyAsync(h->h_cnt, P.cnt + ((it + 1) & 1), 4, hipMemcpyDeviceToHost, st));
-                PNR_HIP(hipStreamSynchronize(st));
-                active = h->h_cnt[0];
+        hipEvent_t prev_samp = nullptr;
+        bool have_prev = false;
+        for (int it = 0; it <= ni; it++) {
+            bool any = false;
+            for (int g = 0; g < G; g++) {
+                Grp &q = grp[g];
+                if (!q.running) continue;
+                if (it >= LAG) { // counters of iteration it - LAG have landed: an upper bound of the traces still running
+                    PNR_HIP(hipEventSynchronize(h->ev[g][(it - LAG) % RING]));
+                    q.active = h->h_cnt[g * RING + (it - LAG) % RING];
+                    if (q.active <= 0) { q.running = false; continue; }
+                }
+                any = true;
+                const int nsplit = pick_nsplit(q.active, ncu, max_split);
+                hipLaunchKernelGGL(ph_predict, dim3(q.active), dim3(256), 0, q.st, T, X, q.P, q.s6, V, np, ni, it, CS);
+                // the sampling launches of the groups take turns (a launch fills every CU's LDS): group g samples after
+                // the previous running group's sampling of the same round, so its sums overlap the others' sampling
+                if (have_prev) PNR_HIP(hipStreamWaitEvent(q.st, prev_samp, 0));
+                c->tic(q.st);
+                hipLaunchKernelGGL(ph_sample<CS>, dim3((unsigned)(q.active * nsplit)), dim3(768), cube_bytes, q.st, V, T, X, q.P, np, ni, it, q.active);
+                c->toc("smc", 1, q.st);
+                if (G > 1) {
+                    PNR_HIP(hipEventRecord(h->ev_samp[g][it % RING], q.st));
+                    prev_samp = h->ev_samp[g][it % RING];
+                    have_prev = true;
+                }
+                c->tic(q.st);
+                hipLaunchKernelGGL(ph_sums, dim3((unsigned)(q.active * S * ng)), dim3(64), 0, q.st, T, X, q.P, np, np_pad, ni, it);
+                c->toc("smc_sums", 1, q.st);
+                hipLaunchKernelGGL(ph_update, dim3(q.active), dim3(256), upd_lds, q.st, V, T, q.P, np, np_pad, ni, it, c->prm.Kc,
+                                   c->prm.znccth, c->prm.neff_ratio, use_density ? c->d_den : nullptr, c->prm.nodepervol, q.O);
+                PNR_HIP(hipMemcpyAsync(&h->h_cnt[g * RING + it % RING], q.P.cnt + ((it + 1) & 1), 4, hipMemcpyDeviceToHost, q.st));
+                PNR_HIP(hipEventRecord(h->ev[g][it % RING], q.st));
             }
+            if (!any) break;
         }
         PNR_HIP(hipGetLastError());
+        for (int g = 1; g < G; g++) PNR_HIP(hipStreamSynchronize(grp[g].st));
         PNR_HIP(hipMemcpyAsync(T_out + t0, h->O.T, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
         PNR_HIP(hipMemcpyAsync(stop_out + t0, h->O.stop, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
         PNR_HIP(hipMemcpyAsync(xc + t0 * ni, h->O.xc, (size_t)nt * ni * 32, hipMemcpyDeviceToHost, st));
