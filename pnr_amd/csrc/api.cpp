@@ -394,6 +394,13 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
     int rc = pnr_density_reset(c);
     if (rc) return rc;
     int64_t iters = 0;
+    // phased driver: a window of trace slots refilled as traces stop (smc_phased.hip); `first_batch` has no meaning there
+    const bool streaming = c->smc_driver == 0 && !getenv("PNR_REPLAY_BATCHES");
+    if (streaming) {
+        rc = pnr_trace_replay_stream(c, seeds, n, r, &iters);
+        if (rc) return rc;
+        n = 0; // nothing left for the batch loop below
+    }
     int64_t batch = first_batch > 0 ? first_batch : 128;
     const int64_t growth_pct = getenv("PNR_BATCH_GROWTH") ? std::max(100, atoi(getenv("PNR_BATCH_GROWTH"))) : 200;
     // A ring of `depth` batches in flight, each on its own stream.  depth 1: strictly sequential batches (the

@@ -182,6 +182,7 @@ struct pnr_phased;
 int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T, int32_t *stop, pnr_xest *xc, int dbg_iters,
                          float *xfilt, int32_t *idxres, float *neff, int use_density);
 void pnr_phased_destroy(pnr_phased *h);
+int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::Replayer &r, int64_t *iters);
 int pnr_density_reset(pnr_ctx *c);                       // zero the device density map (allocating it on first use)
 int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, struct pnr_trace_job *on); // push the voxels touched by the last replay batch
 int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y);

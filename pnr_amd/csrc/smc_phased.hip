@@ -21,8 +21,7 @@
 
 namespace {
 
-enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_N = 16 };
-constexpr int PH_CH = 32; // stash values in flight per lane in ph_sums
+enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_IT = 3, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_N = 16 };
 constexpr int PH_CS = 54; // the sampling kernel holds nothing but the cube in LDS: 54^3 = 157 464 B of the 160 KB
 
 struct PhState {
@@ -41,14 +40,15 @@ struct PhState {
     int ngf, rem, R, W; // full groups of 64 chains, chains in the last group, its row stride, floats per sample row
 };
 
-__global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, const float *__restrict__ seeds6, Vol V, int np, int ni, int it,
-                                                   int CS)
+__global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, const float *__restrict__ seeds6, Vol V, int np, int ni, int it_arg,
+                                                   int lp, int CS)
 {
     const int tid = threadIdx.x, B = blockDim.x;
-    if (blockIdx.x == 0 && tid == 0) P.cnt[(it + 1) & 1] = 0; // filled by ph_update of this iteration
-    if ((int)blockIdx.x >= P.cnt[it & 1]) return;
-    const int tr = P.list[(it & 1) * P.cap + blockIdx.x];
+    if (blockIdx.x == 0 && tid == 0) P.cnt[lp ^ 1] = 0; // filled by ph_update of this step
+    if ((int)blockIdx.x >= P.cnt[lp]) return;
+    const int tr = P.list[lp * P.cap + blockIdx.x];
     int *fl = P.flags + (i64)tr * FL_N;
+    const int it = it_arg >= 0 ? it_arg : fl[FL_IT]; // streaming mode: every trace has its own iteration count
     __shared__ int sbox[8];
     const bool tail = (it == ni) || (fl[FL_STOP] != 0);
     const int pending = it - 1; // the previous iteration's centroid is evaluated with this iteration's chains
@@ -146,14 +146,15 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
 }
 
 template <int CS>
-__global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it, int nslots)
+__global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it_arg, int lp, int nslots)
 {
     extern __shared__ unsigned char cube[];
     // part-major: the first nslots work-groups are one per trace, the later ones join whatever is left of their trace
     const int slot = blockIdx.x % nslots, tid = threadIdx.x, B = blockDim.x, S = T.nsig;
-    if (slot >= P.cnt[it & 1]) return;
-    const int tr = P.list[(it & 1) * P.cap + slot];
+    if (slot >= P.cnt[lp]) return;
+    const int tr = P.list[lp * P.cap + slot];
     const int *fl = P.flags + (i64)tr * FL_N;
+    const int it = it_arg >= 0 ? it_arg : fl[FL_IT];
     const bool tail = (it == ni) || (fl[FL_STOP] != 0);
     const int pending = it - 1;
     const float *cur = P.part + (i64)tr * 2 * np * PSTRIDE + (it & 1) * np * PSTRIDE;
@@ -258,13 +259,15 @@ __global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P
 }
 
 // one wave per (trace, sigma, chain group): the ordered sums of the chains from the stash
-__global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, int np_pad, int ni, int it)
+template <int PH_CH>
+__global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, int np_pad, int ni, int it_arg, int lp)
 {
     const int S = T.nsig, ng = P.ngf + (P.rem > 0 ? 1 : 0), lane = threadIdx.x;
     const int slot = blockIdx.x / (S * ng);
-    if (slot >= P.cnt[it & 1]) return;
-    const int tr = P.list[(it & 1) * P.cap + slot];
+    if (slot >= P.cnt[lp]) return;
+    const int tr = P.list[lp * P.cap + slot];
     const int *fl = P.flags + (i64)tr * FL_N;
+    const int it = it_arg >= 0 ? it_arg : fl[FL_IT];
     const int r = blockIdx.x - slot * (S * ng);
     const int sI = r / ng, g = r - sI * ng;
     const bool tail = (it == ni) || (fl[FL_STOP] != 0);
@@ -293,14 +296,15 @@ __global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, 
     if (valid) P.corr[((i64)tr * S + sI) * np_pad + k] = cv;
 }
 
-__global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np, int np_pad, int ni, int it, float Kc, float znccth,
+__global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np, int np_pad, int ni, int it_arg, int lp, float Kc, float znccth,
                                                   float neff_ratio, const unsigned char *__restrict__ den, int nodepervol, TraceOut O)
 {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, B = blockDim.x, S = T.nsig;
-    if ((int)blockIdx.x >= P.cnt[it & 1]) return;
-    const int tr = P.list[(it & 1) * P.cap + blockIdx.x];
+    if ((int)blockIdx.x >= P.cnt[lp]) return;
+    const int tr = P.list[lp * P.cap + blockIdx.x];
     int *fl = P.flags + (i64)tr * FL_N;
+    const int it = it_arg >= 0 ? it_arg : fl[FL_IT];
     float *cur = lds;                 // [np][9]
     float *prvw = cur + np * PSTRIDE; // [np] weights of the previous iteration
     float *prior = prvw + np;         // [np]
@@ -344,6 +348,7 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
         if (tid == 0) {
             O.T[tr] = fl[FL_T];
             O.stop[tr] = fl[FL_STOP];
+            fl[FL_DONE] = 1;
         }
         return;
     }
@@ -443,12 +448,36 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
             if (it < O.dbg_iters && O.idxres) O.idxres[((i64)tr * O.dbg_iters + it) * np + k] = lo;
         }
     }
-    if (tid == 0) P.list[((it + 1) & 1) * P.cap + atomicAdd(&P.cnt[(it + 1) & 1], 1)] = tr; // still running
+    if (tid == 0) { // still running
+        P.list[(lp ^ 1) * P.cap + atomicAdd(&P.cnt[lp ^ 1], 1)] = tr;
+        fl[FL_IT] = it + 1;
+    }
     for (int e = tid; e < np * PSTRIDE; e += B) gcur[e] = cur[e];
     if (it < O.dbg_iters && O.xfilt) {
         float *dst = O.xfilt + ((i64)tr * O.dbg_iters + it) * np * PSTRIDE;
         for (int e = tid; e < np * PSTRIDE; e += B) dst[e] = cur[e];
     }
+}
+
+// streaming mode: hand `m` free slots to new traces and append them to the list of this step (one work-group, runs
+// alone in stream order between two steps)
+__global__ __launch_bounds__(256) void ph_admit(PhState P, float *__restrict__ s6, const int *__restrict__ new_slots,
+                                                 const float *__restrict__ new_s6, int m, int lp, int ni)
+{
+    __shared__ int base;
+    if (threadIdx.x == 0) base = P.cnt[lp];
+    __syncthreads();
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        const int slot = new_slots[j];
+        for (int a = 0; a < 6; a++) s6[(i64)slot * 6 + a] = new_s6[(i64)j * 6 + a];
+        int *fl = P.flags + (i64)slot * FL_N;
+        for (int a = 0; a < FL_N; a++) fl[a] = 0;
+        fl[FL_T] = ni;
+        for (int a = 0; a < 16; a++) P.xcs[(i64)slot * 16 + a] = 0.f;
+        P.list[lp * P.cap + base + j] = slot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) P.cnt[lp] = base + m;
 }
 
 } // namespace
@@ -465,6 +494,10 @@ struct pnr_phased {
     float *d_s6 = nullptr;
     TraceOut O{};
     int *h_cnt = nullptr;                        // pinned [MAX_GROUPS][RING]
+    // streaming trace + replay: pinned records written by the kernels / read back at every poll, admission staging
+    pnr_xest *h_xc = nullptr; int *h_flags = nullptr; int *h_new = nullptr; float *h_new_s6 = nullptr;
+    int *d_new = nullptr; float *d_new_s6 = nullptr;
+    int64_t stream_cap = 0;
     hipStream_t streams[MAX_GROUPS] = {};        // [0] unused: group 0 runs on the ctx stream
     hipEvent_t ev[MAX_GROUPS][RING] = {};      // counters of iteration it have been copied back
     hipEvent_t ev_samp[MAX_GROUPS][RING] = {}; // the sampling launch of iteration it has finished
@@ -487,6 +520,11 @@ void pnr_phased_destroy(pnr_phased *h)
     if (!h) return;
     phased_free(h);
     if (h->h_cnt) hipHostFree(h->h_cnt);
+    if (h->h_xc) hipHostFree(h->h_xc);
+    if (h->h_flags) hipHostFree(h->h_flags);
+    if (h->h_new) hipHostFree(h->h_new);
+    if (h->h_new_s6) hipHostFree(h->h_new_s6);
+    hipFree(h->d_new); hipFree(h->d_new_s6);
     for (int g = 0; g < pnr_phased::MAX_GROUPS; g++) {
         if (h->streams[g]) (void)hipStreamDestroy(h->streams[g]);
         if (h->ev_done[g]) (void)hipEventDestroy(h->ev_done[g]);
@@ -509,20 +547,39 @@ static int pick_nsplit(int active, int ncu, int max_split)
     return ns < 1 ? 1 : (ns > max_split ? max_split : ns);
 }
 
-int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, int32_t *stop_out, pnr_xest *xc, int dbg_iters,
-                         float *xfilt, int32_t *idxres, float *neff, int use_density)
+// the ordered sums are latency-bound per chain (M values, CH loads in flight per lane): with few traces the deep variant
+// (64 in flight, 256 VGPRs, one wave per SIMD) halves the launch time; with many, HBM bandwidth binds and occupancy wins
+static void launch_sums(int active, int per_trace, hipStream_t st, const Tab &T, const TabX &X, const PhState &P, int np, int np_pad, int ni,
+                        int it, int lp)
 {
-    if (n == 0) return PNR_OK;
-    Vol V;
-    int rc = make_vol(c, V);
+    static const int deep_below = getenv("PNR_SUMS_DEEP") ? atoi(getenv("PNR_SUMS_DEEP")) : 96;
+    if (active <= deep_below)
+        hipLaunchKernelGGL(ph_sums<64>, dim3((unsigned)(active * per_trace)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it, lp);
+    else
+        hipLaunchKernelGGL(ph_sums<32>, dim3((unsigned)(active * per_trace)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it, lp);
+}
+
+struct PhEnv {
+    Vol V; Tab T; TabX X; PhState P;
+    int np, ni, S, np_pad, ng, ncu, max_split, dbg_iters;
+    size_t cube_bytes, upd_lds;
+    long long trace_floats;
+    int64_t NT; // trace slots available (<= the number asked for: bounded by the stash budget)
+    pnr_phased *h;
+};
+
+// device state for up to `want` concurrent traces (fewer if their sample stash exceeds the budget: PNR_STASH_GB,
+// default 64 GB or half of the free HBM) and everything the four kernels take as arguments
+static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool idxres, bool neff, PhEnv &E)
+{
+    int rc = make_vol(c, E.V);
     if (rc) return rc;
-    Tab T;
-    make_tab(c, T);
-    const int np = c->prm.np, ni = c->prm.ni, S = T.nsig;
+    make_tab(c, E.T);
+    const int np = c->prm.np, ni = c->prm.ni, S = E.T.nsig;
     const int np_pad = (np + 1 + 63) / 64 * 64; // slot np = the pending centroid
     if (dbg_iters > ni) dbg_iters = ni;
     if (dbg_iters < 0) dbg_iters = 0;
-    PNR_REQUIRE(2 * n < (1LL << 30), PNR_E_ARG, "too many traces in one batch");
+    PNR_REQUIRE(want >= 1 && want < (1LL << 30), PNR_E_ARG, "bad number of traces");
     for (int s = 0; s < S; s++)
         PNR_REQUIRE(c->tab.grid[4 * s] <= 64 && c->tab.grid[4 * s + 1] <= 64 && c->tab.grid[4 * s + 2] <= 64, PNR_E_ARG,
                     "template grid axis longer than a wavefront");
@@ -539,20 +596,17 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
         }
     }
     const int ngf = (np + 1) / 64, rem = (np + 1) - 64 * ngf, R = (rem + 15) / 16 * 16, W = 64 * ngf + R;
-    const long long Mtot = T.Mtot, trace_floats = Mtot * W;
-    const int64_t ntr_all = 2 * n;
-    // traces per wave: the whole batch when its stash fits the budget (HBM is 288 GB; default budget 64 GB or half of
-    // what is free), else equal slices
+    const long long Mtot = E.T.Mtot, trace_floats = Mtot * W;
     size_t free_b = 0, total_b = 0;
     PNR_HIP(hipMemGetInfo(&free_b, &total_b));
     size_t budget = (size_t)64 << 30;
     if (const char *e = getenv("PNR_STASH_GB")) budget = (size_t)std::max(1, atoi(e)) << 30;
     const size_t have = (size_t)h->cap_traces * (size_t)h->trace_floats * 4; // our own stash counts as free
     budget = std::min(budget, (free_b + have) / 2);
-    int64_t nt_max = (int64_t)(budget / ((size_t)trace_floats * 4));
+    const int64_t nt_max = (int64_t)(budget / ((size_t)trace_floats * 4));
     PNR_REQUIRE(nt_max >= 1, PNR_E_HIP, "not enough device memory for one trace's sample stash (%lld B)", trace_floats * 4);
-    const int64_t nwaves = (ntr_all + nt_max - 1) / nt_max;
-    const int64_t NT = (ntr_all + nwaves - 1) / nwaves;
+    const int64_t nwaves = (want + nt_max - 1) / nt_max;
+    const int64_t NT = (want + nwaves - 1) / nwaves;
     const int64_t need_dbg = NT * dbg_iters;
     if (h->cap_traces < NT || h->np != np || h->np_pad != np_pad || h->S != S || h->ni != ni || h->trace_floats != trace_floats ||
         h->cap_dbg < need_dbg || (xfilt && dbg_iters && !h->O.xfilt) || (idxres && dbg_iters && !h->O.idxres) ||
@@ -584,25 +638,45 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
         PNR_HIP(hipMemsetAsync(h->P.stash, 0, (size_t)cap * trace_floats * 4, c->stream));
         PNR_HIP(hipMemsetAsync(h->P.part, 0, (size_t)cap * 2 * np * PSTRIDE * 4, c->stream));
     }
-    PhState P = h->P;
-    P.trace_floats = trace_floats;
-    P.cap = (int)h->cap_traces;
-    P.ngf = ngf; P.rem = rem; P.R = R; P.W = W;
-    TabX X;
-    X.grid = (const Grid *)c->d_grid; X.axes = c->d_axes; X.axes_off = c->d_axes_off; X.wd = c->d_wd;
-    X.ext_v = c->tab.ext_v; X.ext_uw = c->tab.ext_uw;
-    X.stash = nullptr; X.slot_busy = nullptr; X.nslots = 0; X.slot_floats = 0; X.wave_floats = 0;
+    E.P = h->P;
+    E.P.trace_floats = trace_floats;
+    E.P.cap = (int)h->cap_traces;
+    E.P.ngf = ngf; E.P.rem = rem; E.P.R = R; E.P.W = W;
+    E.X.grid = (const Grid *)c->d_grid; E.X.axes = c->d_axes; E.X.axes_off = c->d_axes_off; E.X.wd = c->d_wd;
+    E.X.ext_v = c->tab.ext_v; E.X.ext_uw = c->tab.ext_uw;
+    E.X.stash = nullptr; E.X.slot_busy = nullptr; E.X.nslots = 0; E.X.slot_floats = 0; E.X.wave_floats = 0;
     hipDeviceProp_t prop;
     PNR_HIP(hipGetDeviceProperties(&prop, c->device));
-    const int ncu = prop.multiProcessorCount;
-    hipStream_t st = c->stream;
+    E.ncu = prop.multiProcessorCount;
+    E.np = np; E.ni = ni; E.S = S; E.np_pad = np_pad; E.ng = ngf + (rem > 0 ? 1 : 0); E.dbg_iters = dbg_iters;
+    E.cube_bytes = (size_t)PH_CS * PH_CS * PH_CS;
+    E.upd_lds = ((size_t)np * PSTRIDE + 4 * (size_t)np + (size_t)S * np_pad + 2 + 2 + 8) * 4;
+    E.trace_floats = trace_floats;
+    E.NT = NT;
+    E.h = h;
+    E.max_split = 24;
+    if (const char *e = getenv("PNR_MAX_SPLIT")) E.max_split = std::max(1, atoi(e));
+    PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
+    return PNR_OK;
+}
+
+int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, int32_t *stop_out, pnr_xest *xc, int dbg_iters,
+                         float *xfilt, int32_t *idxres, float *neff, int use_density)
+{
+    if (n == 0) return PNR_OK;
+    PhEnv E;
+    const int64_t ntr_all = 2 * n;
+    int rc = phased_env(c, ntr_all, dbg_iters, xfilt != nullptr, idxres != nullptr, neff != nullptr, E);
+    if (rc) return rc;
+    const Vol &V = E.V; const Tab &T = E.T; const TabX &X = E.X; const PhState &P = E.P;
+    pnr_phased *h = E.h;
+    const int np = E.np, ni = E.ni, S = E.S, np_pad = E.np_pad, ng = E.ng, ncu = E.ncu, max_split = E.max_split;
+    const long long trace_floats = E.trace_floats;
+    const int64_t NT = E.NT;
+    const size_t cube_bytes = E.cube_bytes, upd_lds = E.upd_lds;
+    dbg_iters = E.dbg_iters;
     constexpr int CS = PH_CS;
-    const size_t cube_bytes = (size_t)CS * CS * CS;
-    const size_t upd_lds = ((size_t)np * PSTRIDE + 4 * (size_t)np + (size_t)S * np_pad + 2 + 2 + 8) * 4;
-    const int ng = ngf + (rem > 0 ? 1 : 0);
-    int max_split = 24;
-    if (const char *e = getenv("PNR_MAX_SPLIT")) max_split = std::max(1, atoi(e));
-    PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cube_bytes));
+    hipStream_t st = c->stream;
 
     // A wave's traces are cut into `ngrp` groups that iterate independently on their own streams: while one group
     // samples (VALU / LDS bound, one work-group per CU) another streams its sums from HBM, and the sampling launches of
@@ -679,12 +753,12 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
                 }
                 any = true;
                 const int nsplit = pick_nsplit(q.active, ncu, max_split);
-                hipLaunchKernelGGL(ph_predict, dim3(q.active), dim3(256), 0, q.st, T, X, q.P, q.s6, V, np, ni, it, CS);
+                hipLaunchKernelGGL(ph_predict, dim3(q.active), dim3(256), 0, q.st, T, X, q.P, q.s6, V, np, ni, it, it & 1, CS);
                 // the sampling launches of the groups take turns (a launch fills every CU's LDS): group g samples after
                 // the previous running group's sampling of the same round, so its sums overlap the others' sampling
                 if (have_prev) PNR_HIP(hipStreamWaitEvent(q.st, prev_samp, 0));
                 c->tic(q.st);
-                hipLaunchKernelGGL(ph_sample<CS>, dim3((unsigned)(q.active * nsplit)), dim3(768), cube_bytes, q.st, V, T, X, q.P, np, ni, it, q.active);
+                hipLaunchKernelGGL(ph_sample<CS>, dim3((unsigned)(q.active * nsplit)), dim3(768), cube_bytes, q.st, V, T, X, q.P, np, ni, it, it & 1, q.active);
                 c->toc("smc", 1, q.st);
                 if (G > 1) {
                     PNR_HIP(hipEventRecord(h->ev_samp[g][it % RING], q.st));
@@ -692,9 +766,9 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
                     have_prev = true;
                 }
                 c->tic(q.st);
-                hipLaunchKernelGGL(ph_sums, dim3((unsigned)(q.active * S * ng)), dim3(64), 0, q.st, T, X, q.P, np, np_pad, ni, it);
+                launch_sums(q.active, S * ng, q.st, T, X, q.P, np, np_pad, ni, it, it & 1);
                 c->toc("smc_sums", 1, q.st);
-                hipLaunchKernelGGL(ph_update, dim3(q.active), dim3(256), upd_lds, q.st, V, T, q.P, np, np_pad, ni, it, c->prm.Kc,
+                hipLaunchKernelGGL(ph_update, dim3(q.active), dim3(256), upd_lds, q.st, V, T, q.P, np, np_pad, ni, it, it & 1, c->prm.Kc,
                                    c->prm.znccth, c->prm.neff_ratio, use_density ? c->d_den : nullptr, c->prm.nodepervol, q.O);
                 PNR_HIP(hipMemcpyAsync(&h->h_cnt[g * RING + it % RING], q.P.cnt + ((it + 1) & 1), 4, hipMemcpyDeviceToHost, q.st));
                 PNR_HIP(hipEventRecord(h->ev[g][it % RING], q.st));
@@ -711,5 +785,169 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
         if (O.neff) PNR_HIP(hipMemcpyAsync(neff + t0 * dbg_iters, O.neff, (size_t)nt * dbg_iters * 4, hipMemcpyDeviceToHost, st));
         PNR_HIP(hipStreamSynchronize(st));
     }
+    return PNR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Streaming trace + replay (the production form of the trace loop, Advantra_plugin.cpp:2658-2710).
+//
+// A window of trace slots is kept full: every few SMC steps the host collects the traces that have stopped, replays --
+// strictly in seed order, as far as the finished traces reach -- the bookkeeping of Tracker::trackPos (replay.h), pushes
+// the voxels that replay filled to the density map on the GPU, and hands the free slots to the next seeds (a seed on a
+// voxel the replayed map already saturates is never traced, :2669-2670).  The kernels end a trace at the first
+// iteration whose centroid voxel is saturated in that map (DENSITY stop, tracker.cpp:855).  The map on the GPU only
+// holds replayed -- final -- nodes of lower-ranked seeds, so it can only under-count what the sequential reference
+// would see: no trace is cut earlier than the reference cuts it, and the replay, which applies the true map, yields
+// exactly the node graph of tracing everything to its map-free end (tests: equal to the one-shot graph).
+// Compared with rank batches there is no batch tail during which most CUs idle, and later seeds see a fresher map.
+// ---------------------------------------------------------------------------------------------------------
+int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::Replayer &r, int64_t *iters_out)
+{
+    if (iters_out) *iters_out = 0;
+    if (n == 0) return PNR_OK;
+    int64_t window = 768;
+    if (const char *e = getenv("PNR_WINDOW")) window = std::max(2, atoi(e));
+    window = std::min<int64_t>(window, 2 * n);
+    window += window & 1;
+    // seeds are admitted at most this far beyond the replay frontier (a trace only sees the map of replayed seeds)
+    int64_t look0 = 128, look_pct = 100;
+    if (const char *e = getenv("PNR_LOOK0")) look0 = std::max(1, atoi(e));
+    if (const char *e = getenv("PNR_LOOK_PCT")) look_pct = std::max(0, atoi(e));
+    int poll = 4;
+    if (const char *e = getenv("PNR_POLL")) poll = std::max(1, atoi(e));
+    PhEnv E;
+    int rc = phased_env(c, window, 0, false, false, false, E);
+    if (rc) return rc;
+    pnr_phased *h = E.h;
+    const int NT = (int)(E.NT - (E.NT & 1)); // slots come in pairs (the two directions of a seed)
+    PNR_REQUIRE(NT >= 2, PNR_E_HIP, "not enough device memory for two trace slots");
+    const int np = E.np, ni = E.ni, S = E.S, np_pad = E.np_pad, ng = E.ng;
+    if (h->stream_cap < NT || h->ni != ni) {
+        PNR_HIP(hipDeviceSynchronize());
+        if (h->h_xc) hipHostFree(h->h_xc);
+        if (h->h_flags) hipHostFree(h->h_flags);
+        if (h->h_new) hipHostFree(h->h_new);
+        if (h->h_new_s6) hipHostFree(h->h_new_s6);
+        hipFree(h->d_new); hipFree(h->d_new_s6);
+        h->h_xc = nullptr; h->h_flags = nullptr; h->h_new = nullptr; h->h_new_s6 = nullptr; h->d_new = nullptr; h->d_new_s6 = nullptr;
+        h->stream_cap = 0;
+        PNR_HIP(hipHostMalloc(&h->h_xc, (size_t)NT * ni * sizeof(pnr_xest)));
+        PNR_HIP(hipHostMalloc(&h->h_flags, (size_t)NT * FL_N * 4));
+        PNR_HIP(hipHostMalloc(&h->h_new, (size_t)NT * 4));
+        PNR_HIP(hipHostMalloc(&h->h_new_s6, (size_t)NT * 24));
+        PNR_HIP(hipMalloc(&h->d_new, (size_t)NT * 4));
+        PNR_HIP(hipMalloc(&h->d_new_s6, (size_t)NT * 24));
+        h->stream_cap = NT;
+    }
+    hipStream_t st = c->stream;
+    PhState P = E.P;
+    TraceOut O = h->O;
+    O.xc = (float *)h->h_xc; // the per-iteration records go straight to pinned host memory (32 B per trace and iteration)
+    O.dbg_iters = 0; O.xfilt = nullptr; O.idxres = nullptr; O.neff = nullptr;
+    PNR_HIP(hipMemsetAsync(P.cnt, 0, 2 * 4, st));
+
+    enum : uint8_t { NOT_YET = 0, LAUNCHED = 1, SKIPPED = 2 };
+    struct SeedRec { uint8_t state = NOT_YET; int pending = 0; int32_t T[2] = {0, 0}; std::vector<pnr_xest> xc; };
+    std::vector<SeedRec> rec((size_t)n);
+    std::vector<int> free_slots;
+    for (int k = NT - 1; k >= 0; k--) free_slots.push_back(k);
+    std::vector<int64_t> slot_seed((size_t)NT, -1);
+    std::vector<int> slot_dir((size_t)NT, 0), busy;
+    int64_t next = 0, frontier = 0, iters = 0;
+    int lp = 0, active = 0;
+    const bool timing = getenv("PNR_TRACE_TIMING") != nullptr;
+    int64_t steps = 0, polls = 0;
+    for (;;) {
+        // ---- admission
+        int m = 0;
+        while (!r.stopped && next < n && free_slots.size() >= 2 && next < frontier + std::max<int64_t>(look0, frontier * look_pct / 100)) {
+            const pnr_seed &sd = seeds[next];
+            SeedRec &q = rec[(size_t)next];
+            if (r.seed_saturated(sd)) { q.state = SKIPPED; next++; continue; }
+            q.state = LAUNCHED; q.pending = 2;
+            q.xc.resize((size_t)2 * ni);
+            for (int dir = 0; dir < 2; dir++) {
+                const int slot = free_slots.back();
+                free_slots.pop_back();
+                slot_seed[(size_t)slot] = next; slot_dir[(size_t)slot] = dir;
+                busy.push_back(slot);
+                h->h_new[m] = slot;
+                float *a = h->h_new_s6 + (size_t)m * 6;
+                a[0] = sd.x; a[1] = sd.y; a[2] = sd.z;
+                a[3] = dir ? -sd.vx : sd.vx; a[4] = dir ? -sd.vy : sd.vy; a[5] = dir ? -sd.vz : sd.vz; // trackNeg (tracker.cpp:819-823)
+                m++;
+            }
+            next++;
+        }
+        if (m > 0) {
+            PNR_HIP(hipMemcpyAsync(h->d_new, h->h_new, (size_t)m * 4, hipMemcpyHostToDevice, st));
+            PNR_HIP(hipMemcpyAsync(h->d_new_s6, h->h_new_s6, (size_t)m * 24, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(ph_admit, dim3(1), dim3(256), 0, st, P, h->d_s6, (const int *)h->d_new, (const float *)h->d_new_s6, m, lp, ni);
+            active += m;
+        }
+        if (active > 0) {
+            // ---- `poll` SMC steps over the active list (every trace at its own iteration)
+            for (int k = 0; k < poll; k++) {
+                const int nsplit = pick_nsplit(active, E.ncu, E.max_split);
+                hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
+                c->tic(st);
+                hipLaunchKernelGGL(ph_sample<PH_CS>, dim3((unsigned)(active * nsplit)), dim3(768), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
+                c->toc("smc", 1, st);
+                c->tic(st);
+                launch_sums(active, S * ng, st, E.T, E.X, P, np, np_pad, ni, -1, lp);
+                c->toc("smc_sums", 1, st);
+                hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), E.upd_lds, st, E.V, E.T, P, np, np_pad, ni, -1, lp, c->prm.Kc, c->prm.znccth,
+                                   c->prm.neff_ratio, c->d_den, c->prm.nodepervol, O);
+                lp ^= 1;
+                steps++;
+            }
+            // ---- poll: which traces have stopped?
+            PNR_HIP(hipMemcpyAsync(h->h_flags, P.flags, (size_t)NT * FL_N * 4, hipMemcpyDeviceToHost, st));
+            PNR_HIP(hipMemcpyAsync(h->h_cnt, P.cnt + lp, 4, hipMemcpyDeviceToHost, st));
+            PNR_HIP(hipStreamSynchronize(st));
+            PNR_HIP(hipGetLastError());
+            polls++;
+            active = h->h_cnt[0];
+            size_t keep = 0;
+            for (size_t b = 0; b < busy.size(); b++) {
+                const int slot = busy[b];
+                const int *fl = h->h_flags + (size_t)slot * FL_N;
+                if (!fl[FL_DONE]) { busy[keep++] = slot; continue; }
+                SeedRec &q = rec[(size_t)slot_seed[(size_t)slot]];
+                const int dir = slot_dir[(size_t)slot];
+                const int Tn = fl[FL_T];
+                q.T[dir] = Tn;
+                const int rows = std::min(Tn, ni);
+                if (rows > 0) std::memcpy(q.xc.data() + (size_t)dir * ni, h->h_xc + (size_t)slot * ni, (size_t)rows * sizeof(pnr_xest));
+                q.pending--;
+                iters += std::min(Tn + 1, ni);
+                slot_seed[(size_t)slot] = -1;
+                free_slots.push_back(slot);
+            }
+            busy.resize(keep);
+        }
+        // ---- replay in seed order as far as the finished traces reach, push the new density to the GPU
+        r.touched.clear();
+        while (frontier < n && !r.stopped) {
+            SeedRec &q = rec[(size_t)frontier];
+            if (q.state == NOT_YET || (q.state == LAUNCHED && q.pending > 0)) break;
+            if (q.state == LAUNCHED) { // (a skipped seed sits on a saturated voxel: the replay would skip it as well)
+                r.add(&seeds[frontier], 1, q.T, q.xc.data());
+                std::vector<pnr_xest>().swap(q.xc);
+            }
+            frontier++;
+        }
+        if (!r.touched.empty()) {
+            rc = pnr_density_update(c, r, nullptr);
+            if (rc) return rc;
+        }
+        if (r.stopped) break; // MAX_TRACE_COUNT (:2702): whatever is still running is never looked at
+        if (frontier >= n) break;
+        PNR_REQUIRE(active > 0 || next < n, PNR_E_STATE, "trace scheduler stalled at seed %lld of %lld", (long long)frontier, (long long)n);
+    }
+    if (timing)
+        fprintf(stderr, "[pnr trace] streaming: %lld seeds, window %d slots, %lld steps, %lld polls, %lld iterations, %zu nodes\n", (long long)n, NT,
+                (long long)steps, (long long)polls, (long long)iters, r.nodes.size());
+    if (iters_out) *iters_out = iters;
     return PNR_OK;
 }
