@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--mode", choices=["stacks", "shard"], default="stacks")
     ap.add_argument("--one-shot", action="store_true", help="trace every seed to its map-free end + one replay (no early DENSITY stops)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the untimed full-occupancy measurement of smc_trace")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed full-occupancy measurement of the sampling kernel")
+    ap.add_argument("--driver", choices=["phased", "persistent"], default="phased",
+                    help="SMC scheduler (pnr_set_smc_driver): one launch per phase (default) or one persistent work-group per trace")
     return ap.parse_args()
 
 
@@ -93,6 +95,13 @@ def cpu_baseline(img_dev, sigs, zdist, np_, n_iters_gpu, nvox, nseed_init):
     }
 
 
+def stash_row_floats(np_):
+    """f32 values per template sample and trace in the phased driver's stash: 64 per full group of chains (np particles
+    + the pending centroid) plus the last group's chains rounded up to 16 (pnr_amd/csrc/smc_phased.hip)"""
+    n = np_ + 1
+    return 64 * (n // 64) + (((n % 64) + 15) // 16) * 16
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,6 +126,7 @@ def main():
     torch.cuda.synchronize()
     p = pnr_amd.make_params(sigmas=sigs, np_=a.np, ni=a.ni, zdist=zdist)
     ctx = pnr_amd.Context(p, local)
+    ctx.set_smc_driver(a.driver)
     ctx.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
     ctx.set_profiling(True)
     nvox = S * S * S
@@ -175,9 +185,12 @@ def main():
         units = nvox * (world if a.mode == "stacks" else 1)
         ms_step = 1e3 * dt / a.steps
         value = units / (dt / a.steps) / 1e6
-        km = {g: ctx.kernel_ms(g) for g in ("gauss", "hessian_eigen", "j8", "seed_maxima", "zncc", "smc")}
-        # dominant kernel = smc_trace (one launch per step).  Algorithmic bytes:
-        # 8 corner bytes x sum(M_sigma) samples per particle evaluation, (np+1) evaluations per SMC iteration.
+        km = {g: ctx.kernel_ms(g) for g in ("gauss", "hessian_eigen", "j8", "seed_maxima", "zncc", "smc", "smc_sums")}
+        # dominant kernel: the sampling kernel of the particle filter -- ph_sample (one launch per SMC step over all
+        # active traces; the "smc" timer group) with the phased driver, smc_trace (one launch per batch, sampling +
+        # sums + update) with the persistent one.  Algorithmic bytes: 8 corner bytes x sum(M_sigma)
+        # samples per particle evaluation, (np+1) evaluations per SMC iteration; ph_sample performs every one of them.
+        kname = "ph_sample<54>" if a.driver == "phased" else "smc_trace"
         Mtot = sum(len(ctx.table(f"model_wgt{s}")) for s in range(len(sigs)))
         smc_ms, smc_n = km["smc"]
         evals = st["iters"] * (a.np + 1)
@@ -190,9 +203,9 @@ def main():
         # a known byte count in the same access pattern: scripts/prof_traffic.sh), collected for THIS workload and
         # committed under profiles/; null for any other workload
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_1024_s2000.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_1024_s2000.json" if a.driver == "persistent" else "r01e_traffic_1024_s2000.json")
         if S == 1024 and a.seeds == 2000 and a.np == 200 and a.ni == 200 and not a.one_shot and a.mode == "stacks" and os.path.exists(tpath):
-            tj = json.load(open(tpath)).get("smc_trace", {})
+            tj = json.load(open(tpath)).get("smc_trace" if a.driver == "persistent" else "ph_sample", {})
             if "FETCH_SIZE" in tj and "WRITE_SIZE" in tj:
                 traffic = tj["FETCH_SIZE"]["bytes_per_launch"] + tj["WRITE_SIZE"]["bytes_per_launch"]
         out = {
@@ -204,12 +217,17 @@ def main():
                                    f"first {a.seeds} sorted seeds traced in both directions per stack, tolerance=5, znccth=0.3, step=2, kappa=3",
                        "parallelism": ("1 GPU" if world == 1 else (f"{world} independent stacks, one per GPU; RCCL gather of node graphs" if a.mode == "stacks"
                                        else f"seeds of one stack round-robin over {world} GPUs; RCCL gather of trace records"))},
-            "roofline": {"kernel": "smc_trace", "bound": "hbm", "bytes_per_launch": bytes_launch, "avg_launch_ms": smc_ms / max(smc_n, 1), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": kname, "bound": "hbm", "bytes_per_launch": bytes_launch, "avg_launch_ms": smc_ms / max(smc_n, 1), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "algorithmic gather bytes 8*sum(M_sigma)=%d B per particle evaluation; served from L1/L2, see DESIGN.md" % (8 * Mtot)},
             "roofline_frangi": {"kernels": "gauss_x_u8+gauss_axis(y,z)+hessian_eigen+j8", "bound": "hbm", "achieved": (len(sigs) + 12) * nvox / (fr_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (len(sigs) + 12) * nvox / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "note": "(S+12) B/voxel compulsory bytes over the Frangi kernel group; fp64 eigen-solver is the limiter"},
+            "roofline_sums": None if a.driver != "phased" or km["smc_sums"][0] <= 0 else {
+                "kernel": "ph_sums<32>", "bound": "hbm", "launches": km["smc_sums"][1], "avg_launch_ms": km["smc_sums"][0] / max(km["smc_sums"][1], 1),
+                "achieved": 2.0 * 4 * Mtot * stash_row_floats(a.np) * st["iters"] * a.steps / (km["smc_sums"][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": 2.0 * 4 * Mtot * stash_row_floats(a.np) * st["iters"] * a.steps / (km["smc_sums"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "real bytes: the ordered sums stream every stashed f32 sample twice (mean, then corr): 2 x 4 x sum(M) x %d B per SMC iteration" % stash_row_floats(a.np)},
             "stages_ms": {k: v for k, v in st.items() if k.endswith("_ms")},
             "kernel_ms_per_step": {g: km[g][0] / a.steps for g in km},
             "counts": {k: v for k, v in st.items() if not k.endswith("_ms")},
@@ -225,9 +243,9 @@ def main():
             ms1, n1 = ctx.kernel_ms("smc")
             ev1 = int((T1 + (T1 < a.ni)).sum()) * (a.np + 1)
             out["roofline_full_occupancy"] = {
-                "kernel": "smc_trace", "launches": n1, "avg_launch_ms": ms1 / max(n1, 1), "achieved": 8.0 * Mtot * ev1 / (ms1 * 1e-3) / 1e9,
+                "kernel": kname, "launches": n1, "avg_launch_ms": ms1 / max(n1, 1), "achieved": 8.0 * Mtot * ev1 / (ms1 * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * Mtot * ev1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "Mevals_per_s": ev1 / ms1 / 1e3,
-                "note": "all %d traces in one launch (no early DENSITY stops): %d SMC iterations; measured after the timed region" % (len(T1), ev1 // (a.np + 1))}
+                "note": "all %d traces started together, traced to their map-free end (no early DENSITY stops): %d SMC iterations; measured after the timed region" % (len(T1), ev1 // (a.np + 1))}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(img, list(sigs), zdist, a.np, st["iters"], nvox, st["n_seeds_init"])
         print(json.dumps(out), flush=True)

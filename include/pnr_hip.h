@@ -142,12 +142,14 @@ int pnr_replay_traces(const pnr_params *p, int64_t w, int64_t h, int64_t l, cons
                       int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links,
                       int64_t *n_links, int64_t *n_traces_used);
 
-/* Production form of the trace loop: trace + replay in seed-rank batches (first_batch seeds, doubling up to
- * 1024; <= 0: default 128).  Before each batch the node-density map produced by the replay of the earlier
- * batches is pushed to the GPU, which ends a trace at the first iteration whose centroid voxel is already
- * saturated there (what the reference's DENSITY stop, tracker.cpp:855, would do at the latest), and seeds on
- * saturated voxels are not launched (Advantra_plugin.cpp:2669-2670).  A stale map only under-counts, so the
- * node graph is identical to pnr_trace_batch + pnr_replay_traces.  *n_iterations = SMC iterations run. */
+/* Production form of the trace loop (Advantra_plugin.cpp:2658-2710): trace + replay with early DENSITY stops.  The
+ * node-density map produced by the replay of lower-ranked seeds is kept on the GPU, which ends a trace at the first
+ * iteration whose centroid voxel is already saturated there (what the reference's DENSITY stop, tracker.cpp:855, would
+ * do at the latest), and seeds on saturated voxels are not launched (:2669-2670).  The GPU map only holds replayed
+ * nodes, so it only under-counts and the node graph is identical to pnr_trace_batch + pnr_replay_traces.
+ * Phased driver (default): a window of traces is kept full, finished traces are replayed in seed order and their slots
+ * handed to the next seeds (first_batch is ignored).  Persistent driver: seed-rank batches of first_batch seeds,
+ * doubling up to 1024 (<= 0: default 128).  *n_iterations = SMC iterations run. */
 int pnr_trace_replay(pnr_ctx *ctx, const pnr_seed *seeds, int64_t n, int64_t first_batch, pnr_node *nodes,
                      int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links,
                      int64_t *n_traces_used, int64_t *n_iterations);

@@ -9,6 +9,7 @@
 
 namespace {
 typedef long long i64;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Vol {
     const unsigned char *img;
@@ -255,11 +256,19 @@ __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, c
     Samples<G> r;
 #pragma unroll
     for (int j = 0; j < G; j++) {
-        const float a00 = (float)c[j][0], a01 = (float)c[j][1], a10 = (float)c[j][2], a11 = (float)c[j][3];
-        const float b00 = (float)c[j][4], b01 = (float)c[j][5], b10 = (float)c[j][6], b11 = (float)c[j][7];
+        // (1-fz)*((1-fy)*((1-fx)*a00 + fx*a01) + fy*((1-fx)*a10 + fx*a11)) + fz*((1-fy)*((1-fx)*b00 + fx*b01) + fy*(...b10, b11)),
+        // the z = z1 (a) and z = z1+1 (b) planes side by side in the two halves of packed f32 operations (v_pk_mul_f32 /
+        // v_pk_add_f32: two IEEE single operations per instruction, each rounded exactly like the scalar one)
+        const f32x2 c00 = {(float)c[j][0], (float)c[j][4]}, c01 = {(float)c[j][1], (float)c[j][5]};
+        const f32x2 c10 = {(float)c[j][2], (float)c[j][6]}, c11 = {(float)c[j][3], (float)c[j][7]};
         const float fx = xf[j], fy = yf[j], fz = zf[j];
-        r.v[j] = (1 - fz) * ((1 - fy) * ((1 - fx) * a00 + fx * a01) + (fy) * ((1 - fx) * a10 + fx * a11)) +
-                 (fz) * ((1 - fy) * ((1 - fx) * b00 + fx * b01) + (fy) * ((1 - fx) * b10 + fx * b11));
+        const f32x2 om = (f32x2){1.f, 1.f} - (f32x2){fx, fy};
+        const float omz = 1 - fz;
+        const f32x2 u0 = (f32x2){om.x, om.x} * c00 + (f32x2){fx, fx} * c01;
+        const f32x2 u1 = (f32x2){om.x, om.x} * c10 + (f32x2){fx, fx} * c11;
+        const f32x2 yv = (f32x2){om.y, om.y} * u0 + (f32x2){fy, fy} * u1;
+        const f32x2 zv = (f32x2){omz, fz} * yv;
+        r.v[j] = zv.x + zv.y;
     }
     return r;
 }
@@ -304,8 +313,9 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
                 for (int j = 0; j < G; j++) {
                     const int iw = (iw0 + j < nw) ? iw0 + j : nw - 1; // wave-uniform
                     const float ww = bcast(r_aw, iw);
-                    xs[j] = x1 + ww * f.wx;
-                    ys[j] = y1 + ww * f.wy;
+                    const f32x2 xy = (f32x2){x1, y1} + (f32x2){ww, ww} * (f32x2){f.wx, f.wy}; // packed: same two roundings each
+                    xs[j] = xy.x;
+                    ys[j] = xy.y;
                     zs[j] = z1 + ww * f.wz;
                 }
                 const Samples<G> sm = interp_group<G, CS>(V, B, xs, ys, zs);
@@ -370,8 +380,9 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
                 for (int j = 0; j < G; j++) {
                     const int iw = (iw0 + j < nw) ? iw0 + j : nw - 1;
                     const float ww = bcast(r_aw, iw);
-                    xs[j] = x1 + ww * f.wx;
-                    ys[j] = y1 + ww * f.wy;
+                    const f32x2 xy = (f32x2){x1, y1} + (f32x2){ww, ww} * (f32x2){f.wx, f.wy}; // packed: same two roundings each
+                    xs[j] = xy.x;
+                    ys[j] = xy.y;
                     zs[j] = z1 + ww * f.wz;
                 }
                 const Samples<G> sm = interp_group<G, CS>(V, B, xs, ys, zs);
@@ -416,8 +427,9 @@ __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const F
             for (int j = 0; j < G; j++) {
                 const int iw = (iw0 + j < nw) ? iw0 + j : nw - 1; // wave-uniform
                 const float ww = bcast(r_aw, iw);
-                xs[j] = x1 + ww * f.wx;
-                ys[j] = y1 + ww * f.wy;
+                const f32x2 xy = (f32x2){x1, y1} + (f32x2){ww, ww} * (f32x2){f.wx, f.wy}; // packed: same two roundings each
+                xs[j] = xy.x;
+                ys[j] = xy.y;
                 zs[j] = z1 + ww * f.wz;
             }
             const Samples<G> sm = interp_group<G, CS>(V, B, xs, ys, zs);
@@ -458,8 +470,9 @@ __device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, 
             for (int j = 0; j < G; j++) {
                 const int iw = (iw0 + j < nw) ? iw0 + j : nw - 1; // wave-uniform
                 const float ww = bcast(r_aw, iw);
-                xs[j] = x1 + ww * f.wx;
-                ys[j] = y1 + ww * f.wy;
+                const f32x2 xy = (f32x2){x1, y1} + (f32x2){ww, ww} * (f32x2){f.wx, f.wy}; // packed: same two roundings each
+                xs[j] = xy.x;
+                ys[j] = xy.y;
                 zs[j] = z1 + ww * f.wz;
             }
             const Samples<G> sm = interp_group<G, CS>(V, B, xs, ys, zs);
