@@ -185,7 +185,7 @@ def main():
         units = nvox * (world if a.mode == "stacks" else 1)
         ms_step = 1e3 * dt / a.steps
         value = units / (dt / a.steps) / 1e6
-        km = {g: ctx.kernel_ms(g) for g in ("gauss", "hessian_eigen", "j8", "seed_maxima", "zncc", "smc", "smc_sums")}
+        km = {g: ctx.kernel_ms(g) for g in ("gauss", "hessian_eigen", "j8", "seed_maxima", "zncc", "smc", "smc_sums", "smc_predict", "smc_update")}
         # dominant kernel: the sampling kernel of the particle filter -- ph_sample (one launch per SMC step over all
         # active traces; the "smc" timer group) with the phased driver, smc_trace (one launch per batch, sampling +
         # sums + update) with the persistent one.  Algorithmic bytes: 8 corner bytes x sum(M_sigma)
@@ -193,6 +193,7 @@ def main():
         kname = "ph_sample<54>" if a.driver == "phased" else "smc_trace"
         Mtot = sum(len(ctx.table(f"model_wgt{s}")) for s in range(len(sigs)))
         smc_ms, smc_n = km["smc"]
+        smc_all_ms = sum(km[g][0] for g in ("smc", "smc_sums", "smc_predict", "smc_update"))
         evals = st["iters"] * (a.np + 1)
         # several launches per step (seed-rank batches): bytes per launch / average launch duration
         # = total bytes of the timed region / total smc_trace device time
@@ -231,7 +232,9 @@ def main():
             "stages_ms": {k: v for k, v in st.items() if k.endswith("_ms")},
             "kernel_ms_per_step": {g: km[g][0] / a.steps for g in km},
             "counts": {k: v for k, v in st.items() if not k.endswith("_ms")},
-            "Mevals_per_s_smc": evals * a.steps / smc_ms / 1e3 if smc_ms > 0 else None,
+            # particle evaluations / time of the whole SMC kernel group (sampling + sums + predict + update)
+            "Mevals_per_s_smc": evals * a.steps / smc_all_ms / 1e3 if smc_all_ms > 0 else None,
+            "smc_group_GBs": 8.0 * Mtot * evals * a.steps / (smc_all_ms * 1e-3) / 1e9 if smc_all_ms > 0 else None,
             "smc_launches_per_step": smc_n / a.steps,
             "Mvox_per_s_frangi": nvox / (fr_ms * 1e-3) / 1e6,
         }

@@ -174,7 +174,7 @@ int pnr_get_table(pnr_ctx *ctx, const char *name, void *out, int64_t cap, int64_
 int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
 
 /* Per-kernel-group device time (HIP events on the ctx stream) accumulated since the last reset:
- * groups: "gauss","hessian_eigen","j8","seed_maxima","zncc","smc" (sampling kernel),"smc_sums".  Enabled by set_profiling. */
+ * groups: "gauss","hessian_eigen","j8","seed_maxima","zncc","smc" (sampling kernel; the whole trace kernel of the persistent driver),"smc_sums","smc_predict","smc_update".  Enabled by set_profiling. */
 int pnr_set_profiling(pnr_ctx *ctx, int enable);
 int pnr_get_kernel_ms(pnr_ctx *ctx, const char *group, double *ms, int64_t *launches);
 int pnr_reset_kernel_ms(pnr_ctx *ctx);

@@ -753,7 +753,9 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
                 }
                 any = true;
                 const int nsplit = pick_nsplit(q.active, ncu, max_split);
+                c->tic(q.st);
                 hipLaunchKernelGGL(ph_predict, dim3(q.active), dim3(256), 0, q.st, T, X, q.P, q.s6, V, np, ni, it, it & 1, CS);
+                c->toc("smc_predict", 1, q.st);
                 // the sampling launches of the groups take turns (a launch fills every CU's LDS): group g samples after
                 // the previous running group's sampling of the same round, so its sums overlap the others' sampling
                 if (have_prev) PNR_HIP(hipStreamWaitEvent(q.st, prev_samp, 0));
@@ -768,8 +770,10 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
                 c->tic(q.st);
                 launch_sums(q.active, S * ng, q.st, T, X, q.P, np, np_pad, ni, it, it & 1);
                 c->toc("smc_sums", 1, q.st);
+                c->tic(q.st);
                 hipLaunchKernelGGL(ph_update, dim3(q.active), dim3(256), upd_lds, q.st, V, T, q.P, np, np_pad, ni, it, it & 1, c->prm.Kc,
                                    c->prm.znccth, c->prm.neff_ratio, use_density ? c->d_den : nullptr, c->prm.nodepervol, q.O);
+                c->toc("smc_update", 1, q.st);
                 PNR_HIP(hipMemcpyAsync(&h->h_cnt[g * RING + it % RING], q.P.cnt + ((it + 1) & 1), 4, hipMemcpyDeviceToHost, q.st));
                 PNR_HIP(hipEventRecord(h->ev[g][it % RING], q.st));
             }
@@ -889,15 +893,19 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
             // ---- `poll` SMC steps over the active list (every trace at its own iteration)
             for (int k = 0; k < poll; k++) {
                 const int nsplit = pick_nsplit(active, E.ncu, E.max_split);
+                c->tic(st);
                 hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
+                c->toc("smc_predict", 1, st);
                 c->tic(st);
                 hipLaunchKernelGGL(ph_sample<PH_CS>, dim3((unsigned)(active * nsplit)), dim3(768), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
                 c->toc("smc", 1, st);
                 c->tic(st);
                 launch_sums(active, S * ng, st, E.T, E.X, P, np, np_pad, ni, -1, lp);
                 c->toc("smc_sums", 1, st);
+                c->tic(st);
                 hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), E.upd_lds, st, E.V, E.T, P, np, np_pad, ni, -1, lp, c->prm.Kc, c->prm.znccth,
                                    c->prm.neff_ratio, c->d_den, c->prm.nodepervol, O);
+                c->toc("smc_update", 1, st);
                 lp ^= 1;
                 steps++;
             }
