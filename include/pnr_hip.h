@@ -142,6 +142,21 @@ int pnr_replay_traces(const pnr_params *p, int64_t w, int64_t h, int64_t l, cons
                       int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links,
                       int64_t *n_links, int64_t *n_traces_used);
 
+/* Soma path (params.somaradius > 0; Advantra_plugin.cpp:2426-2448 and soma_extraction1 :1899-1915): xy erosion
+ * (Frangi::imerode, frangi.cpp:880), xy Gaussian of the u8 stack (Frangi::imgaussian, frangi.cpp:786), maxentropy_th
+ * (toolbox.cpp:657), binarise at > threshold, conn3d (toolbox.cpp:245) -> one SOMA node (x, y, z, sig = mean radius,
+ * corr = -FLT_MAX, type 1) per 26-connected region and the map voxel -> node index the seed filter, the replay and the
+ * trace kernels' early stop use.  Must run after pnr_set_volume and before pnr_frangi (it uses the Frangi scratch) whenever
+ * somaradius > 0; with somaradius = 0 it records "no soma".  E8 (nullable, N bytes) receives the eroded + blurred stack. */
+int pnr_soma(pnr_ctx *ctx, uint8_t *E8, int32_t *threshold, int64_t *n_soma);
+/* soma nodes (in node-list order, index k+1) and the sparse label map: foreground voxels in raster order with their node index */
+int pnr_get_soma(pnr_ctx *ctx, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int64_t *vox, int32_t *label,
+                 int64_t cap_vox, int64_t *n_vox);
+/* pnr_replay_traces with the context's dimensions, parameters and soma (the node list then starts dummy, somas, ...) */
+int pnr_replay_traces_ctx(pnr_ctx *ctx, const pnr_seed *seeds, int64_t n, const int32_t *T, const pnr_xest *xc,
+                          pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links,
+                          int64_t *n_links, int64_t *n_traces_used);
+
 /* Production form of the trace loop (Advantra_plugin.cpp:2658-2710): trace + replay with early DENSITY stops.  The
  * node-density map produced by the replay of lower-ranked seeds is kept on the GPU, which ends a trace at the first
  * iteration whose centroid voxel is already saturated there (what the reference's DENSITY stop, tracker.cpp:855, would
@@ -174,7 +189,7 @@ int pnr_get_table(pnr_ctx *ctx, const char *name, void *out, int64_t cap, int64_
 int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
 
 /* Per-kernel-group device time (HIP events on the ctx stream) accumulated since the last reset:
- * groups: "gauss","hessian_eigen","j8","seed_maxima","zncc","smc" (sampling kernel; the whole trace kernel of the persistent driver),"smc_sums","smc_predict","smc_update".  Enabled by set_profiling. */
+ * groups: "gauss","hessian_eigen","j8","seed_maxima","soma","zncc","smc" (sampling kernel; the whole trace kernel of the persistent driver),"smc_sums","smc_predict","smc_update".  Enabled by set_profiling. */
 int pnr_set_profiling(pnr_ctx *ctx, int enable);
 int pnr_get_kernel_ms(pnr_ctx *ctx, const char *group, double *ms, int64_t *launches);
 int pnr_reset_kernel_ms(pnr_ctx *ctx);

@@ -1061,10 +1061,36 @@ static int neighbours(i64 i, int N, int M, int P, int vol, i64 *out)
     return n;
 }
 
+static i64 replay_impl(const float *seeds, i64 nseeds, const int *T, const float *xc, int niter,
+                       int w, int h, int l, int nodespervol, int vol, int max_trace_count, const int32_t *smap,
+                       const float *soma4, i64 n_soma,
+                       orc_node *nodes, i64 cap_nodes, int32_t *links, i64 cap_links,
+                       i64 *nlinks, i64 *ntraces_used);
+
 i64 orc_replay(const float *seeds, i64 nseeds, const int *T, const float *xc, int niter,
                int w, int h, int l, int nodespervol, int vol, int max_trace_count,
                orc_node *nodes, i64 cap_nodes, int32_t *links, i64 cap_links,
                i64 *nlinks, i64 *ntraces_used)
+{
+    return replay_impl(seeds, nseeds, T, xc, niter, w, h, l, nodespervol, vol, max_trace_count, NULL, NULL, 0, nodes, cap_nodes, links,
+                       cap_links, nlinks, ntraces_used);
+}
+
+i64 orc_replay_soma(const float *seeds, i64 nseeds, const int *T, const float *xc, int niter,
+                    int w, int h, int l, int nodespervol, int vol, int max_trace_count, const int32_t *smap,
+                    const float *soma4, i64 n_soma,
+                    orc_node *nodes, i64 cap_nodes, int32_t *links, i64 cap_links,
+                    i64 *nlinks, i64 *ntraces_used)
+{
+    return replay_impl(seeds, nseeds, T, xc, niter, w, h, l, nodespervol, vol, max_trace_count, smap, soma4, n_soma, nodes, cap_nodes,
+                       links, cap_links, nlinks, ntraces_used);
+}
+
+static i64 replay_impl(const float *seeds, i64 nseeds, const int *T, const float *xc, int niter,
+                       int w, int h, int l, int nodespervol, int vol, int max_trace_count, const int32_t *smap,
+                       const float *soma4, i64 n_soma,
+                       orc_node *nodes, i64 cap_nodes, int32_t *links, i64 cap_links,
+                       i64 *nlinks, i64 *ntraces_used)
 {
     i64 size = (i64)w * h * l, nn = 0, nl = 0;
     uint8_t *den = (uint8_t *)calloc((size_t)size, 1);
@@ -1076,6 +1102,15 @@ i64 orc_replay(const float *seeds, i64 nseeds, const int *T, const float *xc, in
         nodes[0].type = 7;
     }
     nn = 1;
+    for (i64 k = 0; k < n_soma; k++) { /* Node(x, y, z, r, SOMA): v = 0, corr = -FLT_MAX (node.cpp:68-79) */
+        if (nn < cap_nodes) {
+            memset(&nodes[nn], 0, sizeof(orc_node));
+            nodes[nn].x = soma4[4 * k]; nodes[nn].y = soma4[4 * k + 1]; nodes[nn].z = soma4[4 * k + 2]; nodes[nn].sig = soma4[4 * k + 3];
+            nodes[nn].corr = -FLT_MAX;
+            nodes[nn].type = 1;
+        }
+        nn++;
+    }
     int trace_count = 0;
 #define LINK(a, b) do { if (nl < cap_links) { links[2 * nl] = (int32_t)(a); links[2 * nl + 1] = (int32_t)(b); } nl++; } while (0)
     for (i64 s = 0; s < nseeds; ++s) {
@@ -1091,6 +1126,11 @@ i64 orc_replay(const float *seeds, i64 nseeds, const int *T, const float *xc, in
                 if (i < T[j]) {
                     const float *e = X + i * 8;
                     i64 crd = (i64)(int)roundf(e[XC_Z]) * w * h + (i64)(int)roundf(e[XC_Y]) * w + (int)roundf(e[XC_X]);
+                    if (smap && smap[crd] > 0) { /* SOMA reached: link to its node and stop (tracker.cpp:858-869) */
+                        if (i > 0) LINK(smap[crd], nn - 1);
+                        ti_limit = i;
+                        break;
+                    }
                     if ((int)den[crd] >= nodespervol) { /* DENSITY */
                         if (i > 0) LINK(nidx[crd], nn - 1);
                         ti_limit = i;

@@ -107,6 +107,24 @@ int64_t orc_replay(const float *seeds, int64_t nseeds, const int *T, const float
                    orc_node *nodes, int64_t cap_nodes, int32_t *links, int64_t cap_links,
                    int64_t *nlinks, int64_t *ntraces_used);
 
+/* the same with a soma map (tracker.cpp:858-869): smap[voxel] > 0 = index of the SOMA node that owns the voxel; the node
+ * list starts with the dummy node followed by the n_soma soma nodes (x, y, z, r each; Advantra_plugin.cpp:1911-1914) */
+int64_t orc_replay_soma(const float *seeds, int64_t nseeds, const int *T, const float *xc, int niter,
+                        int w, int h, int l, int nodespervol, int vol, int max_trace_count, const int32_t *smap,
+                        const float *soma4, int64_t n_soma,
+                        orc_node *nodes, int64_t cap_nodes, int32_t *links, int64_t cap_links,
+                        int64_t *nlinks, int64_t *ntraces_used);
+
+/* ---------- soma path, pnr_oracle_soma.c ---------- */
+void orc_imerode_xy(const uint8_t *I, int w, int h, int l, float rad, uint8_t *E);
+void orc_imgaussian_u8_xy(uint8_t *I, int w, int h, int l, float sig);
+unsigned char orc_maxentropy_hist(const int64_t *hist256);
+unsigned char orc_maxentropy_th(const uint8_t *img, int64_t size);
+int64_t orc_conn3d(const uint8_t *inimg, int w, int h, int l, int32_t *lab, int diagonal, int values_over, int min_reg_size,
+                   float *xc, float *yc, float *zc, float *rc, int64_t cap);
+int64_t orc_soma_extract(const uint8_t *img, int w, int h, int l, int somaradius, uint8_t *E8, int *th_out, int32_t *smap,
+                         float *nodes4, int64_t cap);
+
 /* ---------- graph post-processing (Advantra_plugin.cpp:2096-2181), pnr_oracle_recon.c ---------- */
 int64_t orc_reconstruct(const orc_node *nodes, int64_t n_nodes, const int32_t *links, int64_t n_links, float trace_rsmpl,
                         float sig2radius, int refine_iter, float epsilon2, float group_radius, int tree_size_min,

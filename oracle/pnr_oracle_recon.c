@@ -159,6 +159,11 @@ static void group1(nvec *nX, nvec *nY, float rad)
     for (long i = 0; i < n; i++) X2Y[i] = -1;
     X2Y[0] = 0;
     nv_push(nY, node_copy(&nX->v[0]));
+    for (long i = 1; i < n; ++i) /* soma nodes as independent groups at the beginning (:1580-1588) */
+        if (nX->v[i].type == 1) {
+            X2Y[i] = nY->n;
+            nv_push(nY, node_copy(&nX->v[i]));
+        }
     for (long i = 1; i < n; ++i) {
         long ci = ord[i].idx;
         if (X2Y[ci] != -1) continue;

@@ -30,6 +30,16 @@ void ref_imgaussian3d(unsigned char *I, int w, int h, int l, float sig, float zd
     Frangi::imgaussian(I, w, h, l, sig, zdist, F); // frangi.cpp:647
 }
 
+void ref_imerode_xy(unsigned char *I, int w, int h, int l, float rad, unsigned char *E)
+{
+    Frangi::imerode(I, w, h, l, rad, E); // frangi.cpp:880 (the xy erosion the soma path calls, Advantra_plugin.cpp:2431)
+}
+
+void ref_imgaussian_u8_xy(unsigned char *I, int w, int h, int l, float sig)
+{
+    Frangi::imgaussian(I, w, h, l, sig); // frangi.cpp:786, in place (Advantra_plugin.cpp:2437)
+}
+
 void ref_hessian3d(unsigned char *I, int w, int h, int l, float sig, float zdist,
                    float *Dzz, float *Dyy, float *Dyz, float *Dxx, float *Dxy, float *Dxz)
 {

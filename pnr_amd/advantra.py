@@ -199,7 +199,7 @@ def advantra_func(infiles, paras, device=0, rng_seed=42, image=None, verbose=Tru
     img = image if image is not None else _load_stack(infiles[0])
     p = make_params(sigmas=sig, somaradius=somaradius, tolerance=tolerance, znccth=znccth, kappa=kappa, step=step, ni=ni,
                     np_=npc, zdist=zdist, nodepervol=nodepervol, vol=vol, rng_seed=rng_seed)
-    ctx = Context(p, device)  # raises for somaradius>0: soma path is not on the accelerated path
+    ctx = Context(p, device)
     res = run_pipeline(ctx, img, verbose=verbose)
     if infiles:
         out = f"{infiles[0]}_Advantra{out_suffix}.swc"
@@ -216,6 +216,8 @@ def run_pipeline(ctx, img, verbose=False, max_seeds=None, one_shot=False, recons
     import time
     t = [time.time()]
     ctx.set_volume(img) if isinstance(img, np.ndarray) else None
+    soma = ctx.soma() if ctx.p.somaradius > 0 else None  # SOMA EXTR. (Advantra_plugin.cpp:2426-2486), before Frangi
+    t[0] = time.time() if soma is None else t[0]
     jmin, jmax = ctx.frangi(); t.append(time.time())
     seeds_init = ctx.extract_seeds(); t.append(time.time())
     seeds = ctx.score_filter_sort(seeds_init); t.append(time.time())
@@ -235,5 +237,5 @@ def run_pipeline(ctx, img, verbose=False, max_seeds=None, one_shot=False, recons
         for nm, a, b in zip(names, t[:-1], t[1:]):
             print(f"{nm}... {b - a:.3f} sec.")
         print(f"{len(seeds_init) / 1000.0}k seeds -> {len(seeds) / 1000.0}k seeds, {ntr} traces, {len(nodes) - 1} nodes")
-    return dict(Jmin=jmin, Jmax=jmax, seeds_init=seeds_init, seeds=seeds, T=T, stop=stop, xc=xc, nodes=nodes, links=links,
+    return dict(soma=soma, Jmin=jmin, Jmax=jmax, seeds_init=seeds_init, seeds=seeds, T=T, stop=stop, xc=xc, nodes=nodes, links=links,
                 ntraces=ntr, iters=iters, tree=tree, parent=parent, times=np.diff(t))

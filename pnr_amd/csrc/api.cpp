@@ -79,7 +79,7 @@ static int validate(const pnr_params &p)
     }
     // messages follow Advantra_plugin.cpp:317-326
     PNR_REQUIRE(p.somaradius >= 0, PNR_E_ARG, "somaradius out of range");
-    PNR_REQUIRE(p.somaradius == 0, PNR_E_ARG, "somaradius>0 (soma detection) is outside the accelerated path");
+    PNR_REQUIRE(p.somaradius <= 21, PNR_E_ARG, "somaradius %d too large (Gaussian radius 3*somaradius > 64)", p.somaradius);
     PNR_REQUIRE(p.tolerance >= 0, PNR_E_ARG, "tolerance out of range");
     PNR_REQUIRE(p.znccth >= 0 && p.znccth <= 1, PNR_E_ARG, "znccth out of range");
     PNR_REQUIRE(p.kappa >= 0 && p.kappa <= 5, PNR_E_ARG, "kappa out of range");
@@ -326,6 +326,16 @@ int pnr_score_filter_sort_seeds(pnr_ctx *c, pnr_seed *seeds, int64_t n, int64_t 
     PNR_REQUIRE(c && n_out && (n == 0 || seeds), PNR_E_ARG, "null argument");
     *n_out = 0;
     if (n == 0) return PNR_OK;
+    if (c->prm.somaradius > 0) { // seeds inside a soma are dropped before they are scored (:2561-2564)
+        PNR_REQUIRE(c->have_soma, PNR_E_STATE, "somaradius > 0: call pnr_soma before the seeds are filtered");
+        int64_t m = 0;
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t j = (int64_t)(int)std::round(seeds[i].z) * c->w * c->h + (int64_t)(int)std::round(seeds[i].y) * c->w + (int)std::round(seeds[i].x);
+            if (c->soma_map.find(j) == c->soma_map.end()) seeds[m++] = seeds[i];
+        }
+        n = m;
+        if (n == 0) return PNR_OK;
+    }
     std::vector<float> pd((size_t)n * 6), corr((size_t)n);
     for (int64_t i = 0; i < n; i++) {
         float *q = &pd[(size_t)i * 6];
@@ -357,7 +367,48 @@ int pnr_trace_batch(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T, in
     return pnr_trace_run(c, seeds, n, T, stop, xc, dbg_iters, xfilt, idxres, neff, /*use_density*/ 0);
 }
 
+// ---- soma path ---------------------------------------------------------------------------
+int pnr_soma(pnr_ctx *c, uint8_t *E8_out, int32_t *threshold, int64_t *n_soma)
+{
+    PNR_REQUIRE(c, PNR_E_ARG, "null ctx");
+    PNR_HIP(hipSetDevice(c->device));
+    int rc = pnr_soma_run(c, E8_out, threshold);
+    if (rc) return rc;
+    if (n_soma) *n_soma = (int64_t)c->soma_nodes.size();
+    return PNR_OK;
+}
+
+int pnr_get_soma(pnr_ctx *c, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int64_t *vox, int32_t *lab, int64_t cap_vox, int64_t *n_vox)
+{
+    PNR_REQUIRE(c, PNR_E_ARG, "null ctx");
+    PNR_REQUIRE(c->have_soma, PNR_E_STATE, "pnr_soma has not run");
+    if (n_nodes) *n_nodes = (int64_t)c->soma_nodes.size();
+    if (n_vox) *n_vox = (int64_t)c->soma_vox.size();
+    if (nodes) std::memcpy(nodes, c->soma_nodes.data(), sizeof(pnr_node) * (size_t)std::min<int64_t>(cap_nodes, (int64_t)c->soma_nodes.size()));
+    const size_t m = (size_t)std::min<int64_t>(cap_vox, (int64_t)c->soma_vox.size());
+    if (vox) std::memcpy(vox, c->soma_vox.data(), 8 * m);
+    if (lab) std::memcpy(lab, c->soma_lab.data(), 4 * m);
+    return PNR_OK;
+}
+
 // ---- host replay ------------------------------------------------------------------------
+int pnr_replay_traces_ctx(pnr_ctx *c, const pnr_seed *seeds, int64_t n, const int32_t *T, const pnr_xest *xc, pnr_node *nodes,
+                          int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used)
+{
+    PNR_REQUIRE(c && n_nodes && n_links && (n == 0 || (seeds && T && xc)), PNR_E_ARG, "null argument");
+    PNR_REQUIRE(c->w > 0, PNR_E_STATE, "no volume set");
+    PNR_REQUIRE(c->prm.somaradius == 0 || c->have_soma, PNR_E_STATE, "somaradius > 0: call pnr_soma first");
+    pnr::Replayer r(c->prm, c->w, c->h, c->l);
+    r.set_soma(&c->soma_map, c->soma_nodes);
+    r.add(seeds, n, T, xc);
+    *n_nodes = (int64_t)r.nodes.size();
+    *n_links = (int64_t)r.links.size() / 2;
+    if (nodes) std::memcpy(nodes, r.nodes.data(), sizeof(pnr_node) * (size_t)std::min<int64_t>(cap_nodes, *n_nodes));
+    if (links) std::memcpy(links, r.links.data(), 8 * (size_t)std::min<int64_t>(cap_links, *n_links));
+    if (n_traces_used) *n_traces_used = r.trace_count;
+    return PNR_OK;
+}
+
 int pnr_replay_traces(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n,
                       const int32_t *T, const pnr_xest *xc, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes,
                       int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used)
@@ -390,7 +441,9 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
     PNR_REQUIRE(c->d_img, PNR_E_STATE, "no volume set");
     PNR_HIP(hipSetDevice(c->device));
     const int ni = c->prm.ni;
+    PNR_REQUIRE(c->prm.somaradius == 0 || c->have_soma, PNR_E_STATE, "somaradius > 0: call pnr_soma first");
     pnr::Replayer r(c->prm, c->w, c->h, c->l);
+    r.set_soma(&c->soma_map, c->soma_nodes);
     int rc = pnr_density_reset(c);
     if (rc) return rc;
     int64_t iters = 0;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace pnr {
@@ -103,6 +104,13 @@ struct pnr_ctx {
     struct pnr_phased *phased = nullptr; // state of the launch-per-phase SMC driver (smc_phased.hip)
     int smc_driver = 0;                  // 0: launch per phase (default), 1: one persistent work-group per trace
 
+    // soma path (somaradius > 0): one SOMA node per region, sparse voxel -> node-index map (soma.hip)
+    std::vector<pnr_node> soma_nodes;
+    std::vector<int64_t> soma_vox;   // foreground voxels in raster order
+    std::vector<int32_t> soma_lab;   // their region = index in the node list (1-based)
+    std::unordered_map<int64_t, int32_t> soma_map;
+    bool have_soma = false;
+
     // seeds
     unsigned char *h_j8 = nullptr; // pinned staging buffer for the J8 download
     size_t h_j8_cap = 0;
@@ -168,6 +176,7 @@ int pnr_frangi_run(pnr_ctx *c, float *Jmin, float *Jmax);
 int pnr_gaussian_run(pnr_ctx *c, float sig, float *d_out /*device N floats*/);
 int pnr_hessian_run(pnr_ctx *c, float sig, float *const d_out[6]);
 int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1);
+int pnr_soma_run(pnr_ctx *c, uint8_t *E8_out, int32_t *threshold);
 int pnr_zncc_run(pnr_ctx *c, const float *h_pos_dir, int64_t n, float *h_corr, float *h_sig);
 int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T, int32_t *stop, pnr_xest *xc,
                   int dbg_iters, float *xfilt, int32_t *idxres, float *neff, int use_density);

@@ -55,6 +55,7 @@ struct Replayer {
     std::vector<int64_t> touched;  // voxels whose density changed since clear_touched()
     int trace_count = 0;
     bool stopped = false;          // MAX_TRACE_COUNT reached (:2702)
+    const std::unordered_map<int64_t, int32_t> *soma = nullptr; // smap: voxel -> index of its SOMA node (> 0)
 
     Replayer(const pnr_params &p, int64_t w, int64_t h, int64_t l) : prm(p), W((int)w), H((int)h), L((int)l)
     {
@@ -64,6 +65,18 @@ struct Replayer {
         d.corr = -FLT_MAX;
         d.type = 7;
         nodes.push_back(d);
+    }
+    // soma nodes follow the dummy node (soma_extraction1, Advantra_plugin.cpp:1911-1914); call before the first add()
+    void set_soma(const std::unordered_map<int64_t, int32_t> *map, const std::vector<pnr_node> &soma_nodes)
+    {
+        soma = (map && !map->empty()) ? map : nullptr;
+        nodes.insert(nodes.end(), soma_nodes.begin(), soma_nodes.end());
+    }
+    int soma_at(int64_t v) const
+    {
+        if (!soma) return 0;
+        auto it = soma->find(v);
+        return it == soma->end() ? 0 : (int)it->second;
     }
     int64_t voxel(float x, float y, float z) const
     {
@@ -98,6 +111,11 @@ struct Replayer {
                     if (i >= T[j]) { ti_limit = i; break; } // iter*New returned false
                     const pnr_xest &e = X[i];
                     const int64_t crd = voxel(e.x, e.y, e.z);
+                    if (const int sn = soma_at(crd)) { // soma reached: link with its node, stop the trace (tracker.cpp:858-869)
+                        if (i > 0) { links.push_back(sn); links.push_back((int32_t)(nodes.size() - 1)); }
+                        ti_limit = i;
+                        break;
+                    }
                     if (den_at(crd) >= prm.nodepervol) { // density limit: link to the node that owns the voxel
                         if (i > 0) { links.push_back(cells[crd].nidx); links.push_back((int32_t)(nodes.size() - 1)); }
                         ti_limit = i;

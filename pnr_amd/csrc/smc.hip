@@ -694,6 +694,20 @@ int pnr_density_reset(pnr_ctx *c)
     }
     PNR_HIP(hipMemsetAsync(c->d_den, 0, (size_t)c->N, c->stream));
     PNR_HIP(hipStreamSynchronize(c->stream)); // trace jobs run on their own streams
+    if (!c->soma_vox.empty()) {
+        // a trace that reaches a soma voxel stops there in the replay (tracker.cpp:858-869): for the kernels' early stop
+        // the soma is simply saturated density
+        const size_t n = c->soma_vox.size();
+        long long *d_idx = nullptr;
+        unsigned char *d_val = nullptr;
+        PNR_HIP(hipMalloc(&d_idx, n * 8));
+        PNR_HIP(hipMalloc(&d_val, n));
+        PNR_HIP(hipMemcpyAsync(d_idx, c->soma_vox.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+        PNR_HIP(hipMemsetAsync(d_val, 0xff, n, c->stream));
+        hipLaunchKernelGGL(den_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_den, (const i64 *)d_idx, (const unsigned char *)d_val, (int)n);
+        PNR_HIP(hipStreamSynchronize(c->stream));
+        hipFree(d_idx); hipFree(d_val);
+    }
     return PNR_OK;
 }
 

@@ -289,8 +289,19 @@ bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *>
         return true;
     }
     Result R;
+    bool ok = true;
+    if (p.somaradius > 0) { // SOMA EXTR. (:2426-2486): erosion, xy blur, max-entropy threshold, regions -> soma nodes
+        auto ts = clk::now();
+        int32_t th = 0;
+        int64_t nsoma = 0;
+        ok = pnr_soma(ctx, nullptr, &th, &nsoma) == PNR_OK;
+        printf("imerode(%d) imgaussian(%d) maxentropy_th() %d  %lld soma regions  %.3f sec.\n", p.somaradius, p.somaradius, (int)th, (long long)nsoma,
+               std::chrono::duration<double>(clk::now() - ts).count());
+    } else {
+        printf("no soma detection\n");
+    }
     auto t0 = clk::now();
-    bool ok = pnr_frangi(ctx, &R.Jmin, &R.Jmax) == PNR_OK; // :2496-2512
+    ok = ok && pnr_frangi(ctx, &R.Jmin, &R.Jmax) == PNR_OK; // :2496-2512
     auto t1 = clk::now();
     const pnr_seed *found = nullptr;
     int64_t nfound = 0;

@@ -158,6 +158,11 @@ void group_spheres(List &src, List &dst, float rad)
     to[0] = 0;
     dst.clear();
     dst.push_back(src[0]);
+    for (size_t i = 1; i < n; i++) // soma nodes are groups of their own, ahead of everything else (:1581-1588)
+        if (src[i].type == 1) {
+            to[i] = (int)dst.size();
+            dst.push_back(src[i]);
+        }
     const Grid grid(src, std::max(2.0f, rad));
     std::vector<int> cand;
     const float r2 = rad * rad;

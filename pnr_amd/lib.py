@@ -82,6 +82,9 @@ def load():
     L.pnr_trace_replay.argtypes = [vp, vp, i64, i64, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.pnr_reconstruct.argtypes = [vp, i64, vp, i64, C.c_float, C.c_float, i32, C.c_float, C.c_float, i32, vp, vp, i64, C.POINTER(i64)]
     L.pnr_get_table.argtypes = [vp, C.c_char_p, vp, i64, C.POINTER(i64)]
+    L.pnr_soma.argtypes = [vp, vp, C.POINTER(C.c_int32), C.POINTER(i64)]
+    L.pnr_get_soma.argtypes = [vp, vp, i64, C.POINTER(i64), vp, vp, i64, C.POINTER(i64)]
+    L.pnr_replay_traces_ctx.argtypes = [vp, vp, i64, vp, vp, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64)]
     L.pnr_set_profiling.argtypes = [vp, i32]
     L.pnr_set_smc_driver.argtypes = [vp, i32]
     L.pnr_get_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
@@ -97,7 +100,7 @@ def load():
 EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", "pnr_set_stream", "pnr_synchronize",
            "pnr_set_volume", "pnr_set_volume_device", "pnr_frangi", "pnr_get_frangi", "pnr_gaussian", "pnr_hessian",
            "pnr_set_j8_v", "pnr_extract_seeds", "pnr_extract_seeds_range", "pnr_zncc_batch",
-           "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_trace_replay", "pnr_reconstruct", "pnr_get_table", "pnr_set_profiling", "pnr_set_smc_driver",
+           "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_replay_traces_ctx", "pnr_soma", "pnr_get_soma", "pnr_trace_replay", "pnr_reconstruct", "pnr_get_table", "pnr_set_profiling", "pnr_set_smc_driver",
            "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch"]
 
 
@@ -244,7 +247,38 @@ class Context:
         return T, stop, xc, dbg
 
     def replay(self, seeds, T, xc):
-        return replay(self.p, self.shape, seeds, T, xc)
+        """host replay of the trace bookkeeping with this context's parameters, dimensions and soma (pnr_replay_traces_ctx)"""
+        s = np.ascontiguousarray(seeds, SEED_DT)
+        T = np.ascontiguousarray(T, np.int32)
+        xc = np.ascontiguousarray(xc, XEST_DT)
+        cap = int(T.sum()) + 2 + 4096
+        while True:
+            nodes = np.zeros(cap, NODE_DT)
+            links = np.zeros((2 * cap + 2, 2), np.int32)
+            nn, nl, nt = C.c_int64(), C.c_int64(), C.c_int64()
+            check(self.L.pnr_replay_traces_ctx(self.h, s.ctypes.data, len(s), T.ctypes.data, xc.ctypes.data, nodes.ctypes.data, cap,
+                                               C.byref(nn), links.ctypes.data, len(links), C.byref(nl), C.byref(nt)))
+            if nn.value <= cap and nl.value <= len(links):
+                return nodes[:nn.value].copy(), links[:nl.value].copy(), nt.value
+            cap = int(nn.value) + 2
+
+    # ---- soma path (somaradius > 0) ----
+    def soma(self, want_e8=False):
+        """pnr_soma: threshold, soma nodes, sparse label map (voxel index, node index) [, the eroded + blurred stack]"""
+        l, h, w = self.shape
+        E8 = np.zeros((l, h, w), np.uint8) if want_e8 else None
+        th, n = C.c_int32(), C.c_int64()
+        check(self.L.pnr_soma(self.h, E8.ctypes.data if want_e8 else None, C.byref(th), C.byref(n)))
+        nn, nv = C.c_int64(), C.c_int64()
+        check(self.L.pnr_get_soma(self.h, None, 0, C.byref(nn), None, None, 0, C.byref(nv)))
+        nodes = np.zeros(nn.value, NODE_DT)
+        vox = np.zeros(nv.value, np.int64)
+        lab = np.zeros(nv.value, np.int32)
+        check(self.L.pnr_get_soma(self.h, nodes.ctypes.data, len(nodes), C.byref(nn), vox.ctypes.data, lab.ctypes.data, len(vox), C.byref(nv)))
+        out = dict(threshold=th.value, nodes=nodes, vox=vox, lab=lab)
+        if want_e8:
+            out["E8"] = E8
+        return out
 
     def trace_replay(self, seeds, first_batch=0, cap_nodes=None):
         """batched trace + replay (pnr_trace_replay): nodes, links, traces used, SMC iterations run"""

@@ -62,6 +62,19 @@ def load_oracle():
     L.orc_replay.argtypes = [f32p, C.c_int64, i32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_void_p, C.c_int64, i32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.orc_replay.restype = C.c_int64
+    L.orc_replay_soma.argtypes = [f32p, C.c_int64, i32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, f32p, C.c_int64,
+                                  C.c_void_p, C.c_int64, i32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.orc_replay_soma.restype = C.c_int64
+    L.orc_imerode_xy.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_float, u8p]
+    L.orc_imgaussian_u8_xy.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_float]
+    L.orc_maxentropy_th.argtypes = [u8p, C.c_int64]
+    L.orc_maxentropy_th.restype = C.c_ubyte
+    L.orc_maxentropy_hist.argtypes = [np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
+    L.orc_maxentropy_hist.restype = C.c_ubyte
+    L.orc_conn3d.argtypes = [u8p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, C.c_int64]
+    L.orc_conn3d.restype = C.c_int64
+    L.orc_soma_extract.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.POINTER(C.c_int), i32p, f32p, C.c_int64]
+    L.orc_soma_extract.restype = C.c_int64
     L.orc_reconstruct.argtypes = [C.c_void_p, C.c_int64, i32p, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int,
                                   C.c_void_p, i32p, C.c_int64]
     L.orc_reconstruct.restype = C.c_int64
@@ -82,6 +95,8 @@ def load_ref():
     L.ref_eigen3.argtypes = [f64p, f64p, f64p]
     L.ref_frangi3d.argtypes = [u8p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                f32p, C.POINTER(C.c_float), C.POINTER(C.c_float), u8p, u8p, u8p]
+    L.ref_imerode_xy.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_float, u8p]
+    L.ref_imgaussian_u8_xy.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_float]
     L.ref_extract_seeds.argtypes = [C.c_double, u8p, C.c_int, C.c_int, C.c_int, u8p, u8p, u8p, f32p, C.c_int64]
     L.ref_extract_seeds.restype = C.c_int64
     return L
@@ -173,12 +188,32 @@ class Tracker:
         return T, stop.value, xc, xf, idx, neff
 
 
-def replay(L, seeds, T, xc, ni, shape, nodespervol, vol, max_trace_count=5000):
+def soma_extract(L, img, somaradius, cap=4096):
+    """(E8, threshold, smap, soma nodes (x, y, z, r)) of the soma path (Advantra_plugin.cpp:2426-2448)"""
+    l, h, w = img.shape
+    img = np.ascontiguousarray(img, np.uint8)
+    E8 = np.zeros_like(img)
+    smap = np.zeros(img.shape, np.int32)
+    nodes4 = np.zeros((cap, 4), np.float32)
+    th = C.c_int()
+    n = L.orc_soma_extract(img, w, h, l, int(somaradius), E8, C.byref(th), smap.reshape(-1), nodes4.reshape(-1), cap)
+    assert n <= cap
+    return E8, th.value, smap, nodes4[:n].copy()
+
+
+def replay(L, seeds, T, xc, ni, shape, nodespervol, vol, max_trace_count=5000, smap=None, soma4=None):
     l, h, w = shape
-    cap = int(T.sum()) + 2
+    nsoma = 0 if soma4 is None else len(soma4)
+    cap = int(T.sum()) + 2 + nsoma
     nodes = np.zeros(cap, NODE_DT)
     links = np.zeros((2 * cap + 2, 2), np.int32)
     nl, nt = C.c_int64(), C.c_int64()
+    if smap is not None:
+        nn = L.orc_replay_soma(np.ascontiguousarray(seeds, np.float32), len(seeds), np.ascontiguousarray(T, np.int32),
+                               np.ascontiguousarray(xc, np.float32), ni, w, h, l, nodespervol, vol, max_trace_count,
+                               np.ascontiguousarray(smap, np.int32).reshape(-1), np.ascontiguousarray(soma4, np.float32).reshape(-1), nsoma,
+                               nodes.ctypes.data, cap, links, len(links), C.byref(nl), C.byref(nt))
+        return nodes[:nn].copy(), links[:nl.value].copy(), nt.value
     nn = L.orc_replay(np.ascontiguousarray(seeds, np.float32), len(seeds), np.ascontiguousarray(T, np.int32),
                       np.ascontiguousarray(xc, np.float32), ni, w, h, l, nodespervol, vol, max_trace_count,
                       nodes.ctypes.data, cap, links, len(links), C.byref(nl), C.byref(nt))

@@ -123,3 +123,15 @@ def synth_torch(w, h, l, seed=1, zdist=1.0, noise=10, device="cuda"):
         nz = (x % (noise + 1)).to(torch.float32).reshape(zb - za, h, w)
         out[za:zb] = torch.clamp(torch.floor(vol[za:zb] + nz), 0, 255).to(torch.uint8)
     return out
+
+
+def add_somas(img, centres_radii, amplitude=230):
+    """Bright solid balls (x, y, z, r) added to a synth() stack: the cell bodies the soma path looks for
+    (somaradius > 0).  Returns a new uint8 array."""
+    l, h, w = img.shape
+    out = img.astype(np.float32)
+    zz, yy, xx = np.meshgrid(np.arange(l), np.arange(h), np.arange(w), indexing="ij")
+    for (cx, cy, cz, r) in centres_radii:
+        d = np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2 + (zz - cz) ** 2)
+        out = np.maximum(out, amplitude * np.clip(r + 1.0 - d, 0.0, 1.0))
+    return np.ascontiguousarray(np.clip(np.floor(out), 0, 255).astype(np.uint8))

@@ -120,6 +120,28 @@ def test_reconstruct_matches_oracle(oracle, vol, tree_min):
     assert set(np.unique(got_n["type"][1:])) == {2}
 
 
+def test_replay_and_reconstruct_with_soma_match_oracle(oracle):
+    """soma nodes in the node list: the oracle's replay with a soma map supplies a graph whose traces end on
+    SOMA nodes; group1 keeps soma nodes as groups of their own (Advantra_plugin.cpp:1580-1588), bfs keeps their type."""
+    img = synth.add_somas(synth.synth(64, 56, 32, seed=2), ((20, 28, 16, 6), (48, 20, 14, 5)))
+    E8, th, smap, n4 = orc.soma_extract(oracle, img, 3)
+    assert len(n4) >= 1
+    s, T, xc = _traces_from_oracle(oracle, img, [2.0], 24, 30, 2.0, nseeds=40)
+    l, h, w = img.shape
+    vox = np.round(s[:, 2]).astype(np.int64) * w * h + np.round(s[:, 1]).astype(np.int64) * w + np.round(s[:, 0]).astype(np.int64)
+    keep = smap.reshape(-1)[vox] == 0
+    s, T, xc = s[keep], T.reshape(-1, 2)[keep].reshape(-1), xc.reshape(len(keep), 2, 30, 8)[keep].reshape(-1, 30, 8)
+    nodes, links, _ = orc.replay(oracle, s, T, xc, 30, img.shape, 4, 1, smap=smap, soma4=n4)
+    ns = len(n4)
+    assert np.all(nodes["type"][1:1 + ns] == 1) and ((links >= 1) & (links <= ns)).any()
+    want_n, want_p = orc.reconstruct(oracle, nodes, links, tree_size_min=3)
+    got_n, got_p = lib.reconstruct(nodes.astype(lib.NODE_DT), links, tree_size_min=3)
+    assert len(got_n) == len(want_n) > 10 and np.array_equal(got_p, want_p)
+    for k in got_n.dtype.names:
+        assert np.array_equal(got_n[k], want_n[k], equal_nan=True), k
+    assert (got_n["type"] == 1).sum() >= 1  # a soma node survives in the tree list with its type
+
+
 def test_reconstruct_degenerate_inputs():
     """only the dummy node; isolated nodes; a self-link and duplicate links (what a DENSITY stop can produce)"""
     dummy = np.zeros(1, lib.NODE_DT)

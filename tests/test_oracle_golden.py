@@ -114,3 +114,54 @@ def test_tracker_table_shapes(oracle):
     v = T.table("v")
     assert np.allclose((v * v).sum(1), 1, atol=1e-6)
     assert np.all(np.diff(T.table("w_cws"), axis=1) >= 0)
+
+
+# ---- soma path: erosion and the u8 Gaussian are pinned on the reference's own frangi.cpp ----
+@pytest.mark.parametrize("shape,rad", [((24, 40, 48), 3), ((5, 7, 9), 4), ((3, 33, 20), 2), ((1, 16, 16), 1)])
+def test_imerode_imgaussian_u8_vs_reference(oracle, ref, shape, rad):
+    if ref is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    rng = np.random.default_rng(5)
+    l, h, w = shape
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    img[:, h // 4: h // 2, w // 4: w // 2] = 200  # a plateau survives the erosion
+    Eo, Er = np.zeros_like(img), np.zeros_like(img)
+    oracle.orc_imerode_xy(img, w, h, l, float(rad), Eo)
+    ref.ref_imerode_xy(img.copy(), w, h, l, float(rad), Er)
+    assert np.array_equal(Eo, Er)
+    Go, Gr = Eo.copy(), Er.copy()
+    oracle.orc_imgaussian_u8_xy(Go, w, h, l, float(rad))
+    ref.ref_imgaussian_u8_xy(Gr, w, h, l, float(rad))
+    assert np.array_equal(Go, Gr) and Go.max() > 0
+
+
+def test_maxentropy_and_conn3d_properties(oracle):
+    """maxentropy_th / conn3d are parity-unpinned restatements (toolbox.cpp needs a Vaa3D header): check what the
+    published algorithm guarantees -- threshold between two well separated modes, regions = 26-connected components
+    numbered in raster order of their first voxel, centroid and mean radius of a ball."""
+    rng = np.random.default_rng(2)
+    a = np.concatenate([rng.integers(0, 20, 9000), rng.integers(180, 220, 1000)]).astype(np.uint8)
+    th = oracle.orc_maxentropy_th(np.ascontiguousarray(a), len(a))
+    assert 19 <= th < 180
+    hist = np.bincount(a, minlength=256).astype(np.int64)
+    assert oracle.orc_maxentropy_hist(hist) == th
+    import scipy.ndimage as ndi
+    vol = np.zeros((12, 20, 24), np.uint8)
+    vol[2:5, 3:6, 4:9] = 255
+    vol[5, 6, 9] = 255          # touches the first block by a corner only: same region with diagonal connectivity
+    vol[8:11, 12:18, 2:5] = 255
+    zz, yy, xx = np.meshgrid(np.arange(12), np.arange(20), np.arange(24), indexing="ij")
+    vol[(xx - 17) ** 2 + (yy - 8) ** 2 + (zz - 6) ** 2 <= 9] = 255
+    lab = np.zeros(vol.shape, np.int32)
+    xc, yc, zc, rc = (np.zeros(16, np.float32) for _ in range(4))
+    n = oracle.orc_conn3d(vol, 24, 20, 12, lab.reshape(-1), 1, 0, 1, xc, yc, zc, rc, 16)
+    want, nw = ndi.label(vol > 0, structure=np.ones((3, 3, 3)))
+    assert n == nw == 3
+    first = [np.flatnonzero(lab.reshape(-1) == k)[0] for k in range(1, n + 1)]
+    assert first == sorted(first)  # numbered in raster order
+    for k in range(1, n + 1):
+        m = lab == k
+        assert len(np.unique(want[m])) == 1 and (want == want[m][0]).sum() == m.sum()
+        assert np.allclose([xc[k - 1], yc[k - 1], zc[k - 1]], [xx[m].mean(), yy[m].mean(), zz[m].mean()], atol=1e-3)
+    ball = int(lab[6, 8, 17])
+    assert 1.5 < rc[ball - 1] < 3.0  # mean distance to the centre of a radius-3 ball = 3/4 * 3
