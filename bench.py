@@ -225,7 +225,7 @@ def main():
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (len(sigs) + 12) * nvox / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "note": "(S+12) B/voxel compulsory bytes over the Frangi kernel group; fp64 eigen-solver is the limiter"},
             "roofline_sums": None if a.driver != "phased" or km["smc_sums"][0] <= 0 else {
-                "kernel": "ph_sums<32>", "bound": "hbm", "launches": km["smc_sums"][1], "avg_launch_ms": km["smc_sums"][0] / max(km["smc_sums"][1], 1),
+                "kernel": "ph_sums", "bound": "hbm", "launches": km["smc_sums"][1], "avg_launch_ms": km["smc_sums"][0] / max(km["smc_sums"][1], 1),
                 "achieved": 2.0 * 4 * Mtot * stash_row_floats(a.np) * st["iters"] * a.steps / (km["smc_sums"][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": 2.0 * 4 * Mtot * stash_row_floats(a.np) * st["iters"] * a.steps / (km["smc_sums"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "real bytes: the ordered sums stream every stashed f32 sample twice (mean, then corr): 2 x 4 x sum(M) x %d B per SMC iteration" % stash_row_floats(a.np)},

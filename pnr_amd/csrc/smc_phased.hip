@@ -259,7 +259,7 @@ __global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P
 }
 
 // one wave per (trace, sigma, chain group): the ordered sums of the chains from the stash
-template <int PH_CH>
+constexpr int PH_CH = 32; // stash values in flight per lane (64: 256 VGPRs, slower with many traces, no faster with few)
 __global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, int np_pad, int ni, int it_arg, int lp)
 {
     const int S = T.nsig, ng = P.ngf + (P.rem > 0 ? 1 : 0), lane = threadIdx.x;
@@ -486,22 +486,19 @@ __global__ __launch_bounds__(256) void ph_admit(PhState P, float *__restrict__ s
 // host driver
 // ---------------------------------------------------------------------------------------------------------
 struct pnr_phased {
-    static constexpr int MAX_GROUPS = 4, RING = 8;
+    static constexpr int RING = 8;
     int64_t cap_traces = 0, cap_dbg = 0;
     int np = 0, np_pad = 0, S = 0, ni = 0;
     long long trace_floats = 0;
     PhState P{};
     float *d_s6 = nullptr;
     TraceOut O{};
-    int *h_cnt = nullptr;                        // pinned [MAX_GROUPS][RING]
+    int *h_cnt = nullptr;       // pinned [RING]: active-trace counters copied back by the stream
+    hipEvent_t ev[RING] = {};   // ... and the events that say so
     // streaming trace + replay: pinned records written by the kernels / read back at every poll, admission staging
     pnr_xest *h_xc = nullptr; int *h_flags = nullptr; int *h_new = nullptr; float *h_new_s6 = nullptr;
     int *d_new = nullptr; float *d_new_s6 = nullptr;
     int64_t stream_cap = 0;
-    hipStream_t streams[MAX_GROUPS] = {};        // [0] unused: group 0 runs on the ctx stream
-    hipEvent_t ev[MAX_GROUPS][RING] = {};      // counters of iteration it have been copied back
-    hipEvent_t ev_samp[MAX_GROUPS][RING] = {}; // the sampling launch of iteration it has finished
-    hipEvent_t ev_start = nullptr, ev_done[MAX_GROUPS] = {};
 };
 
 static void phased_free(pnr_phased *h)
@@ -525,15 +522,8 @@ void pnr_phased_destroy(pnr_phased *h)
     if (h->h_new) hipHostFree(h->h_new);
     if (h->h_new_s6) hipHostFree(h->h_new_s6);
     hipFree(h->d_new); hipFree(h->d_new_s6);
-    for (int g = 0; g < pnr_phased::MAX_GROUPS; g++) {
-        if (h->streams[g]) (void)hipStreamDestroy(h->streams[g]);
-        if (h->ev_done[g]) (void)hipEventDestroy(h->ev_done[g]);
-        for (int r = 0; r < pnr_phased::RING; r++)
-            if (h->ev[g][r]) (void)hipEventDestroy(h->ev[g][r]);
-        for (int r = 0; r < pnr_phased::RING; r++)
-            if (h->ev_samp[g][r]) (void)hipEventDestroy(h->ev_samp[g][r]);
-    }
-    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    for (int r = 0; r < pnr_phased::RING; r++)
+        if (h->ev[r]) (void)hipEventDestroy(h->ev[r]);
     delete h;
 }
 
@@ -545,18 +535,6 @@ static int pick_nsplit(int active, int ncu, int max_split)
     static const int x10 = getenv("PNR_SPLIT_X10") ? std::max(1, atoi(getenv("PNR_SPLIT_X10"))) : 40; // work-groups per CU x 10
     int ns = (int)(((long long)x10 * ncu / 10 + active - 1) / active);
     return ns < 1 ? 1 : (ns > max_split ? max_split : ns);
-}
-
-// the ordered sums are latency-bound per chain (M values, CH loads in flight per lane): with few traces the deep variant
-// (64 in flight, 256 VGPRs, one wave per SIMD) halves the launch time; with many, HBM bandwidth binds and occupancy wins
-static void launch_sums(int active, int per_trace, hipStream_t st, const Tab &T, const TabX &X, const PhState &P, int np, int np_pad, int ni,
-                        int it, int lp)
-{
-    static const int deep_below = getenv("PNR_SUMS_DEEP") ? atoi(getenv("PNR_SUMS_DEEP")) : 96;
-    if (active <= deep_below)
-        hipLaunchKernelGGL(ph_sums<64>, dim3((unsigned)(active * per_trace)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it, lp);
-    else
-        hipLaunchKernelGGL(ph_sums<32>, dim3((unsigned)(active * per_trace)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it, lp);
 }
 
 struct PhEnv {
@@ -586,14 +564,8 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     if (!c->phased) c->phased = new pnr_phased();
     pnr_phased *h = c->phased;
     if (!h->h_cnt) {
-        PNR_HIP(hipHostMalloc(&h->h_cnt, sizeof(int) * pnr_phased::MAX_GROUPS * pnr_phased::RING));
-        PNR_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
-        for (int g = 0; g < pnr_phased::MAX_GROUPS; g++) {
-            if (g > 0) PNR_HIP(hipStreamCreateWithFlags(&h->streams[g], hipStreamNonBlocking));
-            PNR_HIP(hipEventCreateWithFlags(&h->ev_done[g], hipEventDisableTiming));
-            for (int r = 0; r < pnr_phased::RING; r++) PNR_HIP(hipEventCreateWithFlags(&h->ev[g][r], hipEventDisableTiming));
-            for (int r = 0; r < pnr_phased::RING; r++) PNR_HIP(hipEventCreateWithFlags(&h->ev_samp[g][r], hipEventDisableTiming));
-        }
+        PNR_HIP(hipHostMalloc(&h->h_cnt, sizeof(int) * pnr_phased::RING));
+        for (int r = 0; r < pnr_phased::RING; r++) PNR_HIP(hipEventCreateWithFlags(&h->ev[r], hipEventDisableTiming));
     }
     const int ngf = (np + 1) / 64, rem = (np + 1) - 64 * ngf, R = (rem + 15) / 16 * 16, W = 64 * ngf + R;
     const long long Mtot = E.T.Mtot, trace_floats = Mtot * W;
@@ -621,8 +593,8 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
         PNR_HIP(hipMalloc(&h->P.xcs, (size_t)cap * 16 * 4));
         PNR_HIP(hipMalloc(&h->P.flags, (size_t)cap * FL_N * 4));
         PNR_HIP(hipMalloc(&h->P.stash, (size_t)cap * trace_floats * 4));
-        PNR_HIP(hipMalloc(&h->P.list, (size_t)cap * 2 * 4 * pnr_phased::MAX_GROUPS));
-        PNR_HIP(hipMalloc(&h->P.cnt, 2 * 4 * pnr_phased::MAX_GROUPS));
+        PNR_HIP(hipMalloc(&h->P.list, (size_t)cap * 2 * 4));
+        PNR_HIP(hipMalloc(&h->P.cnt, 2 * 4));
         PNR_HIP(hipMalloc(&h->P.ctr, (size_t)cap * 4));
         PNR_HIP(hipMalloc(&h->d_s6, (size_t)cap * 24));
         PNR_HIP(hipMalloc(&h->O.T, (size_t)cap * 4));
@@ -671,22 +643,13 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
     const Vol &V = E.V; const Tab &T = E.T; const TabX &X = E.X; const PhState &P = E.P;
     pnr_phased *h = E.h;
     const int np = E.np, ni = E.ni, S = E.S, np_pad = E.np_pad, ng = E.ng, ncu = E.ncu, max_split = E.max_split;
-    const long long trace_floats = E.trace_floats;
     const int64_t NT = E.NT;
     const size_t cube_bytes = E.cube_bytes, upd_lds = E.upd_lds;
     dbg_iters = E.dbg_iters;
     constexpr int CS = PH_CS;
     hipStream_t st = c->stream;
 
-    // A wave's traces are cut into `ngrp` groups that iterate independently on their own streams: while one group
-    // samples (VALU / LDS bound, one work-group per CU) another streams its sums from HBM, and the sampling launches of
-    // a group fill the CUs the other group's last round leaves idle.  Results do not depend on the grouping.
-    int ngrp = 1;
-    if (const char *e = getenv("PNR_PHASED_GROUPS")) ngrp = std::min(std::max(1, atoi(e)), (int)pnr_phased::MAX_GROUPS);
-    constexpr int LAG = 3, RING = pnr_phased::RING; // the host runs at most LAG iterations ahead of a group's counters
-    struct Grp {
-        PhState P; TraceOut O; const float *s6; int start, nt, active; hipStream_t st; bool running;
-    };
+    constexpr int LAG = 3, RING = pnr_phased::RING; // the host runs at most LAG iterations ahead of the active-trace counter
     std::vector<float> s6;
     std::vector<int> flags, list0;
     for (int64_t t0 = 0; t0 < ntr_all; t0 += NT) {
@@ -699,38 +662,15 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
             a[0] = sd.x; a[1] = sd.y; a[2] = sd.z;
             a[3] = neg ? -sd.vx : sd.vx; a[4] = neg ? -sd.vy : sd.vy; a[5] = neg ? -sd.vz : sd.vz;
         }
-        const int G = std::max(1, std::min(ngrp, nt));
         flags.assign((size_t)nt * FL_N, 0);
-        for (int j = 0; j < nt; j++) flags[(size_t)j * FL_N + FL_T] = ni;
-        list0.assign((size_t)pnr_phased::MAX_GROUPS * 2 * P.cap, 0);
-        int cnt0[2 * pnr_phased::MAX_GROUPS] = {};
-        Grp grp[pnr_phased::MAX_GROUPS];
+        list0.resize((size_t)nt);
+        for (int j = 0; j < nt; j++) { flags[(size_t)j * FL_N + FL_T] = ni; list0[(size_t)j] = j; }
+        const int cnt0[2] = {nt, 0};
         TraceOut O = h->O;
         O.dbg_iters = dbg_iters;
         if (!xfilt || !dbg_iters) O.xfilt = nullptr;
         if (!idxres || !dbg_iters) O.idxres = nullptr;
         if (!neff || !dbg_iters) O.neff = nullptr;
-        for (int g = 0; g < G; g++) {
-            Grp &q = grp[g];
-            q.start = (int)((int64_t)nt * g / G);
-            q.nt = (int)((int64_t)nt * (g + 1) / G) - q.start;
-            q.active = q.nt;
-            q.running = q.nt > 0;
-            q.st = g == 0 ? st : h->streams[g];
-            const size_t o = (size_t)q.start;
-            q.P = P;
-            q.P.part += o * 2 * np * PSTRIDE; q.P.prior += o * np; q.P.idxres += o * np; q.P.corr += o * S * np_pad;
-            q.P.xcs += o * 16; q.P.flags += o * FL_N; q.P.stash += o * (size_t)trace_floats; q.P.ctr += o;
-            q.P.list += (size_t)g * 2 * P.cap; q.P.cnt += 2 * g;
-            q.s6 = h->d_s6 + o * 6;
-            q.O = O;
-            q.O.T += o; q.O.stop += o; q.O.xc += o * ni * 8;
-            if (q.O.xfilt) q.O.xfilt += o * dbg_iters * np * PSTRIDE;
-            if (q.O.idxres) q.O.idxres += o * dbg_iters * np;
-            if (q.O.neff) q.O.neff += o * dbg_iters;
-            for (int j = 0; j < q.nt; j++) list0[(size_t)g * 2 * P.cap + j] = j;
-            cnt0[2 * g] = q.nt;
-        }
         PNR_HIP(hipMemcpyAsync(h->d_s6, s6.data(), s6.size() * 4, hipMemcpyHostToDevice, st));
         PNR_HIP(hipMemcpyAsync(P.flags, flags.data(), flags.size() * 4, hipMemcpyHostToDevice, st));
         PNR_HIP(hipMemcpyAsync(P.list, list0.data(), list0.size() * 4, hipMemcpyHostToDevice, st));
@@ -739,48 +679,31 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
         PNR_HIP(hipMemsetAsync(P.xcs, 0, (size_t)nt * 16 * 4, st));
         if (O.idxres) PNR_HIP(hipMemsetAsync(O.idxres, 0xff, (size_t)nt * dbg_iters * np * 4, st));
         PNR_HIP(hipStreamSynchronize(st)); // the uploads above come from pageable host vectors reused below
-        hipEvent_t prev_samp = nullptr;
-        bool have_prev = false;
+        int active = nt; // upper bound of the traces still running
         for (int it = 0; it <= ni; it++) {
-            bool any = false;
-            for (int g = 0; g < G; g++) {
-                Grp &q = grp[g];
-                if (!q.running) continue;
-                if (it >= LAG) { // counters of iteration it - LAG have landed: an upper bound of the traces still running
-                    PNR_HIP(hipEventSynchronize(h->ev[g][(it - LAG) % RING]));
-                    q.active = h->h_cnt[g * RING + (it - LAG) % RING];
-                    if (q.active <= 0) { q.running = false; continue; }
-                }
-                any = true;
-                const int nsplit = pick_nsplit(q.active, ncu, max_split);
-                c->tic(q.st);
-                hipLaunchKernelGGL(ph_predict, dim3(q.active), dim3(256), 0, q.st, T, X, q.P, q.s6, V, np, ni, it, it & 1, CS);
-                c->toc("smc_predict", 1, q.st);
-                // the sampling launches of the groups take turns (a launch fills every CU's LDS): group g samples after
-                // the previous running group's sampling of the same round, so its sums overlap the others' sampling
-                if (have_prev) PNR_HIP(hipStreamWaitEvent(q.st, prev_samp, 0));
-                c->tic(q.st);
-                hipLaunchKernelGGL(ph_sample<CS>, dim3((unsigned)(q.active * nsplit)), dim3(768), cube_bytes, q.st, V, T, X, q.P, np, ni, it, it & 1, q.active);
-                c->toc("smc", 1, q.st);
-                if (G > 1) {
-                    PNR_HIP(hipEventRecord(h->ev_samp[g][it % RING], q.st));
-                    prev_samp = h->ev_samp[g][it % RING];
-                    have_prev = true;
-                }
-                c->tic(q.st);
-                launch_sums(q.active, S * ng, q.st, T, X, q.P, np, np_pad, ni, it, it & 1);
-                c->toc("smc_sums", 1, q.st);
-                c->tic(q.st);
-                hipLaunchKernelGGL(ph_update, dim3(q.active), dim3(256), upd_lds, q.st, V, T, q.P, np, np_pad, ni, it, it & 1, c->prm.Kc,
-                                   c->prm.znccth, c->prm.neff_ratio, use_density ? c->d_den : nullptr, c->prm.nodepervol, q.O);
-                c->toc("smc_update", 1, q.st);
-                PNR_HIP(hipMemcpyAsync(&h->h_cnt[g * RING + it % RING], q.P.cnt + ((it + 1) & 1), 4, hipMemcpyDeviceToHost, q.st));
-                PNR_HIP(hipEventRecord(h->ev[g][it % RING], q.st));
+            if (it >= LAG) { // the counter of iteration it - LAG has landed (no pipeline drain: the host stays LAG steps ahead)
+                PNR_HIP(hipEventSynchronize(h->ev[(it - LAG) % RING]));
+                active = h->h_cnt[(it - LAG) % RING];
+                if (active <= 0) break;
             }
-            if (!any) break;
+            const int nsplit = pick_nsplit(active, ncu, max_split);
+            c->tic(st);
+            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, T, X, P, (const float *)h->d_s6, V, np, ni, it, it & 1, CS);
+            c->toc("smc_predict", 1, st);
+            c->tic(st);
+            hipLaunchKernelGGL(ph_sample<CS>, dim3((unsigned)(active * nsplit)), dim3(768), cube_bytes, st, V, T, X, P, np, ni, it, it & 1, active);
+            c->toc("smc", 1, st);
+            c->tic(st);
+            hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it, it & 1);
+            c->toc("smc_sums", 1, st);
+            c->tic(st);
+            hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), upd_lds, st, V, T, P, np, np_pad, ni, it, it & 1, c->prm.Kc, c->prm.znccth,
+                               c->prm.neff_ratio, use_density ? c->d_den : nullptr, c->prm.nodepervol, O);
+            c->toc("smc_update", 1, st);
+            PNR_HIP(hipMemcpyAsync(&h->h_cnt[it % RING], P.cnt + ((it + 1) & 1), 4, hipMemcpyDeviceToHost, st));
+            PNR_HIP(hipEventRecord(h->ev[it % RING], st));
         }
         PNR_HIP(hipGetLastError());
-        for (int g = 1; g < G; g++) PNR_HIP(hipStreamSynchronize(grp[g].st));
         PNR_HIP(hipMemcpyAsync(T_out + t0, h->O.T, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
         PNR_HIP(hipMemcpyAsync(stop_out + t0, h->O.stop, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
         PNR_HIP(hipMemcpyAsync(xc + t0 * ni, h->O.xc, (size_t)nt * ni * 32, hipMemcpyDeviceToHost, st));
@@ -900,7 +823,7 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
                 hipLaunchKernelGGL(ph_sample<PH_CS>, dim3((unsigned)(active * nsplit)), dim3(768), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
                 c->toc("smc", 1, st);
                 c->tic(st);
-                launch_sums(active, S * ng, st, E.T, E.X, P, np, np_pad, ni, -1, lp);
+                hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp);
                 c->toc("smc_sums", 1, st);
                 c->tic(st);
                 hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), E.upd_lds, st, E.V, E.T, P, np, np_pad, ni, -1, lp, c->prm.Kc, c->prm.znccth,

@@ -192,6 +192,32 @@ def test_batched_trace_replay_equals_one_shot(first_batch, vol, npv):
     assert iters <= full
 
 
+@pytest.mark.parametrize("window,look0,look_pct,poll,maxtr", [(2, 1, 0, 1, 0), (6, 3, 50, 3, 0), (4096, 4096, 100, 7, 0), (64, 16, 100, 4, 12)])
+def test_streaming_scheduler_edge_cases(monkeypatch, smc_driver, window, look0, look_pct, poll, maxtr):
+    """pnr_trace_replay_stream with a window of one seed, a lookahead of one seed, everything admitted at once, odd polling
+    periods and the MAX_TRACE_COUNT stop (Advantra_plugin.cpp:2702): always the one-shot node graph."""
+    if smc_driver != "phased":
+        pytest.skip("the streaming scheduler belongs to the phased driver")
+    img = synth.synth(80, 64, 32, seed=4)
+    kw = dict(max_trace_count=maxtr) if maxtr else {}
+    p = pnr_amd.make_params(sigmas=[2.0], np_=32, ni=40, zdist=2.0, nodepervol=3, vol=5, **kw)
+    c = pnr_amd.Context(p, 0)
+    c.set_volume(img)
+    c.frangi()
+    seeds = c.score_filter_sort(c.extract_seeds())
+    assert len(seeds) > 30
+    T, stop, xc, _ = c.trace_batch(seeds)
+    n1, l1, nt1 = c.replay(seeds, T, xc)
+    for k, v in (("PNR_WINDOW", window), ("PNR_LOOK0", look0), ("PNR_LOOK_PCT", look_pct), ("PNR_POLL", poll)):
+        monkeypatch.setenv(k, str(v))
+    n2, l2, nt2, iters = c.trace_replay(seeds)
+    assert nt1 == nt2 and len(n1) == len(n2) > 20 and np.array_equal(l1, l2)
+    for k in n1.dtype.names:
+        assert np.array_equal(n1[k], n2[k], equal_nan=True), k
+    if maxtr:
+        assert nt2 == maxtr + 1  # the loop ends after the trace that exceeds the cap (:2702)
+
+
 def test_trace_config5_shape_vs_oracle(oracle):
     """BASELINE configs[4] parameter shape at a size the oracle finishes in seconds: 4 scales {2,4,6,8},
     zdist=4 (anisotropic), np=500: chains loop over the work-group twice, the LDS cube shrinks to 44^3."""
