@@ -91,7 +91,9 @@ int pnr_synchronize(pnr_ctx *ctx);
 
 /* data1d + in_sz of reconstruction_func (Advantra_plugin.cpp:2241-2255).  Host pointer is
  * borrowed for the call and copied to HBM; the _device variant borrows a device pointer that
- * must stay valid until the next set_volume/destroy (no copy). */
+ * must stay valid until the next set_volume/destroy (no copy).  l == 1 (a single slice) selects the reference's 2-D mode:
+ * Frangi::frangi2d (frangi.cpp:392) and the is2d branches of the tracker (Advantra_plugin.cpp:2496-2497, :2526); the tracker
+ * tables are rebuilt whenever the dimensionality changes.  2-D stacks are traced by the phased SMC driver only. */
 int pnr_set_volume(pnr_ctx *ctx, const uint8_t *img, int64_t w, int64_t h, int64_t l);
 int pnr_set_volume_device(pnr_ctx *ctx, const void *dev_img, int64_t w, int64_t h, int64_t l);
 

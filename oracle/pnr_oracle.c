@@ -597,10 +597,11 @@ void orc_glibc_rand(uint32_t seed, int n, uint32_t *out)
 /*  T0  Tracker::Tracker tables                      tracker.cpp:79-527   */
 /* ====================================================================== */
 #define ORC_NDIR3D 50
+#define ORC_NDIR2D 30 /* tracker.cpp:27 */
 #define ORC_RAND_MAX 2147483647
 
 struct orc_tracker {
-    int nsig, step, npcles, niter, sz, ndir, nodespervol;
+    int nsig, step, npcles, niter, sz, ndir, nodespervol, is2d;
     float sig[16];
     float kappa, znccth, Kc, neff_ratio, zDist;
     /* model2_* (tracker.cpp:178-231) */
@@ -636,11 +637,19 @@ orc_tracker *orc_tracker_new(const float *sigs, int nsig, int step, int npcles, 
                              float kappa, float znccth, float Kc, float neff_ratio,
                              float zdist, int nodespervol, uint32_t rng_seed)
 {
+    return orc_tracker_new2(sigs, nsig, step, npcles, niter, kappa, znccth, Kc, neff_ratio, zdist, nodespervol, rng_seed, 0);
+}
+
+/* is2d = (P == 1) selects the 2-D branches of the constructor (Advantra_plugin.cpp:2526) */
+orc_tracker *orc_tracker_new2(const float *sigs, int nsig, int step, int npcles, int niter,
+                              float kappa, float znccth, float Kc, float neff_ratio,
+                              float zdist, int nodespervol, uint32_t rng_seed, int is2d)
+{
     if (nsig < 1 || nsig > 16) return NULL;
     orc_tracker *t = (orc_tracker *)calloc(1, sizeof(*t));
     t->nsig = nsig; t->step = step; t->npcles = npcles; t->niter = niter;
     t->kappa = kappa; t->znccth = znccth; t->Kc = Kc; t->neff_ratio = neff_ratio;
-    t->zDist = zdist; t->nodespervol = nodespervol; t->ndir = ORC_NDIR3D;
+    t->zDist = zdist; t->nodespervol = nodespervol; t->is2d = is2d ? 1 : 0; t->ndir = is2d ? ORC_NDIR2D : ORC_NDIR3D;
     for (int i = 0; i < nsig; i++) t->sig[i] = sigs[i];
 
     /* ---- model2 templates, 3-D branch (tracker.cpp:210-231) ---- */
@@ -653,6 +662,28 @@ orc_tracker *orc_tracker_new(const float *sigs, int nsig, int step, int npcles, 
         Vs = (Vs < 1.0) ? 1.0f : Vs;
         float vlim = V2 + FLT_MIN, ulim = U2 + FLT_MIN, wlim = W2 + FLT_MIN;
         int cnt = 0;
+        if (is2d) { /* 2-D branch (tracker.cpp:191-208): offsets (vv, uu, 0), weight exp(-uu^2 / 2 sig^2) */
+            for (float vv = (float)-V2; vv <= vlim; vv += Vs)
+                for (float uu = (float)-U2; uu <= ulim; uu += Vs) cnt++;
+            t->M[i] = cnt;
+            t->mvuw[i] = (float *)malloc(sizeof(float) * 3 * (size_t)cnt);
+            t->mwgt[i] = (float *)malloc(sizeof(float) * (size_t)cnt);
+            float avg2 = 0.0f;
+            int k2 = 0;
+            for (float vv = (float)-V2; vv <= vlim; vv += Vs)
+                for (float uu = (float)-U2; uu <= ulim; uu += Vs) {
+                    float value = (float)exp(-(uu * uu) / (2 * pow((double)sigs[i], 2)));
+                    t->mwgt[i][k2] = value;
+                    t->mvuw[i][3 * k2 + 0] = vv;
+                    t->mvuw[i][3 * k2 + 1] = uu;
+                    t->mvuw[i][3 * k2 + 2] = 0;
+                    avg2 += value;
+                    k2++;
+                }
+            avg2 /= cnt;
+            t->mavg[i] = avg2;
+            continue;
+        }
         for (float vv = (float)-V2; vv <= vlim; vv += Vs)
             for (float uu = (float)-U2; uu <= ulim; uu += Vs)
                 for (float ww = (float)-W2; ww <= wlim; ww += Vs) cnt++;
@@ -679,9 +710,10 @@ orc_tracker *orc_tracker_new(const float *sigs, int nsig, int step, int npcles, 
 
     /* ---- prediction offsets (tracker.cpp:375-438) ---- */
     int R = 2 * step, sz = 0;
+    const int Rz = is2d ? 0 : R; /* 2-D: dz = 0 only (tracker.cpp:383-387) */
     for (int dx = -R; dx <= R; ++dx)
         for (int dy = -R; dy <= R; ++dy)
-            for (int dz = -R; dz <= R; ++dz)
+            for (int dz = -Rz; dz <= Rz; ++dz)
                 if (dx * dx + dy * dy + dz * dz <= R * R && dx * dx + dy * dy + dz * dz > 0) sz++;
     t->sz = sz;
     t->p = (float *)malloc(sizeof(float) * 3 * (size_t)sz);
@@ -694,7 +726,7 @@ orc_tracker *orc_tracker_new(const float *sigs, int nsig, int step, int npcles, 
     int i = 0;
     for (int dx = -R; dx <= R; ++dx)
         for (int dy = -R; dy <= R; ++dy)
-            for (int dz = -R; dz <= R; ++dz) {
+            for (int dz = -Rz; dz <= Rz; ++dz) {
                 if (!(dx * dx + dy * dy + dz * dz <= R * R && dx * dx + dy * dy + dz * dz > 0)) continue;
                 float *p = t->p + 3 * i, *u = t->u + 3 * i;
                 p[0] = (float)dx;
@@ -719,6 +751,13 @@ orc_tracker *orc_tracker_new(const float *sigs, int nsig, int step, int npcles, 
     t->v = (float *)malloc(sizeof(float) * 3 * (size_t)nd);
     double phi_k = 0, phi_k_1 = 0;
     for (int k = 0; k < nd; k++) {
+        if (is2d) { /* 30 directions on the circle (tracker.cpp:776-783): float angle, std::cos / std::sin float overloads */
+            float ang1 = (float)(0.0 + k * ((2 * 3.14) / (float)nd));
+            t->v[3 * k + 0] = cosf(ang1);
+            t->v[3 * k + 1] = sinf(ang1);
+            t->v[3 * k + 2] = 0;
+            continue;
+        }
         double h_k = 1 - 2 * ((double)k / (nd - 1));
         double theta_k = acos(h_k);
         if (k == 0 || k == (nd - 1)) {
@@ -807,6 +846,9 @@ float orc_interp(float _x, float _y, float _z, const uint8_t *img, int width, in
     float yc = clampf(_y, 0, (float)(height - 1.001));
     int y1 = (int)yc, y2 = y1 + 1;
     float yf = yc - y1;
+    if (length == 1) /* 2-D branch: _z is not used (tracker.cpp:2152-2175) */
+        return (1 - yf) * ((1 - xf) * img[(i64)y1 * width + x1] + xf * img[(i64)y1 * width + x2]) +
+               (yf) * ((1 - xf) * img[(i64)y2 * width + x1] + xf * img[(i64)y2 * width + x2]);
     float zc = clampf(_z, 0, (float)(length - 1.001));
     int z1 = (int)zc, z2 = z1 + 1;
     float zf = zc - z1;
@@ -835,9 +877,13 @@ float orc_zncc(orc_tracker *t, float _x, float _y, float _z, float _vx, float _v
     } else {
         ux = 1; uy = 0; uz = 0;
     }
-    wx = uy * _vz - uz * _vy;
-    wy = -ux * _vz + uz * _vx;
-    wz = ux * _vy - uy * _vx;
+    if (t->is2d) { /* tracker.cpp:1908-1912 */
+        wx = 0; wy = 0; wz = 0;
+    } else {
+        wx = uy * _vz - uz * _vy;
+        wy = -ux * _vz + uz * _vx;
+        wz = ux * _vy - uy * _vx;
+    }
 
     float out_corr = -FLT_MAX;
     static float *buf = NULL;

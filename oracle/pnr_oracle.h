@@ -49,6 +49,10 @@ typedef struct orc_tracker orc_tracker;
 orc_tracker *orc_tracker_new(const float *sigs, int nsig, int step, int npcles, int niter,
                              float kappa, float znccth, float Kc, float neff_ratio,
                              float zdist, int nodespervol, uint32_t rng_seed);
+/* the same with is2d = (P == 1): 2-D templates (v, u, 0), in-plane prediction offsets, 30 directions, bilinear interp */
+orc_tracker *orc_tracker_new2(const float *sigs, int nsig, int step, int npcles, int niter,
+                             float kappa, float znccth, float Kc, float neff_ratio,
+                             float zdist, int nodespervol, uint32_t rng_seed, int is2d);
 void orc_tracker_free(orc_tracker *t);
 
 /* table access for parity tests (pointers stay owned by the tracker) */
@@ -114,6 +118,11 @@ int64_t orc_replay_soma(const float *seeds, int64_t nseeds, const int *T, const 
                         const float *soma4, int64_t n_soma,
                         orc_node *nodes, int64_t cap_nodes, int32_t *links, int64_t cap_links,
                         int64_t *nlinks, int64_t *ntraces_used);
+
+/* ---------- 2-D Frangi for single-slice stacks, pnr_oracle_2d.c ---------- */
+void orc_hessian2d(const uint8_t *I, int w, int h, float sig, float *Dyy, float *Dxy, float *Dxx);
+void orc_frangi2d(const uint8_t *I, int w, int h, const float *sigs, int nsig, float BetaOne, float BetaTwo,
+                  float *J, float *Jmin, float *Jmax, uint8_t *Vx, uint8_t *Vy, uint8_t *Vz);
 
 /* ---------- soma path, pnr_oracle_soma.c ---------- */
 void orc_imerode_xy(const uint8_t *I, int w, int h, int l, float rad, uint8_t *E);

@@ -30,6 +30,23 @@ void ref_imgaussian3d(unsigned char *I, int w, int h, int l, float sig, float zd
     Frangi::imgaussian(I, w, h, l, sig, zdist, F); // frangi.cpp:647
 }
 
+void ref_frangi2d(unsigned char *I, int w, int h, const float *sigs, int nsig, float betaone, float betatwo,
+                  float *J, float *Jmin, float *Jmax, unsigned char *Vx, unsigned char *Vy, unsigned char *Vz)
+{
+    MuteStdout m;
+    std::vector<float> s(sigs, sigs + nsig);
+    Frangi f(s, 1.f, .5f, .5f, 500.f, betaone, betatwo); // Advantra_plugin.cpp:2488 (frangi_betaone, frangi_betatwo)
+    f.frangi2d(I, w, h, 1, J, *Jmin, *Jmax, Vx, Vy, Vz); // frangi.cpp:392, the P == 1 branch of :2496-2497
+}
+
+void ref_hessian2d(unsigned char *I, int w, int h, float sig, float *Dyy, float *Dxy, float *Dxx)
+{
+    MuteStdout m;
+    std::vector<float> s(1, sig);
+    Frangi f(s, 1.f, .5f, .5f, 500.f, .5f, 15.f);
+    f.hessian2d(I, w, h, sig, Dyy, Dxy, Dxx); // frangi.cpp:508
+}
+
 void ref_imerode_xy(unsigned char *I, int w, int h, int l, float rad, unsigned char *E)
 {
     Frangi::imerode(I, w, h, l, rad, E); // frangi.cpp:880 (the xy erosion the soma path calls, Advantra_plugin.cpp:2431)

@@ -71,8 +71,7 @@ class Tracker:
 
     def __init__(self, sigs, step, npcles, niter, kappa, is2d, znccth, Kc=20.0, neff_ratio=0.8, zdist=2.0, nodespervol=4,
                  vol=1, rng_seed=42, device=0):
-        if is2d:
-            raise PnrError("2-D mode (P==1) is outside the accelerated path")
+        self.is2d = bool(is2d)  # P == 1: the 2-D tables are built when a single-slice stack is set (set_image)
         self.p = make_params(sigmas=sigs, step=step, np_=npcles, ni=niter, kappa=kappa, znccth=znccth, zdist=zdist,
                              nodepervol=nodespervol, vol=vol, rng_seed=rng_seed, Kc=Kc, neff_ratio=neff_ratio)
         self.ctx = Context(self.p, device)
@@ -80,7 +79,11 @@ class Tracker:
         self.ndir = len(self.ctx.table("v")) // 3
 
     def set_image(self, img):
+        if (img.shape[0] == 1) != self.is2d:
+            raise PnrError("Tracker(is2d=%s) needs a %s stack" % (self.is2d, "single-slice" if self.is2d else "multi-slice"))
         self.ctx.set_volume(img)
+        self.sz = len(self.ctx.table("w0"))
+        self.ndir = len(self.ctx.table("v")) // 3
 
     def znccBBB(self, pos_dir):
         """corr, sig for n poses (x,y,z,vx,vy,vz) -- tracker.cpp:1891."""

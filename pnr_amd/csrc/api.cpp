@@ -42,6 +42,39 @@ static int download(pnr_ctx *c, T *dst, const T *src, size_t n)
     return PNR_OK;
 }
 
+// tracker tables for the 3-D (default) or the 2-D (single-slice stack, P == 1) branch of Tracker::Tracker: built on the host,
+// resident on the device.  Rebuilt when pnr_set_volume changes the dimensionality.
+static int load_tables(pnr_ctx *c, bool is2d)
+{
+    hipFree(c->d_p); hipFree(c->d_u); hipFree(c->d_w0); hipFree(c->d_w0cws); hipFree(c->d_v); hipFree(c->d_w);
+    hipFree(c->d_wcws); hipFree(c->d_tmpl); hipFree(c->d_corrc); hipFree(c->d_sig); hipFree(c->d_M); hipFree(c->d_moff);
+    hipFree(c->d_rng); hipFree(c->d_grid); hipFree(c->d_axes); hipFree(c->d_axes_off); hipFree(c->d_wd);
+    c->d_p = c->d_u = c->d_w0 = c->d_w0cws = c->d_v = c->d_w = c->d_wcws = c->d_tmpl = c->d_corrc = c->d_sig = nullptr;
+    c->d_M = c->d_moff = nullptr; c->d_rng = nullptr; c->d_grid = nullptr; c->d_axes = nullptr; c->d_axes_off = nullptr; c->d_wd = nullptr;
+    pnr::build_tables(c->prm, is2d, c->tab);
+    const pnr::Tables &t = c->tab;
+    std::vector<float> sig(c->prm.sig, c->prm.sig + c->prm.nsig);
+    int rc = upload(&c->d_p, t.p, c->stream);
+    if (!rc) rc = upload(&c->d_u, t.u, c->stream);
+    if (!rc) rc = upload(&c->d_w0, t.w0, c->stream);
+    if (!rc) rc = upload(&c->d_w0cws, t.w0_cws, c->stream);
+    if (!rc) rc = upload(&c->d_v, t.v, c->stream);
+    if (!rc) rc = upload(&c->d_w, t.w, c->stream);
+    if (!rc) rc = upload(&c->d_wcws, t.w_cws, c->stream);
+    if (!rc) rc = upload(&c->d_tmpl, t.tmpl, c->stream);
+    if (!rc) rc = upload(&c->d_corrc, t.corrc, c->stream);
+    if (!rc) rc = upload(&c->d_sig, sig, c->stream);
+    if (!rc) rc = upload(&c->d_M, t.M, c->stream);
+    if (!rc) rc = upload(&c->d_moff, t.moff, c->stream);
+    if (!rc) rc = upload(&c->d_rng, t.rng, c->stream);
+    if (!rc) rc = upload(&c->d_grid, t.grid, c->stream);
+    if (!rc) rc = upload(&c->d_axes, t.axes, c->stream);
+    if (!rc) rc = upload(&c->d_axes_off, t.axes_off, c->stream);
+    if (!rc) rc = upload(&c->d_wd, t.wd, c->stream);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = PNR_E_HIP;
+    return rc;
+}
+
 extern "C" {
 
 const char *pnr_last_error(void) { return pnr::g_err; }
@@ -119,26 +152,7 @@ int pnr_create(const pnr_params *p, int device, pnr_ctx **out)
     if (const char *e = getenv("PNR_SMC_DRIVER")) c->smc_driver = (strcmp(e, "persistent") == 0) ? 1 : 0;
     (void)hipEventCreate(&c->ev0);
     (void)hipEventCreate(&c->ev1);
-    pnr::build_tables(c->prm, c->tab);
-    const pnr::Tables &t = c->tab;
-    std::vector<float> sig(c->prm.sig, c->prm.sig + c->prm.nsig);
-    rc = upload(&c->d_p, t.p, c->stream);
-    if (!rc) rc = upload(&c->d_u, t.u, c->stream);
-    if (!rc) rc = upload(&c->d_w0, t.w0, c->stream);
-    if (!rc) rc = upload(&c->d_w0cws, t.w0_cws, c->stream);
-    if (!rc) rc = upload(&c->d_v, t.v, c->stream);
-    if (!rc) rc = upload(&c->d_w, t.w, c->stream);
-    if (!rc) rc = upload(&c->d_wcws, t.w_cws, c->stream);
-    if (!rc) rc = upload(&c->d_tmpl, t.tmpl, c->stream);
-    if (!rc) rc = upload(&c->d_corrc, t.corrc, c->stream);
-    if (!rc) rc = upload(&c->d_sig, sig, c->stream);
-    if (!rc) rc = upload(&c->d_M, t.M, c->stream);
-    if (!rc) rc = upload(&c->d_moff, t.moff, c->stream);
-    if (!rc) rc = upload(&c->d_rng, t.rng, c->stream);
-    if (!rc) rc = upload(&c->d_grid, t.grid, c->stream);
-    if (!rc) rc = upload(&c->d_axes, t.axes, c->stream);
-    if (!rc) rc = upload(&c->d_axes_off, t.axes_off, c->stream);
-    if (!rc) rc = upload(&c->d_wd, t.wd, c->stream);
+    rc = load_tables(c, /*is2d*/ false);
     if (!rc && hipMalloc(&c->d_minmax, 8) != hipSuccess) rc = PNR_E_HIP;
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = PNR_E_HIP;
     if (rc) {
@@ -189,14 +203,20 @@ int pnr_synchronize(pnr_ctx *c)
 static int set_dims(pnr_ctx *c, int64_t w, int64_t h, int64_t l)
 {
     PNR_REQUIRE(c, PNR_E_ARG, "null ctx");
-    // P == 1 would take the reference's frangi2d / 2-D tracker branch (Advantra_plugin.cpp:2496-2497): out of scope
-    PNR_REQUIRE(w >= 2 && h >= 2 && l >= 2, PNR_E_ARG, "volume must be at least 2x2x2 (2-D mode is not accelerated)");
+    // P == 1 takes the reference's frangi2d / 2-D tracker branch (Advantra_plugin.cpp:2496-2497, :2526)
+    PNR_REQUIRE(w >= 2 && h >= 2 && l >= 1, PNR_E_ARG, "volume must be at least 2x2x1");
     PNR_REQUIRE(w <= 1 << 20 && h <= 1 << 20 && l <= 1 << 20 && w * h < (1LL << 31), PNR_E_ARG, "volume extent too large");
     PNR_HIP(hipSetDevice(c->device));
     c->w = w; c->h = h; c->l = l;
     c->N = w * h * l;
     c->have_j8 = false;
     c->seeds.clear();
+    c->have_soma = false;
+    if ((l == 1) != c->tab.is2d) { // the tracker tables depend on the dimensionality (Tracker(..., P == 1, ...))
+        PNR_HIP(hipDeviceSynchronize());
+        const int rc = load_tables(c, l == 1);
+        if (rc) return rc;
+    }
     return PNR_OK;
 }
 
@@ -261,6 +281,7 @@ int pnr_gaussian(pnr_ctx *c, float sig, float *F)
 int pnr_hessian(pnr_ctx *c, float sig, float *Dzz, float *Dyy, float *Dyz, float *Dxx, float *Dxy, float *Dxz)
 {
     PNR_REQUIRE(c && c->d_img, PNR_E_STATE, "pnr_hessian: no volume set");
+    PNR_REQUIRE(c->l > 1, PNR_E_ARG, "pnr_hessian taps the 3-D Hessian: not defined for a single-slice stack");
     PNR_REQUIRE(sig > 0, PNR_E_ARG, "sigma must be positive");
     int rc = pnr_ensure_frangi_buffers(c);
     if (rc) return rc;

@@ -34,6 +34,7 @@ void set_error(const char *fmt, ...);
 // ---- host tables (tables.cpp): Tracker::Tracker (tracker.cpp:79-527) + Gaussian taps ----
 struct Tables {
     int sz = 0, ndir = 50, nsig = 0;
+    bool is2d = false; // built for a single-slice stack (P == 1)
     std::vector<float> p, u, d0, w0, w0_cws, v, w, w_cws; // p,u: sz x 3; w,w_cws: ndir x sz
     std::vector<int> M;                                   // samples per sigma
     std::vector<int> moff;                                // prefix offsets into tmpl
@@ -48,7 +49,7 @@ struct Tables {
     std::vector<uint32_t> rng;                            // np + 1 glibc rand() draws
     std::vector<std::vector<float>> gxy, gz;              // Gaussian taps per sigma
 };
-void build_tables(const pnr_params &p, Tables &t);
+void build_tables(const pnr_params &p, bool is2d, Tables &t);
 void glibc_rand_stream(uint32_t seed, int n, uint32_t *out);
 int gaussian_taps(float sig, std::vector<float> &g); // returns radius L
 

@@ -17,6 +17,7 @@
 // operation the reference's scalar loop performs, in the same order, so Gaussian / Hessian /
 // eigenvectors are bit-identical; only exp() (fp64, ocml vs glibc, <1 ulp each) can differ.
 #include "ctx.h"
+#include "smc_device.h" // expf_libm: the device expf that equals the host libm value
 #include <cfloat>
 #include <cmath>
 
@@ -460,6 +461,70 @@ __global__ __launch_bounds__(HE_BLOCK, 8) void hessian_eigen(const float *__rest
 }
 
 // ----------------------------------------------------------------------------------------
+// K4': single-slice stacks (P == 1): hessian2d (frangi.cpp:508-574) + the closed-form 2x2 eigen-analysis and the
+// Rb / S2 vesselness of frangi2d (:392-506).  One thread per pixel; mixed f32 / f64 exactly as the reference
+// (pow(float, 2) and the sqrt over such sums are double, exp / abs / the final sqrt take the float overloads).
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned char quant_dir2(float v, float n)
+{
+    const double r = (double)(((v / n) + 1) / 2) * 255.0; // round((((v/n)+1)/2)*255.0), half away from zero
+    if (!(r == r)) return 0;                              // zero vector: (int)NaN is INT_MIN on the reference's platform -> clamped to 0
+    int val = (int)((r > 0.0) ? floor(r + 0.5) : ceil(r - 0.5));
+    val = (val < 0) ? 0 : (val > 255) ? 255 : val;
+    return (unsigned char)val;
+}
+
+__global__ __launch_bounds__(256) void frangi2d_pixel(const float *__restrict__ F, float *__restrict__ J, unsigned char *__restrict__ Vx,
+                                                      unsigned char *__restrict__ Vy, unsigned char *__restrict__ Vz, int w, int h, float sig2,
+                                                      float beta, float cc, int first, unsigned int *__restrict__ minmax)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    unsigned int omin = 0xffffffffu, omax = 0u;
+    if (i < (i64)w * h) {
+        const int x = (int)(i % w), y = (int)(i / w);
+        const float Dyy = d2(F, i, w, y, h, w, y, h, 1) * sig2;
+        const float Dxx = d2(F, i, 1, x, w, 1, x, w, 1) * sig2;
+        const float Dxy = d2(F, i, 1, x, w, w, y, h, 0) * sig2;
+        const float dd = Dxx - Dyy;
+        const float tmp = (float)sqrt((double)dd * (double)dd + 4 * ((double)Dxy * (double)Dxy));
+        float v2x = 2 * Dxy;
+        float v2y = Dyy - Dxx + tmp;
+        const float mag = (float)sqrt((double)v2x * (double)v2x + (double)v2y * (double)v2y);
+        if (mag > 0) { v2x /= mag; v2y /= mag; }
+        const float v1x = -v2y, v1y = v2x;
+        const float mu1 = (float)(0.5 * (double)(Dxx + Dyy + tmp));
+        const float mu2 = (float)(0.5 * (double)(Dxx + Dyy - tmp));
+        const bool check = fabsf(mu1) < fabsf(mu2);
+        float L1 = check ? mu2 : mu1;
+        const float L2 = check ? mu1 : mu2;
+        const float Vecx = check ? v2x : v1x, Vecy = check ? v2y : v1y;
+        L1 = (L1 == 0) ? FLT_MIN : L1;
+        const float q = L2 / L1;
+        const float Rb = (float)((double)q * (double)q);
+        const float S2 = (float)((double)L1 * (double)L1 + (double)L2 * (double)L2);
+        float If = expf_libm(-Rb / beta) * (1 - expf_libm(-S2 / cc));
+        If = (L1 > 0) ? 0 : If; // blackwhite == false
+        if (first || If > J[i]) {
+            J[i] = If;
+            const float Vecn = sqrtf(Vecx * Vecx + Vecy * Vecy);
+            Vx[i] = quant_dir2(Vecx, Vecn);
+            Vy[i] = quant_dir2(Vecy, Vecn);
+            Vz[i] = 0;
+            omin = omax = f2ord(If);
+        }
+    }
+    // Jmin / Jmax are updated only where a scale wrote (frangi.cpp:449-451, :475-477)
+    for (int o = 32; o > 0; o >>= 1) {
+        omin = min(omin, (unsigned int)__shfl_xor((int)omin, o));
+        omax = max(omax, (unsigned int)__shfl_xor((int)omax, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (omin != 0xffffffffu) atomicMin(&minmax[0], omin);
+        if (omax != 0u) atomicMax(&minmax[1], omax);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
 // K5: J -> J8 (Advantra_plugin.cpp:2499-2512)
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void j8_kernel(const float *__restrict__ J, unsigned char *__restrict__ J8, i64 n,
@@ -534,6 +599,8 @@ static int gaussian3d(pnr_ctx *c, const std::vector<float> &gxy, const std::vect
     float *bufY = (bufX == c->d_tmpA) ? c->d_tmpB : c->d_tmpA;  // y-pass out
     float *bufZ = d_out;
     if (bufZ == bufY) { float *t = bufX; bufX = bufY; bufY = t; }
+    const bool two_d = (l == 1); // single-slice stack: the 2-D imgaussian has no z pass (frangi.cpp:576-645)
+    if (two_d) { bufY = d_out; bufX = (d_out == c->d_tmpA) ? c->d_tmpB : c->d_tmpA; }
     c->tic();
     {
         const int tiles_x = (w + GX_BLOCK - 1) / GX_BLOCK;
@@ -547,13 +614,13 @@ static int gaussian3d(pnr_ctx *c, const std::vector<float> &gxy, const std::vect
         hipLaunchKernelGGL(gauss_axis, dim3((unsigned)((i64)tiles_x * tiles_a * l)), dim3(256), sm, c->stream, bufX, bufY,
                            w, h, (i64)w, l, (i64)w * h, tiles_x, tiles_a, d_txy, Lxy);
     }
-    {
+    if (!two_d) {
         const int tiles_x = (w + 63) / 64, tiles_a = (l + TA - 1) / TA;
         const size_t sm = ((size_t)(TA + 2 * Lz) * 64 + 2 * Lz + 1) * 4;
         hipLaunchKernelGGL(gauss_axis, dim3((unsigned)((i64)tiles_x * tiles_a * h)), dim3(256), sm, c->stream, bufY, bufZ,
                            w, l, (i64)w * h, h, (i64)w, tiles_x, tiles_a, d_tz, Lz);
     }
-    c->toc("gauss", 3);
+    c->toc("gauss", two_d ? 2 : 3);
     PNR_HIP(hipGetLastError());
     return PNR_OK;
 }
@@ -615,6 +682,11 @@ int pnr_frangi_run(pnr_ctx *c, float *Jmin, float *Jmax)
         if (rc) { hipFree(d_taps); return rc; }
         const int tiles_x = (w + HE_BLOCK - 1) / HE_BLOCK;
         c->tic();
+        if (l == 1) { // P == 1: frangi2d (Advantra_plugin.cpp:2496-2497) with frangi_betaone = .5, frangi_betatwo = 15 (:69-70)
+            const float beta2d = (float)(2 * std::pow((double).5f, 2)), c2d = (float)(2 * std::pow((double)15.f, 2));
+            hipLaunchKernelGGL(frangi2d_pixel, dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, (const float *)c->d_tmpA, c->d_J,
+                               c->d_Vx, c->d_Vy, c->d_Vz, w, h, P.sig[s] * P.sig[s], beta2d, c2d, s == 0 ? 1 : 0, c->d_minmax);
+        } else
         hipLaunchKernelGGL(hessian_eigen<false>, dim3((unsigned)((i64)h * l * tiles_x)), dim3(HE_BLOCK), 0, c->stream, c->d_tmpA,
                            c->d_J, c->d_Vx, c->d_Vy, c->d_Vz, w, h, l, tiles_x, P.sig[s] * P.sig[s], two_a2, two_b2, two_c2,
                            s == 0 ? 1 : 0, c->d_minmax, HessOut{});

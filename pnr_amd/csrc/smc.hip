@@ -527,6 +527,7 @@ int pnr_job_launch(pnr_ctx *c, pnr_trace_job *j, const pnr_seed *seeds, int64_t 
     if (n == 0) return PNR_OK;
     if (!j->own_stream) j->stream = c->stream;
     j->phased = (c->smc_driver == 0);
+    PNR_REQUIRE(j->phased || c->l > 1, PNR_E_ARG, "single-slice (2-D) stacks are traced by the phased SMC driver only");
     if (j->phased) {
         j->seeds.assign(seeds, seeds + n);
         j->n = n; j->dbg_iters = dbg_iters; j->use_density = use_density;

@@ -78,6 +78,11 @@ __device__ __forceinline__ float interp(const Vol &V, float x, float y, float z)
     const float yc = clampf(y, 0.f, V.ymax);
     const int y1 = (int)yc;
     const float yf = yc - (float)y1;
+    if (V.l == 1) { // single-slice stack: bilinear, z is not used (tracker.cpp:2152-2175)
+        const unsigned char *a = V.img + (i64)y1 * V.w + x1;
+        const float a00 = a[0], a01 = a[1], a10 = a[V.w], a11 = a[V.w + 1];
+        return (1 - yf) * ((1 - xf) * a00 + xf * a01) + (yf) * ((1 - xf) * a10 + xf * a11);
+    }
     const float zc = clampf(z, 0.f, V.zmax);
     const int z1 = (int)zc;
     const float zf = zc - (float)z1;
@@ -208,7 +213,7 @@ struct Samples {
     float v[G];
 };
 
-template <int G, int CS>
+template <int G, int CS, bool IS2D = false>
 __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, const float (&x)[G], const float (&y)[G],
                                                    const float (&z)[G])
 {
@@ -219,7 +224,7 @@ __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, c
     bool all_in = true;
 #pragma unroll
     for (int j = 0; j < G; j++) {
-        const float xc = clamp3(x[j], 0.f, V.xmax), yc = clamp3(y[j], 0.f, V.ymax), zc = clamp3(z[j], 0.f, V.zmax);
+        const float xc = clamp3(x[j], 0.f, V.xmax), yc = clamp3(y[j], 0.f, V.ymax), zc = IS2D ? 0.f : clamp3(z[j], 0.f, V.zmax);
         // xc - (float)(int)xc of the reference == xc - floor(xc) for xc >= 0, an exact subtraction: v_fract_f32
         xf[j] = __builtin_amdgcn_fractf(xc);
         yf[j] = __builtin_amdgcn_fractf(yc);
@@ -237,23 +242,35 @@ __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, c
         lds_cu8 *a1 = lds_plus1_opaque(a);
         c[j][0] = a[0];            c[j][1] = a1[0];
         c[j][2] = a[CS];           c[j][3] = a1[CS];
-        c[j][4] = a[CS * CS];      c[j][5] = a1[CS * CS];
-        c[j][6] = a[CS * CS + CS]; c[j][7] = a1[CS * CS + CS];
+        if (!IS2D) {
+            c[j][4] = a[CS * CS];      c[j][5] = a1[CS * CS];
+            c[j][6] = a[CS * CS + CS]; c[j][7] = a1[CS * CS + CS];
+        }
     }
     if (__builtin_amdgcn_ballot_w64(!all_in) != 0ull) { // wave-uniform: some lane has a corner group outside the cube
 #pragma unroll
         for (int j = 0; j < G; j++) {
             if (!in[j]) { // rare: recompute the voxel index instead of keeping it live for every sample
-                const int x1 = (int)clamp3(x[j], 0.f, V.xmax), y1 = (int)clamp3(y[j], 0.f, V.ymax), z1 = (int)clamp3(z[j], 0.f, V.zmax);
+                const int x1 = (int)clamp3(x[j], 0.f, V.xmax), y1 = (int)clamp3(y[j], 0.f, V.ymax), z1 = IS2D ? 0 : (int)clamp3(z[j], 0.f, V.zmax);
                 const unsigned char *a = V.img + ((i64)z1 * V.wh + (i64)y1 * V.w + x1);
                 c[j][0] = a[0];        c[j][1] = a[1];
                 c[j][2] = a[V.w];      c[j][3] = a[V.w + 1];
-                c[j][4] = a[V.wh];     c[j][5] = a[V.wh + 1];
-                c[j][6] = a[V.wh + V.w]; c[j][7] = a[V.wh + V.w + 1];
+                if (!IS2D) {
+                    c[j][4] = a[V.wh];     c[j][5] = a[V.wh + 1];
+                    c[j][6] = a[V.wh + V.w]; c[j][7] = a[V.wh + V.w + 1];
+                }
             }
         }
     }
     Samples<G> r;
+    if (IS2D) { // single-slice stack: (1-fy)*((1-fx)*I11 + fx*I12) + fy*((1-fx)*I21 + fx*I22) (tracker.cpp:2175)
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            const float fx = xf[j], fy = yf[j];
+            r.v[j] = (1 - fy) * ((1 - fx) * (float)c[j][0] + fx * (float)c[j][1]) + (fy) * ((1 - fx) * (float)c[j][2] + fx * (float)c[j][3]);
+        }
+        return r;
+    }
 #pragma unroll
     for (int j = 0; j < G; j++) {
         // (1-fz)*((1-fy)*((1-fx)*a00 + fx*a01) + fy*((1-fx)*a10 + fx*a11)) + fz*((1-fy)*((1-fx)*b00 + fx*b01) + fy*(...b10, b11)),
@@ -405,7 +422,7 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
 // Phase A: sampling is order-free, so it is cut into work items (sigma, group of 64 particles,
 // v-slice) that the 12 waves pull from a shared counter: the long (sigma >= 4) and short chains
 // no longer pin the iteration time to the longest chain.  Values go to the stash at [sample][lane].
-template <int CS>
+template <int CS, bool IS2D = false>
 __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
                                              const float *__restrict__ ax, int iv, float *__restrict__ stash_lane, int iu0 = 0,
                                              int iu1 = 1 << 30)
@@ -432,7 +449,7 @@ __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const F
                 ys[j] = xy.y;
                 zs[j] = z1 + ww * f.wz;
             }
-            const Samples<G> sm = interp_group<G, CS>(V, B, xs, ys, zs);
+            const Samples<G> sm = interp_group<G, CS, IS2D>(V, B, xs, ys, zs);
 #pragma unroll
             for (int j = 0; j < G; j++)
                 if (iw0 + j < nw) sp[(iw0 + j) * 64] = sm.v[j];
@@ -445,7 +462,7 @@ __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const F
 // wave `parts` = 64 / cnt times, copy p of chain j taking the template rows iu = p, p + parts, ... of the v-slice.
 // Sampling is order-free, so the values are the same as in sample_slice; they go to a narrow [sample][stride] region
 // (stride = cnt rounded up to 16 floats).  The per-lane uu comes from the row register by ds_bpermute.
-template <int CS>
+template <int CS, bool IS2D = false>
 __device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
                                                     const float *__restrict__ ax, int iv, int parts, int p, bool active,
                                                     float *__restrict__ stash_col, int stride)
@@ -475,7 +492,7 @@ __device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, 
                 ys[j] = xy.y;
                 zs[j] = z1 + ww * f.wz;
             }
-            const Samples<G> sm = interp_group<G, CS>(V, B, xs, ys, zs);
+            const Samples<G> sm = interp_group<G, CS, IS2D>(V, B, xs, ys, zs);
 #pragma unroll
             for (int j = 0; j < G; j++)
                 if (ok && iw0 + j < nw) sp[(iw0 + j) * stride] = sm.v[j];

@@ -127,8 +127,12 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     if (tid == 0) { // cube origin: centred on the bounding box of all templates, kept inside the volume
         const int dim[3] = {V.w, V.h, V.l};
         for (int a = 0; a < 3; a++) {
-            const int lo = sbox[a] < 0 ? 0 : (sbox[a] > dim[a] - 1 ? dim[a] - 1 : sbox[a]);
-            const int hi = sbox[3 + a] > dim[a] - 1 ? dim[a] - 1 : (sbox[3 + a] < lo ? lo : sbox[3 + a]);
+            // samples beyond a border are clamped onto it (interp: [0, dim - 1.001]) and then read the two outermost
+            // rows, so the box always keeps those when it touches or lies past the border
+            int lo = sbox[a] < 0 ? 0 : (sbox[a] > dim[a] - 1 ? dim[a] - 1 : sbox[a]);
+            int hi = sbox[3 + a] > dim[a] - 1 ? dim[a] - 1 : (sbox[3 + a] < lo ? lo : sbox[3 + a]);
+            if (lo > dim[a] - 2) lo = dim[a] - 2 < 0 ? 0 : dim[a] - 2;
+            if (hi < 1) hi = dim[a] - 1 < 1 ? dim[a] - 1 : 1;
             int o = (lo + hi + 1) / 2 - CS / 2;
             if (o > dim[a] - CS) o = dim[a] - CS;
             if (o < 0) o = 0;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     }
 }
 
-template <int CS>
+template <int CS, bool IS2D>
 __global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it_arg, int lp, int nslots)
 {
     extern __shared__ unsigned char cube[];
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
             const float *q = is_cen ? xc_pen : (valid ? cur + k * PSTRIDE : (tail ? xc_pen : cur));
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
-            sample_slice<CS>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+            sample_slice<CS, IS2D>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
         } else {
             const int cnt = tail ? 1 : rem, jbase = tail ? rem - 1 : 0; // tail: the centroid's chains only
             const int parts = 64 / cnt;
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P
             const int k = ngf * 64 + j;
             const float *q = (k == np) ? xc_pen : cur + k * PSTRIDE; // k == np before the first centroid: zeros, discarded
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
-            sample_slice_packed<CS>(V, Bx, f, nv, nu, nw, ax, iv, parts, pp, act, sbase + (i64)ngf * Ms * 64 + j, P.R);
+            sample_slice_packed<CS, IS2D>(V, Bx, f, nv, nu, nw, ax, iv, parts, pp, act, sbase + (i64)ngf * Ms * 64 + j, P.R);
         }
     }
 }
@@ -628,7 +632,8 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     E.h = h;
     E.max_split = 24;
     if (const char *e = getenv("PNR_MAX_SPLIT")) E.max_split = std::max(1, atoi(e));
-    PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
+    PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
+    PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
     return PNR_OK;
 }
 
@@ -691,7 +696,10 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
             hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, T, X, P, (const float *)h->d_s6, V, np, ni, it, it & 1, CS);
             c->toc("smc_predict", 1, st);
             c->tic(st);
-            hipLaunchKernelGGL(ph_sample<CS>, dim3((unsigned)(active * nsplit)), dim3(768), cube_bytes, st, V, T, X, P, np, ni, it, it & 1, active);
+            if (V.l == 1)
+                hipLaunchKernelGGL((ph_sample<CS, true>), dim3((unsigned)(active * nsplit)), dim3(768), cube_bytes, st, V, T, X, P, np, ni, it, it & 1, active);
+            else
+                hipLaunchKernelGGL((ph_sample<CS, false>), dim3((unsigned)(active * nsplit)), dim3(768), cube_bytes, st, V, T, X, P, np, ni, it, it & 1, active);
             c->toc("smc", 1, st);
             c->tic(st);
             hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it, it & 1);
@@ -820,7 +828,10 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
                 hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
                 c->toc("smc_predict", 1, st);
                 c->tic(st);
-                hipLaunchKernelGGL(ph_sample<PH_CS>, dim3((unsigned)(active * nsplit)), dim3(768), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
+                if (E.V.l == 1)
+                    hipLaunchKernelGGL((ph_sample<PH_CS, true>), dim3((unsigned)(active * nsplit)), dim3(768), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
+                else
+                    hipLaunchKernelGGL((ph_sample<PH_CS, false>), dim3((unsigned)(active * nsplit)), dim3(768), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
                 c->toc("smc", 1, st);
                 c->tic(st);
                 hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp);

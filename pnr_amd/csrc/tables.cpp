@@ -57,9 +57,10 @@ static double i0_poly(double x)
            (0.39894228 + y * (0.1328592e-1 + y * (0.225319e-2 + y * (-0.157565e-2 + y * (0.916281e-2 + y * (-0.2057706e-1 + y * (0.2635537e-1 + y * (-0.1647633e-1 + y * 0.392377e-2))))))));
 }
 
-static void build_templates(const pnr_params &P, Tables &t)
+static void build_templates(const pnr_params &P, bool is2d, Tables &t)
 {
-    // model2_* of tracker.cpp:178-231 (3-D branch); model2_N = 12 samples per 3*sigma
+    // model2_* of tracker.cpp:178-231; model2_N = 12 samples per 3*sigma.  2-D branch (:191-208): offsets (vv, uu, 0),
+    // weight exp(-uu^2 / 2 sig^2) -- the same product grid with a single w value 0
     t.M.clear(); t.moff.clear(); t.tmpl.clear(); t.mwgt.clear(); t.mavg.clear(); t.corrc.clear();
     t.grid.clear(); t.axes.clear(); t.axes_off.clear(); t.wd.clear(); t.ext_v = t.ext_uw = 0;
     int off = 0;
@@ -75,7 +76,9 @@ static void build_templates(const pnr_params &P, Tables &t)
         std::vector<float> av, au, aw;
         for (float vv = (float)-V2; vv <= V2 + FLT_MIN; vv += Vs) av.push_back(vv);
         for (float uu = (float)-U2; uu <= U2 + FLT_MIN; uu += Vs) au.push_back(uu);
-        for (float ww = (float)-W2; ww <= W2 + FLT_MIN; ww += Vs) aw.push_back(ww);
+        if (is2d) aw.push_back(0.f);
+        else
+            for (float ww = (float)-W2; ww <= W2 + FLT_MIN; ww += Vs) aw.push_back(ww);
         t.grid.push_back((int)av.size()); t.grid.push_back((int)au.size()); t.grid.push_back((int)aw.size()); t.grid.push_back(off);
         t.axes_off.push_back((int)t.axes.size());
         t.axes.insert(t.axes.end(), av.begin(), av.end());
@@ -85,13 +88,21 @@ static void build_templates(const pnr_params &P, Tables &t)
         for (float x : au) t.ext_uw = std::fmax(t.ext_uw, std::fabs(x));
         for (float x : aw) t.ext_uw = std::fmax(t.ext_uw, std::fabs(x));
         for (float vv = (float)-V2; vv <= V2 + FLT_MIN; vv += Vs)
-            for (float uu = (float)-U2; uu <= U2 + FLT_MIN; uu += Vs)
+            for (float uu = (float)-U2; uu <= U2 + FLT_MIN; uu += Vs) {
+                if (is2d) {
+                    const float value = (float)std::exp((double)(-(uu * uu)) / (2 * std::pow((double)sg, 2)));
+                    wgt.push_back(value);
+                    vuw.push_back(vv); vuw.push_back(uu); vuw.push_back(0.f);
+                    avg += value;
+                    continue;
+                }
                 for (float ww = (float)-W2; ww <= W2 + FLT_MIN; ww += Vs) {
                     const float value = (float)std::exp((double)(-((uu * uu) + (ww * ww))) / (2 * std::pow((double)sg, 2)));
                     wgt.push_back(value);
                     vuw.push_back(vv); vuw.push_back(uu); vuw.push_back(ww);
                     avg += value;
                 }
+            }
         const int M = (int)wgt.size();
         avg /= (float)M;
         // (wgt - avg) and corrc = sum pow(wgt-avg,2) do not depend on the image: the reference
@@ -114,14 +125,14 @@ static void build_templates(const pnr_params &P, Tables &t)
     }
 }
 
-static void build_prediction(const pnr_params &P, Tables &t)
+static void build_prediction(const pnr_params &P, bool is2d, Tables &t)
 {
-    // tracker.cpp:375-438: integer offsets inside the radius-2*step ball, z scaled by 1/zdist
-    const int R = 2 * P.step;
+    // tracker.cpp:375-438: integer offsets inside the radius-2*step ball (2-D: disc, dz = 0), z scaled by 1/zdist
+    const int R = 2 * P.step, Rz = is2d ? 0 : R;
     std::vector<int> px, py, pz;
     for (int dx = -R; dx <= R; ++dx)
         for (int dy = -R; dy <= R; ++dy)
-            for (int dz = -R; dz <= R; ++dz) {
+            for (int dz = -Rz; dz <= Rz; ++dz) {
                 const int r2 = dx * dx + dy * dy + dz * dz;
                 if (r2 <= R * R && r2 > 0) { px.push_back(dx); py.push_back(dy); pz.push_back(dz); }
             }
@@ -146,11 +157,20 @@ static void build_prediction(const pnr_params &P, Tables &t)
     }
 }
 
-static void build_directions(Tables &t)
+static void build_directions(bool is2d, Tables &t)
 {
-    // tracker.cpp:785-799 (3-D): spiral points on the sphere, poles at phi = 0
+    // tracker.cpp:785-799 (3-D): spiral points on the sphere, poles at phi = 0; :776-783 (2-D): 30 angles on the circle
     const int n = t.ndir;
     t.v.resize(3 * n);
+    if (is2d) {
+        for (int k = 0; k < n; k++) {
+            const float ang1 = (float)(0.0 + k * ((2 * 3.14) / (float)n)); // "3.14" as in the reference
+            t.v[3 * k + 0] = std::cos(ang1); // float overloads
+            t.v[3 * k + 1] = std::sin(ang1);
+            t.v[3 * k + 2] = 0.f;
+        }
+        return;
+    }
     double phi = 0, phi_prev = 0;
     for (int k = 0; k < n; k++) {
         const double hk = 1 - 2 * ((double)k / (n - 1));
@@ -191,13 +211,14 @@ static void build_oriented_priors(const pnr_params &P, Tables &t)
     }
 }
 
-void build_tables(const pnr_params &P, Tables &t)
+void build_tables(const pnr_params &P, bool is2d, Tables &t)
 {
     t.nsig = P.nsig;
-    t.ndir = 50; // Tracker::ndirs3d
-    build_templates(P, t);
-    build_prediction(P, t);
-    build_directions(t);
+    t.is2d = is2d;
+    t.ndir = is2d ? 30 : 50; // Tracker::ndirs2d / ndirs3d (tracker.cpp:27-28)
+    build_templates(P, is2d, t);
+    build_prediction(P, is2d, t);
+    build_directions(is2d, t);
     build_oriented_priors(P, t);
     t.rng.resize((size_t)P.np + 1);
     glibc_rand_stream(P.rng_seed, P.np + 1, t.rng.data());

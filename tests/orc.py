@@ -62,6 +62,11 @@ def load_oracle():
     L.orc_replay.argtypes = [f32p, C.c_int64, i32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_void_p, C.c_int64, i32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.orc_replay.restype = C.c_int64
+    L.orc_frangi2d.argtypes = [u8p, C.c_int, C.c_int, f32p, C.c_int, C.c_float, C.c_float, f32p, C.POINTER(C.c_float), C.POINTER(C.c_float), u8p, u8p, u8p]
+    L.orc_hessian2d.argtypes = [u8p, C.c_int, C.c_int, C.c_float, f32p, f32p, f32p]
+    L.orc_tracker_new2.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_int, C.c_uint32, C.c_int]
+    L.orc_tracker_new2.restype = C.c_void_p
     L.orc_replay_soma.argtypes = [f32p, C.c_int64, i32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, f32p, C.c_int64,
                                   C.c_void_p, C.c_int64, i32p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.orc_replay_soma.restype = C.c_int64
@@ -95,6 +100,8 @@ def load_ref():
     L.ref_eigen3.argtypes = [f64p, f64p, f64p]
     L.ref_frangi3d.argtypes = [u8p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                f32p, C.POINTER(C.c_float), C.POINTER(C.c_float), u8p, u8p, u8p]
+    L.ref_frangi2d.argtypes = [u8p, C.c_int, C.c_int, f32p, C.c_int, C.c_float, C.c_float, f32p, C.POINTER(C.c_float), C.POINTER(C.c_float), u8p, u8p, u8p]
+    L.ref_hessian2d.argtypes = [u8p, C.c_int, C.c_int, C.c_float, f32p, f32p, f32p]
     L.ref_imerode_xy.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_float, u8p]
     L.ref_imgaussian_u8_xy.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_float]
     L.ref_extract_seeds.argtypes = [C.c_double, u8p, C.c_int, C.c_int, C.c_int, u8p, u8p, u8p, f32p, C.c_int64]
@@ -105,6 +112,17 @@ def load_ref():
 # ---------------- convenience wrappers ----------------
 NODE_DT = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("vx", "f4"), ("vy", "f4"), ("vz", "f4"),
                     ("corr", "f4"), ("sig", "f4"), ("type", "i4")])
+
+
+def frangi2d(L, img, sigs, betaone=0.5, betatwo=15.0, prefix="orc"):
+    """2-D Frangi of a single-slice stack (1, h, w): J, Jmin, Jmax, Vx, Vy, Vz (frangi.cpp:392)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    _, h, w = img.shape
+    J = np.zeros(img.shape, np.float32)
+    Vx, Vy, Vz = (np.zeros(img.shape, np.uint8) for _ in range(3))
+    jmin, jmax = C.c_float(), C.c_float()
+    getattr(L, prefix + "_frangi2d")(img, w, h, np.asarray(sigs, np.float32), len(sigs), betaone, betatwo, J, C.byref(jmin), C.byref(jmax), Vx, Vy, Vz)
+    return J, jmin.value, jmax.value, Vx, Vy, Vz
 
 
 def frangi3d(L, img, sigs, zdist, alpha=0.5, beta=0.5, Cc=500.0, prefix="orc"):
@@ -135,11 +153,11 @@ def extract_seeds(L, tol, J8, Vx, Vy, Vz, prefix="orc"):
 
 
 class Tracker:
-    def __init__(self, L, sigs, step, np_, ni, kappa, znccth, Kc=20.0, neff_ratio=0.8, zdist=2.0, nodespervol=4, rng_seed=42):
+    def __init__(self, L, sigs, step, np_, ni, kappa, znccth, Kc=20.0, neff_ratio=0.8, zdist=2.0, nodespervol=4, rng_seed=42, is2d=False):
         self.L = L
         self.sigs = np.asarray(sigs, np.float32)
         self.np, self.ni = np_, ni
-        self.h = L.orc_tracker_new(self.sigs, len(self.sigs), step, np_, ni, kappa, znccth, Kc, neff_ratio, zdist, nodespervol, rng_seed)
+        self.h = L.orc_tracker_new2(self.sigs, len(self.sigs), step, np_, ni, kappa, znccth, Kc, neff_ratio, zdist, nodespervol, rng_seed, int(is2d))
         assert self.h
         self.sz = L.orc_tracker_sz(self.h)
         self.ndir = L.orc_tracker_ndir(self.h)

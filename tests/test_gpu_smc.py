@@ -135,6 +135,35 @@ def test_trace_nan_direction_and_border_seed(oracle):
             assert np.allclose(mat(xc[j])[:rows], xco[:rows], rtol=F32_RTOL, atol=F32_ATOL, equal_nan=True)
 
 
+def test_trace_leaving_through_a_border(oracle):
+    """bright lines running into the +y, +z and -x faces: the trace leaves the volume there, and the record of the failing
+    iteration still carries the ZNCC of the out-of-volume centroid, whose samples are clamped onto the two outermost
+    rows (Tracker::interp, tracker.cpp:2140-2178) -- rows the cube staging must keep"""
+    img = synth.synth(48, 40, 24, seed=1, noise=6)
+    img[9:12, :, 19:22] = 200      # along y, through both y faces
+    img[:, 28:31, 33:36] = 200     # along z
+    img[17:20, 6:9, :] = 200       # along x
+    so = np.array([[20, 34, 10, 0, 1, 0, 0, 0], [34, 29, 19, 0, 0, 1, 0, 0], [5, 7, 18, -1, 0, 0, 0, 0], [20, 3, 10, 0, -1, 0, 0, 0]], np.float32)
+    To = orc.Tracker(oracle, [2.0], 2, 40, 12, 3.0, 0.3, zdist=1.0)
+    seeds = np.zeros(len(so), lib.SEED_DT)
+    for i, k in enumerate(lib.SEED_DT.names):
+        seeds[k] = so[:, i]
+    c = pnr_amd.Context(pnr_amd.make_params(sigmas=[2.0], np_=40, ni=12, zdist=1.0), 0)
+    c.set_volume(img)
+    T, stop, xc, _ = c.trace_batch(seeds)
+    left = 0
+    for i, sd in enumerate(so):
+        for d, sgn in enumerate((1, -1)):
+            q = sd[:6].copy(); q[3:] *= sgn
+            Tn, st, xco, *_ = To.trace(img, q)
+            j = 2 * i + d
+            assert T[j] == Tn and stop[j] == st, (j, T[j], Tn, stop[j], st)
+            rows = min(Tn + 1, 12)
+            assert np.array_equal(mat(xc[j])[:rows], xco[:rows]), j
+            left += int(st == 1)
+    assert left >= 4  # the outward traces all end outside the volume
+
+
 def test_end_to_end_vs_oracle(oracle):
     """BASELINE configs[0]-shaped plumbing case, reduced so the oracle finishes in seconds:
     Frangi -> J8 -> seeds -> score/filter/sort -> trace -> replay: seed list, trace lengths, node

@@ -165,3 +165,24 @@ def test_maxentropy_and_conn3d_properties(oracle):
         assert np.allclose([xc[k - 1], yc[k - 1], zc[k - 1]], [xx[m].mean(), yy[m].mean(), zz[m].mean()], atol=1e-3)
     ball = int(lab[6, 8, 17])
     assert 1.5 < rc[ball - 1] < 3.0  # mean distance to the centre of a radius-3 ball = 3/4 * 3
+
+
+# ---- 2-D mode: Frangi::frangi2d / hessian2d pinned on the reference's own frangi.cpp ----
+@pytest.mark.parametrize("shape,sigs", [((1, 40, 48), [2.0]), ((1, 33, 21), [2.0, 3.0]), ((1, 64, 64), [1.0, 2.0, 4.0]), ((1, 7, 9), [2.0])])
+def test_frangi2d_vs_reference(oracle, ref, shape, sigs):
+    if ref is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    _, h, w = shape
+    img = synth.synth(w, h, 9, seed=4)[4:5].copy() if min(h, w) > 16 else np.random.default_rng(3).integers(0, 255, shape, dtype=np.uint8)
+    for sg in sigs:
+        a = [np.zeros(shape, np.float32) for _ in range(3)]
+        b = [np.zeros(shape, np.float32) for _ in range(3)]
+        oracle.orc_hessian2d(img, w, h, sg, *a)
+        ref.ref_hessian2d(img.copy(), w, h, sg, *b)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    Jo, jmo, jMo, Vxo, Vyo, Vzo = orc.frangi2d(oracle, img, sigs)
+    Jr, jmr, jMr, Vxr, Vyr, Vzr = orc.frangi2d(ref, img.copy(), sigs, prefix="ref")
+    assert np.array_equal(Jo, Jr) and jmo == jmr and jMo == jMr
+    assert np.array_equal(Vxo, Vxr) and np.array_equal(Vyo, Vyr) and np.array_equal(Vzo, Vzr) and not Vzo.any()
+    if min(h, w) > 16:
+        assert jMo > 0.05
