@@ -53,3 +53,33 @@ def test_cli_matches_python_pipeline(tmp_path):
     assert rows.shape == want.shape and len(rows) > 50
     assert np.array_equal(rows[:, [0, 1, 6]], want[:, [0, 1, 6]])  # ids, types, parents
     assert np.allclose(rows[:, 2:6], want[:, 2:6], atol=2e-3)      # %.3f text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["soma", "slice"])
+def test_cli_soma_and_single_slice(tmp_path, case):
+    """the C++ host runs the soma path for somaradius > 0 and the 2-D mode for a one-page TIFF, like the Python mirror"""
+    from PIL import Image
+    if case == "soma":
+        img = synth.add_somas(synth.synth(64, 56, 32, seed=2), ((20, 28, 16, 6), (48, 20, 14, 5)))
+        paras, kw = "2,3 3 5 0.3 3 2 25 40 2 4 1".split(), dict(somaradius=3, ni=25, np_=40, vol=1)
+    else:
+        img = np.ascontiguousarray(synth.synth(96, 80, 9, seed=4).max(0, keepdims=True))
+        paras, kw = "2,3 0 5 0.3 3 2 25 40 2 4 1".split(), dict(somaradius=0, ni=25, np_=40, vol=1)
+    tif = str(tmp_path / "stack.tif")
+    pages = [Image.fromarray(z) for z in img]
+    pages[0].save(tif, save_all=True, append_images=pages[1:], compression=None)
+    r = run("-f", "advantra_func", "-i", tif, "-p", *paras)
+    assert r.returncode == 0, r.stderr
+    if case == "soma":
+        assert "soma regions" in r.stdout
+    rows = np.array([[float(v) for v in ln.split()] for ln in open(tif + "_Advantra.swc") if ln[0] != "#"])
+    ctx = pnr_amd.Context(pnr_amd.make_params(sigmas=[2, 3], tolerance=5, znccth=0.3, kappa=3, step=2, zdist=2, nodepervol=4, **kw), 0)
+    res = pnr_amd.advantra.run_pipeline(ctx, img)
+    ref = str(tmp_path / "ref.swc")
+    pnr_amd.write_swc_tree(ref, res["tree"], res["parent"])
+    want = np.array([[float(v) for v in ln.split()] for ln in open(ref) if ln[0] != "#"])
+    assert rows.shape == want.shape and len(rows) > 20
+    assert np.array_equal(rows[:, [0, 1, 6]], want[:, [0, 1, 6]]) and np.allclose(rows[:, 2:6], want[:, 2:6], atol=2e-3)
+    if case == "soma":
+        assert (rows[:, 1] == 1).sum() >= 1  # a SOMA-typed node in the SWC
