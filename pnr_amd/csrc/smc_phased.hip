@@ -22,6 +22,7 @@
 namespace {
 
 enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_IT = 3, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_N = 16 };
+constexpr int PH_THREADS = 1024; // sampling work-group: 16 waves (<= 128 VGPRs each)
 constexpr int PH_CS = 54; // the sampling kernel holds nothing but the cube in LDS: 54^3 = 157 464 B of the 160 KB
 
 struct PhState {
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
 }
 
 template <int CS, bool IS2D>
-__global__ __launch_bounds__(768) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it_arg, int lp, int nslots)
+__global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it_arg, int lp, int nslots)
 {
     extern __shared__ unsigned char cube[];
     // part-major: the first nslots work-groups are one per trace, the later ones join whatever is left of their trace
@@ -697,9 +698,9 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
             c->toc("smc_predict", 1, st);
             c->tic(st);
             if (V.l == 1)
-                hipLaunchKernelGGL((ph_sample<CS, true>), dim3((unsigned)(active * nsplit)), dim3(768), cube_bytes, st, V, T, X, P, np, ni, it, it & 1, active);
+                hipLaunchKernelGGL((ph_sample<CS, true>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), cube_bytes, st, V, T, X, P, np, ni, it, it & 1, active);
             else
-                hipLaunchKernelGGL((ph_sample<CS, false>), dim3((unsigned)(active * nsplit)), dim3(768), cube_bytes, st, V, T, X, P, np, ni, it, it & 1, active);
+                hipLaunchKernelGGL((ph_sample<CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), cube_bytes, st, V, T, X, P, np, ni, it, it & 1, active);
             c->toc("smc", 1, st);
             c->tic(st);
             hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it, it & 1);
@@ -829,9 +830,9 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
                 c->toc("smc_predict", 1, st);
                 c->tic(st);
                 if (E.V.l == 1)
-                    hipLaunchKernelGGL((ph_sample<PH_CS, true>), dim3((unsigned)(active * nsplit)), dim3(768), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
+                    hipLaunchKernelGGL((ph_sample<PH_CS, true>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
                 else
-                    hipLaunchKernelGGL((ph_sample<PH_CS, false>), dim3((unsigned)(active * nsplit)), dim3(768), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
+                    hipLaunchKernelGGL((ph_sample<PH_CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
                 c->toc("smc", 1, st);
                 c->tic(st);
                 hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp);
