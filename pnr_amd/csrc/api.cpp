@@ -168,7 +168,7 @@ void pnr_destroy(pnr_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto *j : c->jobs) pnr_job_destroy(j);
+    pnr_job_destroy(c->job);
     pnr_phased_destroy(c->phased);
     if (c->h_j8) hipHostFree(c->h_j8);
     hipFree(c->d_img_owned); hipFree(c->d_stash); hipFree(c->d_slot_busy); hipFree(c->d_den); hipFree(c->d_den_idx); hipFree(c->d_den_val);
@@ -475,58 +475,31 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
         if (rc) return rc;
         n = 0; // nothing left for the batch loop below
     }
+    // persistent driver: strictly sequential seed-rank batches (128, 256, ... 1024 seeds): the freshest map a batch scheme can
+    // have.  (Several batches in flight on separate streams were slower: they must be collected in rank order, so the in-flight
+    // count collapses behind every slow batch, and a staler map costs iterations.)
     int64_t batch = first_batch > 0 ? first_batch : 128;
     const int64_t growth_pct = getenv("PNR_BATCH_GROWTH") ? std::max(100, atoi(getenv("PNR_BATCH_GROWTH"))) : 200;
-    // A ring of `depth` batches in flight, each on its own stream.  depth 1: strictly sequential batches (the
-    // freshest map, fewest wasted iterations, but every batch waits for its 200-iteration stragglers while
-    // most CUs idle).  depth > 1: later batches already occupy the CUs that earlier ones leave idle; batches are
-    // collected and replayed strictly in rank order, and each launch sees the map of everything replayed so far.
-    const int max_depth = (int)(sizeof(c->jobs) / sizeof(c->jobs[0])) - 1;
-    const char *dep = getenv("PNR_TRACE_DEPTH");
-    int depth = dep ? atoi(dep) : 1;
-    depth = depth < 1 ? 1 : (depth > max_depth ? max_depth : depth);
     const int64_t batch_max = getenv("PNR_BATCH_MAX") ? std::max(1, atoi(getenv("PNR_BATCH_MAX"))) : 1024;
-    for (int k = 0; k < depth; k++)
-        if (!c->jobs[k]) {
-            c->jobs[k] = pnr_job_create(c, true);
-            PNR_REQUIRE(c->jobs[k], PNR_E_HIP, "could not create a trace stream");
-        }
-    struct Slot {
-        std::vector<pnr_seed> bs;
-        std::vector<int32_t> T, stop;
-        std::vector<pnr_xest> xc;
-        bool live = false;
-    };
-    std::vector<Slot> slots((size_t)depth);
-    int64_t next = 0; // first seed not yet assigned to a batch
-    auto launch = [&](int k) -> int {
-        Slot &sl = slots[(size_t)k];
-        sl.live = false;
-        if (next >= n || r.stopped) return PNR_OK;
+    std::vector<pnr_seed> bs;
+    std::vector<int32_t> T, stop;
+    std::vector<pnr_xest> xc;
+    for (int64_t next = 0; next < n && !r.stopped;) {
         const int64_t i1 = std::min(n, next + std::min(batch, batch_max));
-        sl.bs.clear();
-        // seeds already on a saturated voxel are skipped by the replay whatever their traces are: not launched
-        for (int64_t i = next; i < i1; i++)
-            if (!r.seed_saturated(seeds[i])) sl.bs.push_back(seeds[i]);
+        bs.clear();
+        for (int64_t i = next; i < i1; i++) // a seed on a saturated voxel is skipped by the replay whatever its traces are: not launched
+            if (!r.seed_saturated(seeds[i])) bs.push_back(seeds[i]);
         next = i1;
         if (batch < batch_max) batch = std::max<int64_t>(batch + 1, batch * growth_pct / 100);
-        const int64_t m = (int64_t)sl.bs.size();
-        sl.T.assign((size_t)(2 * m), 0);
-        sl.stop.assign((size_t)(2 * m), 0);
-        sl.xc.resize((size_t)(2 * m) * ni);
-        sl.live = true;
-        return pnr_job_launch(c, c->jobs[k], sl.bs.data(), m, 0, false, false, false, /*use_density*/ 1);
-    };
-    for (int k = 0; k < depth && !rc; k++) rc = launch(k);
-    if (rc) return rc;
-    for (int k = 0; slots[(size_t)k].live; k = (k + 1) % depth) { // slot k always holds the oldest batch in flight
-        Slot &sl = slots[(size_t)k];
-        const int64_t m = (int64_t)sl.bs.size();
-        rc = pnr_job_finish(c, c->jobs[k], sl.T.data(), sl.stop.data(), sl.xc.data(), nullptr, nullptr, nullptr);
+        const int64_t m = (int64_t)bs.size();
+        T.assign((size_t)(2 * m), 0);
+        stop.assign((size_t)(2 * m), 0);
+        xc.resize((size_t)(2 * m) * ni);
+        rc = pnr_trace_run(c, bs.data(), m, T.data(), stop.data(), xc.data(), 0, nullptr, nullptr, nullptr, /*use_density*/ 1);
         if (rc) return rc;
         int64_t bi = 0, bmax = 0;
         for (int64_t j = 0; j < 2 * m; j++) {
-            const int64_t e = std::min<int64_t>(sl.T[(size_t)j] + 1, ni);
+            const int64_t e = std::min<int64_t>(T[(size_t)j] + 1, ni);
             bi += e;
             bmax = std::max(bmax, e);
         }
@@ -535,15 +508,10 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
             fprintf(stderr, "[pnr trace] batch of %lld seeds launched: %lld iterations, longest trace %lld, nodes so far %zu\n", (long long)m,
                     (long long)bi, (long long)bmax, r.nodes.size());
         r.touched.clear();
-        r.add(sl.bs.data(), m, sl.T.data(), sl.xc.data());
-        rc = pnr_density_update(c, r, c->jobs[k]);
-        if (rc) return rc;
-        rc = launch(k);
+        r.add(bs.data(), m, T.data(), xc.data());
+        rc = pnr_density_update(c, r);
         if (rc) return rc;
     }
-    for (int k = 0; k < depth; k++) // batches may still be running when MAX_TRACE_COUNT ended the loop
-        if (slots[(size_t)k].live)
-            (void)pnr_job_finish(c, c->jobs[k], slots[(size_t)k].T.data(), slots[(size_t)k].stop.data(), slots[(size_t)k].xc.data(), nullptr, nullptr, nullptr);
     *n_nodes = (int64_t)r.nodes.size();
     *n_links = (int64_t)r.links.size() / 2;
     if (nodes) std::memcpy(nodes, r.nodes.data(), sizeof(pnr_node) * (size_t)std::min<int64_t>(cap_nodes, *n_nodes));

@@ -99,9 +99,7 @@ struct pnr_ctx {
     uint8_t *d_den_val = nullptr;
     size_t den_stage_cap = 0;
 
-    // trace jobs: [0..PNR_MAX_DEPTH) own streams (ring of batches in pnr_trace_replay), the last one on the ctx stream
-    static constexpr int PNR_MAX_DEPTH = 16;
-    struct pnr_trace_job *jobs[PNR_MAX_DEPTH + 1] = {};
+    struct pnr_trace_job *job = nullptr; // device buffers of pnr_trace_batch / the persistent driver's batches (ctx stream)
     struct pnr_phased *phased = nullptr; // state of the launch-per-phase SMC driver (smc_phased.hip)
     int smc_driver = 0;                  // 0: launch per phase (default), 1: one persistent work-group per trace
 
@@ -194,6 +192,6 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
 void pnr_phased_destroy(pnr_phased *h);
 int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::Replayer &r, int64_t *iters);
 int pnr_density_reset(pnr_ctx *c);                       // zero the device density map (allocating it on first use)
-int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, struct pnr_trace_job *on); // push the voxels touched by the last replay batch
+int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r); // push the voxels touched since Replayer::touched was cleared
 int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y);
 int pnr_ensure_frangi_buffers(pnr_ctx *c);

@@ -668,7 +668,7 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
                   float *xfilt, int32_t *idxres, float *neff, int use_density)
 {
     if (n == 0) return PNR_OK;
-    pnr_trace_job *&sj = c->jobs[pnr_ctx::PNR_MAX_DEPTH];
+    pnr_trace_job *&sj = c->job;
     if (!sj) sj = pnr_job_create(c, false);
     PNR_REQUIRE(sj, PNR_E_HIP, "could not create a trace job");
     int rc = pnr_job_launch(c, sj, seeds, n, dbg_iters, xfilt != nullptr, idxres != nullptr, neff != nullptr, use_density);
@@ -712,17 +712,14 @@ int pnr_density_reset(pnr_ctx *c)
     return PNR_OK;
 }
 
-int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, pnr_trace_job *on)
+int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r)
 {
-    // runs on the stream of the batch that has just been collected: an extra stream could land on a hardware queue
-    // shared with a batch that is still running (ROCm multiplexes streams onto 4 queues) and wait behind it
-    hipStream_t st = on ? on->stream : c->stream;
+    hipStream_t st = c->stream;
     const size_t n = r.touched.size();
     if (n == 0) return PNR_OK;
     std::vector<unsigned char> val(n);
     for (size_t i = 0; i < n; i++) val[i] = (unsigned char)r.den_at(r.touched[i]); // final value: duplicates agree
-    // grow-only staging buffers: hipFree synchronises the whole device and would serialise the trace batches
-    // that are in flight on the other streams
+    // grow-only staging buffers (hipFree synchronises the whole device)
     if (c->den_stage_cap < n) {
         PNR_HIP(hipDeviceSynchronize());
         hipFree(c->d_den_idx);

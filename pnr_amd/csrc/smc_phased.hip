@@ -881,7 +881,7 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
             frontier++;
         }
         if (!r.touched.empty()) {
-            rc = pnr_density_update(c, r, nullptr);
+            rc = pnr_density_update(c, r);
             if (rc) return rc;
         }
         if (r.stopped) break; // MAX_TRACE_COUNT (:2702): whatever is still running is never looked at
