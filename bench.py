@@ -190,7 +190,7 @@ def main():
         # active traces; the "smc" timer group) with the phased driver, smc_trace (one launch per batch, sampling +
         # sums + update) with the persistent one.  Algorithmic bytes: 8 corner bytes x sum(M_sigma)
         # samples per particle evaluation, (np+1) evaluations per SMC iteration; ph_sample performs every one of them.
-        kname = "ph_sample<54>" if a.driver == "phased" else "smc_trace"
+        kname = "ph_sample<54, false>" if a.driver == "phased" else "smc_trace"
         Mtot = sum(len(ctx.table(f"model_wgt{s}")) for s in range(len(sigs)))
         smc_ms, smc_n = km["smc"]
         smc_all_ms = sum(km[g][0] for g in ("smc", "smc_sums", "smc_predict", "smc_update"))
@@ -204,7 +204,7 @@ def main():
         # a known byte count in the same access pattern: scripts/prof_traffic.sh), collected for THIS workload and
         # committed under profiles/; null for any other workload
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_1024_s2000.json" if a.driver == "persistent" else "r01e_traffic_1024_s2000.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_1024_s2000.json" if a.driver == "persistent" else "r01f_traffic_1024_s2000.json")
         if S == 1024 and a.seeds == 2000 and a.np == 200 and a.ni == 200 and not a.one_shot and a.mode == "stacks" and os.path.exists(tpath):
             tj = json.load(open(tpath)).get("smc_trace" if a.driver == "persistent" else "ph_sample", {})
             if "FETCH_SIZE" in tj and "WRITE_SIZE" in tj:
