@@ -94,13 +94,13 @@ __global__ void gather_dirs(const unsigned char *__restrict__ Vx, const unsigned
 }
 
 // ---------------- host: tolerance flood-fill of one layer (ImageJ MaximumFinder) ----------------
-enum : unsigned char { F_MAXIMUM = 1, F_LISTED = 2, F_PROCESSED = 4, F_MAX_AREA = 8, F_EQUAL = 16, F_MAX_POINT = 32 };
+enum : unsigned char { F_MAXIMUM = 1, F_LISTED = 2, F_PROCESSED = 4, F_MAX_AREA = 8, F_EQUAL = 16, F_MAX_POINT = 32, F_BORDER = 64 };
 
 struct LayerFinder {
     int w, h;
     std::vector<unsigned char> flags;
     std::vector<int> list;
-    LayerFinder(int w_, int h_) : w(w_), h(h_), flags((size_t)w_ * h_), list((size_t)w_ * h_) {}
+    LayerFinder(int w_, int h_) : w(w_), h(h_), flags((size_t)w_ * h_ + 8), list((size_t)w_ * h_) {}
 
     static inline bool inside(int x, int y, int d, int w, int h)
     {
@@ -119,9 +119,11 @@ struct LayerFinder {
     // keys ascending; emits accepted maxima (pixel offsets) in processing order (highest first)
     void run(const unsigned char *L8, const i64 *keys, i64 nkeys, float tol, std::vector<int> &accepted)
     {
-        static const int DX[8] = {0, 1, 1, 1, 0, -1, -1, -1}, DY[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
         const int step[8] = {-w, -w + 1, 1, w + 1, w, w - 1, -1, -w - 1};
         std::memset(flags.data(), 0, flags.size());
+        for (int x = 0; x < w; x++) { flags[x] = F_BORDER; flags[(size_t)(h - 1) * w + x] = F_BORDER; } // image edge (seed.cpp: isWithin / edge tests)
+        for (int y = 0; y < h; y++) { flags[(size_t)y * w] = F_BORDER; flags[(size_t)y * w + w - 1] = F_BORDER; }
+        const uint32_t L3 = 0x010101u * F_LISTED;
         for (i64 q = nkeys - 1; q >= 0; --q) {
             int start = (int)(unsigned int)(keys[q] & 0xffffffffLL);
             if (flags[start] & F_PROCESSED) continue;
@@ -139,27 +141,38 @@ struct LayerFinder {
                 int neq = 1;
                 for (int cur = 0; cur < len; ++cur) {
                     const int off = list[cur];
-                    const int x = off % w, y = off / w;
-                    const bool inner = (y != 0 && y != h - 1) && (x != 0 && x != w - 1);
+                    const unsigned char *f = flags.data() + off;
+                    const bool inner = !(f[0] & F_BORDER);
+                    int x = 0, y = 0;
+                    if (inner) {
+                        // all eight neighbours already in the list (the usual case inside a large flood): every direction
+                        // of the loop below would `continue`
+                        uint32_t a, b;
+                        std::memcpy(&a, f - w - 1, 4);
+                        std::memcpy(&b, f + w - 1, 4);
+                        if ((a & L3) == L3 && (b & L3) == L3 && (f[-1] & f[1] & F_LISTED)) continue;
+                    } else {
+                        x = off % w; y = off / w;
+                    }
                     for (int d = 0; d < 8; d++) {
                         const int o2 = off + step[d];
                         if (!(inner || inside(x, y, d, w, h))) continue;
-                        if (flags[o2] & F_LISTED) continue;
-                        if (flags[o2] & F_PROCESSED) { possible = false; break; }
-                        const int x2 = x + DX[d], y2 = y + DY[d];
+                        const unsigned char f2 = flags[o2];
+                        if (f2 & F_LISTED) continue;
+                        if (f2 & F_PROCESSED) { possible = false; break; }
                         const float v2 = (float)L8[o2];
                         if (v2 > v0) { possible = false; break; } // maxSortingError == 0 (seed.cpp:634)
                         if (v2 >= v0 - tol) {
                             list[len++] = o2;
-                            flags[o2] |= F_LISTED;
-                            if (x2 == 0 || x2 == w - 1 || y2 == 0 || y2 == h - 1) {
+                            flags[o2] = f2 | F_LISTED;
+                            if (f2 & F_BORDER) {
                                 edge = true;
                                 possible = false; // excludeEdgesNow
                                 break;
                             }
                             if (v2 == v0) {
                                 flags[o2] |= F_EQUAL;
-                                ex += x2; ey += y2; neq++;
+                                ex += o2 % w; ey += o2 / w; neq++;
                             }
                         }
                     }
@@ -172,12 +185,12 @@ struct LayerFinder {
                 int besti = 0;
                 for (int k = 0; k < len; k++) {
                     const int off = list[k];
-                    const int x = off % w, y = off / w;
                     flags[off] &= keep;
                     flags[off] |= F_PROCESSED;
                     if (possible) {
                         flags[off] |= F_MAX_AREA;
                         if (flags[off] & F_EQUAL) {
+                            const int x = off % w, y = off / w;
                             const double d2 = (ex - x) * (double)(ex - x) + (ey - y) * (double)(ey - y);
                             if (d2 < best) { best = d2; besti = k; }
                         }
