@@ -625,6 +625,17 @@ static int gaussian3d(pnr_ctx *c, const std::vector<float> &gxy, const std::vect
     return PNR_OK;
 }
 
+// x pass of the separable Gaussian on a u8 stack (also the first pass of the soma path's xy blur, frangi.cpp:806-836)
+int pnr_gauss_x_u8_launch(pnr_ctx *c, const uint8_t *src, float *dst, const float *d_taps, int L)
+{
+    const int w = (int)c->w;
+    const i64 rows = c->h * c->l;
+    PNR_REQUIRE(L <= MAX_L, PNR_E_ARG, "Gaussian radius %d > %d", L, MAX_L);
+    const int tiles_x = (w + GX_BLOCK - 1) / GX_BLOCK;
+    hipLaunchKernelGGL(gauss_x_u8, dim3((unsigned)(rows * tiles_x)), dim3(GX_BLOCK), 0, c->stream, src, dst, w, rows, tiles_x, d_taps, L);
+    return PNR_OK;
+}
+
 static int check_grid(pnr_ctx *c)
 {
     const i64 rows = c->h * c->l;

@@ -1,15 +1,15 @@
 // soma.hip -- soma path for somaradius > 0 (Advantra_plugin.cpp:2426-2448, soma_extraction1 :1899-1915).
 //
 //   Frangi::imerode (xy)        frangi.cpp:880-968   erode_x / erode_y   u8 min filter, window 2*ceil(rad)+1, clamp-to-edge
-//   Frangi::imgaussian (u8, xy) frangi.cpp:786-878   gauss_x_f32 / gauss_y_trunc: the reference's y pass accumulates INTO the
+//   Frangi::imgaussian (u8, xy) frangi.cpp:786-878   gauss_x_u8 (frangi.hip) / gauss_y_trunc_hist: the reference's y pass accumulates INTO the
 //                                                    unsigned char output, i.e. converts the running sum back to u8 after
 //                                                    every tap -- reproduced tap by tap, ascending
-//   maxentropy_th               toolbox.cpp:657-737  hist256 on the GPU, the 256-bin entropy search on the host (libm logf/log)
+//   maxentropy_th               toolbox.cpp:657-737  256-bin histogram fused into the y pass, the entropy search on the host (libm logf/log)
 //   binarise + conn3d           :1901-1908, toolbox.cpp:245-509  foreground voxels are compacted on the GPU in raster order;
 //                               the region growing itself is sequential by definition (centroid / radius are running f32 means
 //                               in LIFO visit order) and runs on the host over the foreground voxels only
 //
-// All four kernels are streaming u8 / f32 passes (HBM-bound, a few ms at 1024^3).  Results: one SOMA node per region, a
+// The four kernels are streaming u8 / f32 passes.  Results: one SOMA node per region, a
 // sparse voxel -> node-index map used by the seed filter (:2561-2564), by the replay (tracker.cpp:858-869) and -- written
 // as "saturated" into the GPU density map -- by the trace kernels' early stop.
 #include "ctx.h"
@@ -53,48 +53,53 @@ __global__ __launch_bounds__(SOMA_BLOCK) void erode_y(const unsigned char *__res
     E[i] = (unsigned char)m;
 }
 
-// K[i0] += I[i1] * G[...], taps ascending, clamp-to-edge (frangi.cpp:806-836)
-__global__ __launch_bounds__(SOMA_BLOCK) void gauss_x_f32(const unsigned char *__restrict__ I, float *__restrict__ K, const float *__restrict__ G, int w,
-                                                         i64 n, int L)
+// y pass of the u8 Gaussian: `I[i0] = 0; I[i0] += K[i1] * G[...]` -- the left operand is an unsigned char, so the running sum is
+// truncated at every tap (frangi.cpp:839-872).  Tile: 64 (x, coalesced) x TYS (y) outputs, the TYS + 2L input rows staged in LDS;
+// the 256-bin histogram of the result (maxentropy_th's input, toolbox.cpp:663-668) is taken on the way out, eight interleaved
+// copies per work-group so that the dominant background value does not serialise on one LDS address.
+constexpr int TYS = 32;
+__global__ __launch_bounds__(256) void gauss_y_trunc_hist(const float *__restrict__ K, unsigned char *__restrict__ I, const float *__restrict__ G, int w,
+                                                          int h, int tiles_x, int tiles_y, int L, unsigned long long *__restrict__ hist)
 {
-    const i64 i = (i64)blockIdx.x * SOMA_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int x = (int)(i % w);
-    const i64 row = i - x;
-    float a = 0.f;
-    for (int d = -L; d <= L; d++) {
-        const int x1 = x + d < 0 ? 0 : (x + d > w - 1 ? w - 1 : x + d);
-        a += (float)I[row + x1] * G[d + L];
-    }
-    K[i] = a;
-}
-
-// I[i0] = 0; I[i0] += K[i1] * G[...]: the left operand is an unsigned char, so the sum is truncated at every tap (:839-872)
-__global__ __launch_bounds__(SOMA_BLOCK) void gauss_y_trunc(const float *__restrict__ K, unsigned char *__restrict__ I, const float *__restrict__ G, int w,
-                                                           int h, i64 n, int L)
-{
-    const i64 i = (i64)blockIdx.x * SOMA_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const i64 wh = (i64)w * h;
-    const i64 z = i / wh, r = i - z * wh;
-    const int y = (int)(r / w), x = (int)(r - (i64)y * w);
-    unsigned a = 0;
-    for (int d = -L; d <= L; d++) {
-        const int y1 = y + d < 0 ? 0 : (y + d > h - 1 ? h - 1 : y + d);
-        a = (unsigned)(int)((float)a + K[z * wh + (i64)y1 * w + x] * G[d + L]) & 0xffu; // value in [0, 255]: plain truncation
-    }
-    I[i] = (unsigned char)a;
-}
-
-__global__ __launch_bounds__(SOMA_BLOCK) void hist256(const unsigned char *__restrict__ I, i64 n, unsigned long long *__restrict__ hist)
-{
-    __shared__ unsigned int sh[256];
-    sh[threadIdx.x] = 0;
+    extern __shared__ float smem[]; // [(TYS + 2L)][64] | taps[2L+1] | hist[8][256] (u32)
+    float *s_in = smem;
+    float *s_tap = smem + (TYS + 2 * L) * 64;
+    unsigned int *s_hist = (unsigned int *)(s_tap + 2 * L + 1);
+    i64 b = blockIdx.x;
+    const int tx_tile = (int)(b % tiles_x);
+    b /= tiles_x;
+    const int ty_tile = (int)(b % tiles_y);
+    const i64 z = b / tiles_y;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int x = tx_tile * 64 + lane, y0 = ty_tile * TYS;
+    const float *base = K + z * (i64)w * h;
+    const int rows = TYS + 2 * L;
+    for (int t = threadIdx.x; t < 8 * 256; t += 256) s_hist[t] = 0;
+    if (x < w)
+        for (int r = grp; r < rows; r += 4) {
+            int y = y0 - L + r;
+            y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+            s_in[r * 64 + lane] = base[(i64)y * w + x];
+        }
+    for (int t = threadIdx.x; t < 2 * L + 1; t += 256) s_tap[t] = G[t];
     __syncthreads();
-    const i64 stride = (i64)gridDim.x * SOMA_BLOCK;
-    for (i64 i = (i64)blockIdx.x * SOMA_BLOCK + threadIdx.x; i < n; i += stride) atomicAdd(&sh[I[i]], 1u);
+    if (x < w) {
+        unsigned char *dst = I + z * (i64)w * h;
+#pragma unroll 1
+        for (int j = 0; j < TYS / 4; ++j) {
+            const int ry = grp + 4 * j, y = y0 + ry;
+            if (y >= h) break;
+            unsigned a = 0;
+            for (int k = 0; k <= 2 * L; ++k) a = (unsigned)(int)((float)a + s_in[(ry + k) * 64 + lane] * s_tap[k]) & 0xffu; // in [0, 255]: plain truncation
+            dst[(i64)y * w + x] = (unsigned char)a;
+            atomicAdd(&s_hist[(lane & 7) * 256 + a], 1u);
+        }
+    }
     __syncthreads();
-    if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+    unsigned int tot = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) tot += s_hist[q * 256 + threadIdx.x];
+    if (tot) atomicAdd(&hist[threadIdx.x], (unsigned long long)tot);
 }
 
 // foreground (E8 > th) voxels per (z,y) row, then their indices in raster order
@@ -258,10 +263,15 @@ int pnr_soma_run(pnr_ctx *c, uint8_t *E8_out, int32_t *threshold)
     c->tic();
     hipLaunchKernelGGL(erode_x, dim3(nb), dim3(SOMA_BLOCK), 0, st, c->d_img, d_K, w, n, Le);
     hipLaunchKernelGGL(erode_y, dim3(nb), dim3(SOMA_BLOCK), 0, st, (const unsigned char *)d_K, d_E, w, h, n, Le);
-    hipLaunchKernelGGL(gauss_x_f32, dim3(nb), dim3(SOMA_BLOCK), 0, st, (const unsigned char *)d_E, c->d_tmpA, (const float *)d_G, w, n, Lg);
-    hipLaunchKernelGGL(gauss_y_trunc, dim3(nb), dim3(SOMA_BLOCK), 0, st, (const float *)c->d_tmpA, d_E, (const float *)d_G, w, h, n, Lg);
-    hipLaunchKernelGGL(hist256, dim3(2048), dim3(SOMA_BLOCK), 0, st, (const unsigned char *)d_E, n, d_hist);
-    c->toc("soma", 5);
+    rc = pnr_gauss_x_u8_launch(c, d_E, c->d_tmpA, d_G, Lg); // K[i0] += I[i1] * G[...], taps ascending, clamp-to-edge (frangi.cpp:806-836)
+    if (rc) { cleanup(); return rc; }
+    {
+        const int tiles_x = (w + 63) / 64, tiles_y = (h + TYS - 1) / TYS;
+        const size_t sm = ((size_t)(TYS + 2 * Lg) * 64 + 2 * Lg + 1) * 4 + 8 * 256 * 4;
+        hipLaunchKernelGGL(gauss_y_trunc_hist, dim3((unsigned)((i64)tiles_x * tiles_y * l)), dim3(256), sm, st, (const float *)c->d_tmpA, d_E,
+                           (const float *)d_G, w, h, tiles_x, tiles_y, Lg, d_hist);
+    }
+    c->toc("soma", 4);
     unsigned long long hist[256];
     PNR_HIP(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, st));
     if (E8_out) PNR_HIP(hipMemcpyAsync(E8_out, d_E, (size_t)n, hipMemcpyDeviceToHost, st));

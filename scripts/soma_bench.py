@@ -26,6 +26,6 @@ for rep in range(3):
     t0 = time.time(); s = c.soma(); t1 = time.time()
     ms, n = c.kernel_ms("soma")
     N = S ** 3
-    print(f"rep {rep}: pnr_soma wall {t1 - t0:.3f} s, kernels {ms:.2f} ms ({n} launches) = {14 * N / (ms * 1e-3) / 1e9:.0f} GB/s of 14 B/voxel compulsory traffic; "
+    print(f"rep {rep}: pnr_soma wall {t1 - t0:.3f} s, kernels {ms:.2f} ms ({n} launches) = {13 * N / (ms * 1e-3) / 1e9:.0f} GB/s of 13 B/voxel compulsory traffic; "
           f"threshold {s['threshold']}, {len(s['nodes'])} soma nodes, {len(s['vox'])} foreground voxels", flush=True)
 print("nodes (x, y, z, r):", np.stack([s['nodes'][k] for k in ('x', 'y', 'z', 'sig')], -1).round(1).tolist()[:12])
