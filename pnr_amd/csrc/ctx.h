@@ -46,6 +46,7 @@ struct Tables {
     std::vector<int> axes_off;                            // per sigma offset into axes
     std::vector<float> wd;                                // sum(M): wgt - avg
     float ext_v = 0, ext_uw = 0;                          // largest |vv| and |uu|,|ww|
+    std::vector<float> ext_vs, ext_uws;                   // the same per sigma
     std::vector<uint32_t> rng;                            // np + 1 glibc rand() draws
     std::vector<std::vector<float>> gxy, gz;              // Gaussian taps per sigma
 };

@@ -562,6 +562,7 @@ int pnr_job_launch(pnr_ctx *c, pnr_trace_job *j, const pnr_seed *seeds, int64_t 
     TabX X;
     X.grid = (const Grid *)c->d_grid; X.axes = c->d_axes; X.axes_off = c->d_axes_off; X.wd = c->d_wd;
     X.ext_v = c->tab.ext_v; X.ext_uw = c->tab.ext_uw;
+    for (int s2 = 0; s2 < 8; s2++) { X.ext_vs[s2] = 0.f; X.ext_uws[s2] = 0.f; }
     { // pass-1 sample stash: one region per resident work-group (<= 1 per CU: each takes all 160 KB of LDS)
         int Mmax = 0;
         for (int s = 0; s < S; s++) Mmax = std::max(Mmax, c->tab.M[s]);

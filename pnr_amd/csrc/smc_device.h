@@ -213,7 +213,9 @@ struct Samples {
     float v[G];
 };
 
-template <int G, int CS, bool IS2D = false>
+// FAST: the caller guarantees that every sample of the group lies inside the volume (the clamp is the identity) and that its
+// corner pairs lie inside the cube (ph_predict proved it for all templates of this sigma): no clamp, no range test, no fallback.
+template <int G, int CS, bool IS2D = false, bool FAST = false>
 __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, const float (&x)[G], const float (&y)[G],
                                                    const float (&z)[G])
 {
@@ -224,14 +226,15 @@ __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, c
     bool all_in = true;
 #pragma unroll
     for (int j = 0; j < G; j++) {
-        const float xc = clamp3(x[j], 0.f, V.xmax), yc = clamp3(y[j], 0.f, V.ymax), zc = IS2D ? 0.f : clamp3(z[j], 0.f, V.zmax);
+        const float xc = FAST ? x[j] : clamp3(x[j], 0.f, V.xmax), yc = FAST ? y[j] : clamp3(y[j], 0.f, V.ymax);
+        const float zc = IS2D ? 0.f : (FAST ? z[j] : clamp3(z[j], 0.f, V.zmax));
         // xc - (float)(int)xc of the reference == xc - floor(xc) for xc >= 0, an exact subtraction: v_fract_f32
         xf[j] = __builtin_amdgcn_fractf(xc);
         yf[j] = __builtin_amdgcn_fractf(yc);
         zf[j] = __builtin_amdgcn_fractf(zc);
         const unsigned rx = (unsigned)((int)xc - B.ox), ry = (unsigned)((int)yc - B.oy), rz = (unsigned)((int)zc - B.oz);
         const unsigned m = max(max(rx, ry), rz);
-        in[j] = m < (unsigned)(CS - 1);
+        in[j] = FAST || m < (unsigned)(CS - 1);
         all_in = all_in && in[j];
         const unsigned l = __umul24(rz, CS * CS) + __umul24(ry, CS) + rx;
         loff[j] = in[j] ? l : 0u;
@@ -247,7 +250,7 @@ __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, c
             c[j][6] = a[CS * CS + CS]; c[j][7] = a1[CS * CS + CS];
         }
     }
-    if (__builtin_amdgcn_ballot_w64(!all_in) != 0ull) { // wave-uniform: some lane has a corner group outside the cube
+    if (!FAST && __builtin_amdgcn_ballot_w64(!all_in) != 0ull) { // wave-uniform: some lane has a corner group outside the cube
 #pragma unroll
         for (int j = 0; j < G; j++) {
             if (!in[j]) { // rare: recompute the voxel index instead of keeping it live for every sample
@@ -422,7 +425,7 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
 // Phase A: sampling is order-free, so it is cut into work items (sigma, group of 64 particles,
 // v-slice) that the 12 waves pull from a shared counter: the long (sigma >= 4) and short chains
 // no longer pin the iteration time to the longest chain.  Values go to the stash at [sample][lane].
-template <int CS, bool IS2D = false>
+template <int CS, bool IS2D = false, bool FAST = false>
 __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
                                              const float *__restrict__ ax, int iv, float *__restrict__ stash_lane, int iu0 = 0,
                                              int iu1 = 1 << 30)
@@ -449,7 +452,7 @@ __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const F
                 ys[j] = xy.y;
                 zs[j] = z1 + ww * f.wz;
             }
-            const Samples<G> sm = interp_group<G, CS, IS2D>(V, B, xs, ys, zs);
+            const Samples<G> sm = interp_group<G, CS, IS2D, FAST>(V, B, xs, ys, zs);
 #pragma unroll
             for (int j = 0; j < G; j++)
                 if (iw0 + j < nw) sp[(iw0 + j) * 64] = sm.v[j];
@@ -462,7 +465,7 @@ __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const F
 // wave `parts` = 64 / cnt times, copy p of chain j taking the template rows iu = p, p + parts, ... of the v-slice.
 // Sampling is order-free, so the values are the same as in sample_slice; they go to a narrow [sample][stride] region
 // (stride = cnt rounded up to 16 floats).  The per-lane uu comes from the row register by ds_bpermute.
-template <int CS, bool IS2D = false>
+template <int CS, bool IS2D = false, bool FAST = false>
 __device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
                                                     const float *__restrict__ ax, int iv, int parts, int p, bool active,
                                                     float *__restrict__ stash_col, int stride)
@@ -492,7 +495,7 @@ __device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, 
                 ys[j] = xy.y;
                 zs[j] = z1 + ww * f.wz;
             }
-            const Samples<G> sm = interp_group<G, CS, IS2D>(V, B, xs, ys, zs);
+            const Samples<G> sm = interp_group<G, CS, IS2D, FAST>(V, B, xs, ys, zs);
 #pragma unroll
             for (int j = 0; j < G; j++)
                 if (ok && iw0 + j < nw) sp[(iw0 + j) * stride] = sm.v[j];
@@ -559,6 +562,7 @@ struct TabX { // extra template tables for the box kernel
     const int *axes_off;
     const float *wd;    // sum(M): wgt - avg
     float ext_v, ext_uw; // largest template half-extents (voxels) along v and along u / w
+    float ext_vs[8], ext_uws[8]; // ... per sigma (PNR_MAX_SIGMAS = 8)
     float *stash;        // nslots x waves x Mmax x 64 f32 of HBM scratch (null: re-sample in pass 2)
     int *slot_busy;      // nslots flags, 0 = free
     int nslots;

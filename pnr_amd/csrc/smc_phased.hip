@@ -21,7 +21,7 @@
 
 namespace {
 
-enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_IT = 3, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_N = 16 };
+enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_IT = 3, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_FAST = 12, FL_N = 16 };
 constexpr int PH_THREADS = 1024; // sampling work-group: 16 waves (<= 128 VGPRs each)
 constexpr int PH_CS = 54; // the sampling kernel holds nothing but the cube in LDS: 54^3 = 157 464 B of the 160 KB
 
@@ -146,8 +146,40 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
                 fl[FL_Y0 + 2 * (a - 1)] = r0;
                 fl[FL_Y0 + 2 * (a - 1) + 1] = r1;
             }
+            sbox[a] = o; // origin for the per-sigma test below
         }
+        sbox[7] = (1 << T.nsig) - 1;
     }
+    __syncthreads();
+    // Per sigma: do ALL templates of this trace lie inside the cube and inside the volume?  Then the sampling kernel takes
+    // the variant without clamps, range tests and fallback for that sigma (the common case for the smaller scales).
+    {
+        const int dim[3] = {V.w, V.h, V.l};
+        const float hi_lim[3] = {V.xmax, V.ymax, V.zmax};
+        unsigned ok = (1u << T.nsig) - 1u;
+        for (int k = tid; k <= np; k += B) {
+            const float *q;
+            if (k == np) { if (pending < 0) continue; q = xc_pen; }
+            else { if (tail) continue; q = cur + k * PSTRIDE; }
+            const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
+            const float av[3] = {fabsf(q[3]), fabsf(q[4]), fabsf(q[5])};
+            const float auw[3] = {fabsf(f.ux) + fabsf(f.wx), fabsf(f.uy) + fabsf(f.wy), fabsf(f.uz) + fabsf(f.wz)};
+            for (int s = 0; s < T.nsig; s++) {
+                bool fit = true;
+                for (int a = 0; a < (V.l == 1 ? 2 : 3); a++) {
+                    const float e = X.ext_vs[s] * av[a] + X.ext_uws[s] * auw[a] + 0.5f;
+                    const float lo = q[a] - e, hi = q[a] + e;
+                    // inside the volume: the clamp to [0, dim - 1.001] is the identity; inside the cube: (int)coord - origin <= CS - 2
+                    fit = fit && lo >= 0.f && hi <= hi_lim[a] && floorf(lo) >= (float)sbox[a] && floorf(hi) + 1.f <= (float)(sbox[a] + CS - 1);
+                }
+                (void)dim;
+                if (!fit) ok &= ~(1u << s);
+            }
+        }
+        if (ok != (1u << T.nsig) - 1u) atomicAnd(&sbox[7], (int)ok);
+    }
+    __syncthreads();
+    if (tid == 0) fl[FL_FAST] = sbox[7];
 }
 
 template <int CS, bool IS2D>
@@ -203,6 +235,7 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
     }
     __syncthreads();
     const int ngf = P.ngf, rem = P.rem;
+    const int fastmask = __builtin_amdgcn_readfirstlane(fl[FL_FAST]); // sigmas whose templates all lie inside the cube and the volume
     // work items: a full group's item is ROWS template rows (iu) of one v-slice, the packed last group's a whole v-slice
     constexpr int ROWS = 5;
     int nvsum = 0, nchsum = 0;
@@ -249,7 +282,10 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
             if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
             const float *q = is_cen ? xc_pen : (valid ? cur + k * PSTRIDE : (tail ? xc_pen : cur));
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
-            sample_slice<CS, IS2D>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+            if (fastmask >> sI & 1)
+                sample_slice<CS, IS2D, true>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+            else
+                sample_slice<CS, IS2D, false>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
         } else {
             const int cnt = tail ? 1 : rem, jbase = tail ? rem - 1 : 0; // tail: the centroid's chains only
             const int parts = 64 / cnt;
@@ -621,6 +657,7 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     E.P.ngf = ngf; E.P.rem = rem; E.P.R = R; E.P.W = W;
     E.X.grid = (const Grid *)c->d_grid; E.X.axes = c->d_axes; E.X.axes_off = c->d_axes_off; E.X.wd = c->d_wd;
     E.X.ext_v = c->tab.ext_v; E.X.ext_uw = c->tab.ext_uw;
+    for (int s2 = 0; s2 < 8; s2++) { E.X.ext_vs[s2] = s2 < S ? c->tab.ext_vs[s2] : 0.f; E.X.ext_uws[s2] = s2 < S ? c->tab.ext_uws[s2] : 0.f; }
     E.X.stash = nullptr; E.X.slot_busy = nullptr; E.X.nslots = 0; E.X.slot_floats = 0; E.X.wave_floats = 0;
     hipDeviceProp_t prop;
     PNR_HIP(hipGetDeviceProperties(&prop, c->device));

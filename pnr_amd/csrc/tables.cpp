@@ -63,6 +63,7 @@ static void build_templates(const pnr_params &P, bool is2d, Tables &t)
     // weight exp(-uu^2 / 2 sig^2) -- the same product grid with a single w value 0
     t.M.clear(); t.moff.clear(); t.tmpl.clear(); t.mwgt.clear(); t.mavg.clear(); t.corrc.clear();
     t.grid.clear(); t.axes.clear(); t.axes_off.clear(); t.wd.clear(); t.ext_v = t.ext_uw = 0;
+    t.ext_vs.clear(); t.ext_uws.clear();
     int off = 0;
     for (int s = 0; s < P.nsig; s++) {
         const float sg = P.sig[s];
@@ -87,6 +88,13 @@ static void build_templates(const pnr_params &P, bool is2d, Tables &t)
         for (float x : av) t.ext_v = std::fmax(t.ext_v, std::fabs(x));
         for (float x : au) t.ext_uw = std::fmax(t.ext_uw, std::fabs(x));
         for (float x : aw) t.ext_uw = std::fmax(t.ext_uw, std::fabs(x));
+        {
+            float ev = 0, eu = 0;
+            for (float x : av) ev = std::fmax(ev, std::fabs(x));
+            for (float x : au) eu = std::fmax(eu, std::fabs(x));
+            for (float x : aw) eu = std::fmax(eu, std::fabs(x));
+            t.ext_vs.push_back(ev); t.ext_uws.push_back(eu);
+        }
         for (float vv = (float)-V2; vv <= V2 + FLT_MIN; vv += Vs)
             for (float uu = (float)-U2; uu <= U2 + FLT_MIN; uu += Vs) {
                 if (is2d) {
