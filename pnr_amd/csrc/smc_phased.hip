@@ -614,6 +614,7 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     PNR_HIP(hipMemGetInfo(&free_b, &total_b));
     size_t budget = (size_t)64 << 30;
     if (const char *e = getenv("PNR_STASH_GB")) budget = (size_t)std::max(1, atoi(e)) << 30;
+    if (const char *e = getenv("PNR_STASH_MB")) budget = (size_t)std::max(1, atoi(e)) << 20; // tests: force several waves / a narrow window
     const size_t have = (size_t)h->cap_traces * (size_t)h->trace_floats * 4; // our own stash counts as free
     budget = std::min(budget, (free_b + have) / 2);
     const int64_t nt_max = (int64_t)(budget / ((size_t)trace_floats * 4));

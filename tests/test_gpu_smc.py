@@ -247,6 +247,31 @@ def test_streaming_scheduler_edge_cases(monkeypatch, smc_driver, window, look0, 
         assert nt2 == maxtr + 1  # the loop ends after the trace that exceeds the cap (:2702)
 
 
+def test_small_stash_budget_gives_same_traces(monkeypatch, smc_driver):
+    """a stash budget that holds only a few traces: pnr_trace_batch runs in several waves, pnr_trace_replay with a narrower
+    window than asked for -- identical results"""
+    if smc_driver != "phased":
+        pytest.skip("the stash budget belongs to the phased driver")
+    img = synth.synth(80, 64, 32, seed=4)
+    p = pnr_amd.make_params(sigmas=[2.0, 3.0], np_=32, ni=30, zdist=2.0)
+    a = pnr_amd.Context(p, 0)
+    a.set_volume(img)
+    a.frangi()
+    seeds = a.score_filter_sort(a.extract_seeds())[:40]
+    Ta, sa, xa, _ = a.trace_batch(seeds)
+    na, la, _, _ = a.trace_replay(seeds)
+    monkeypatch.setenv("PNR_STASH_MB", "4")  # 2 x 4 MB / 2: room for a handful of traces
+    b = pnr_amd.Context(p, 0)
+    b.set_volume(img)
+    Tb, sb, xb, _ = b.trace_batch(seeds)
+    nb, lb, _, _ = b.trace_replay(seeds)
+    assert np.array_equal(Ta, Tb) and np.array_equal(sa, sb)
+    for j in range(len(Ta)):
+        rows = min(Ta[j] + 1, 30)
+        assert np.array_equal(mat(xa[j])[:rows], mat(xb[j])[:rows])
+    assert len(na) == len(nb) and np.array_equal(la, lb) and all(np.array_equal(na[k], nb[k]) for k in na.dtype.names)
+
+
 def test_trace_config5_shape_vs_oracle(oracle):
     """BASELINE configs[4] parameter shape at a size the oracle finishes in seconds: 4 scales {2,4,6,8},
     zdist=4 (anisotropic), np=500: chains loop over the work-group twice, the LDS cube shrinks to 44^3."""
