@@ -510,48 +510,55 @@ template <int STRIDE = 64, int CH = 32>
 __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash_lane, int M, const float *__restrict__ wd,
                                                  float corrc)
 {
-    static_assert(CH <= 64, "one template weight per lane and chunk");
-    const int lane = threadIdx.x & 63;
+    // M = nfull full chunks of CH values + a tail.  The full chunks run without any per-value test (each value is a handful of
+    // dependent VALU operations: a branch per value doubled the serial time of a chain); the next chunk is in flight meanwhile.
+    const int nfull = M / CH, tail = M - nfull * CH; // wave-uniform
     float cur[CH], nxt[CH];
     float ag = 0.f;
+    if (nfull > 0) {
 #pragma unroll
-    for (int j = 0; j < CH; j++) cur[j] = stash_lane[(j < M ? j : M - 1) * STRIDE];
-    for (int k0 = 0; k0 < M; k0 += CH) {
-        const int k1 = k0 + CH;
-        if (k1 < M) {
+        for (int j = 0; j < CH; j++) cur[j] = stash_lane[j * STRIDE];
+    }
+    for (int c = 0; c < nfull; c++) {
+        const float *nx = stash_lane + (i64)(c + 1) * CH * STRIDE;
+        if (c + 1 < nfull) {
 #pragma unroll
-            for (int j = 0; j < CH; j++) nxt[j] = stash_lane[(k1 + j < M ? k1 + j : M - 1) * STRIDE];
+            for (int j = 0; j < CH; j++) nxt[j] = nx[j * STRIDE];
         }
 #pragma unroll
-        for (int j = 0; j < CH; j++)
-            if (k0 + j < M) ag += cur[j];
+        for (int j = 0; j < CH; j++) ag += cur[j];
 #pragma unroll
         for (int j = 0; j < CH; j++) cur[j] = nxt[j];
     }
+    for (int k = nfull * CH; k < M; k++) ag += stash_lane[(i64)k * STRIDE];
     ag /= (float)M;
     float corra = 0.f, corrb = 0.f;
-    float w_cur, w_nxt = 0.f;
+    if (nfull > 0) {
 #pragma unroll
-    for (int j = 0; j < CH; j++) cur[j] = stash_lane[(j < M ? j : M - 1) * STRIDE];
-    w_cur = wd[(lane < CH && lane < M) ? lane : 0];
-    for (int k0 = 0; k0 < M; k0 += CH) {
-        const int k1 = k0 + CH;
-        if (k1 < M) {
+        for (int j = 0; j < CH; j++) cur[j] = stash_lane[j * STRIDE];
+    }
+    for (int c = 0; c < nfull; c++) {
+        const float *nx = stash_lane + (i64)(c + 1) * CH * STRIDE;
+        if (c + 1 < nfull) {
 #pragma unroll
-            for (int j = 0; j < CH; j++) nxt[j] = stash_lane[(k1 + j < M ? k1 + j : M - 1) * STRIDE];
-            w_nxt = wd[(lane < CH && k1 + lane < M) ? k1 + lane : 0];
+            for (int j = 0; j < CH; j++) nxt[j] = nx[j * STRIDE];
+        }
+        const float *wk = wd + c * CH; // wave-uniform address: scalar loads
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const float di = cur[j] - ag;
+            corra += di * wk[j];
+            corrb = (float)((double)corrb + (double)di * (double)di); // corrb += pow(f32,2)
         }
 #pragma unroll
-        for (int j = 0; j < CH; j++)
-            if (k0 + j < M) { // wave-uniform
-                const float di = cur[j] - ag;
-                corra += di * bcast(w_cur, j);
-                corrb = (float)((double)corrb + (double)di * (double)di); // corrb += pow(f32,2)
-            }
-#pragma unroll
         for (int j = 0; j < CH; j++) cur[j] = nxt[j];
-        w_cur = w_nxt;
     }
+    for (int k = nfull * CH; k < M; k++) {
+        const float di = stash_lane[(i64)k * STRIDE] - ag;
+        corra += di * wd[k];
+        corrb = (float)((double)corrb + (double)di * (double)di);
+    }
+    (void)tail;
     const float prod = corrb * corrc;
     return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f; // tracker.cpp:1955
 }
