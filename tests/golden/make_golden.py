@@ -46,6 +46,27 @@ def main():
                    Dzz=H[0], Dyy=H[1], Dyz=H[2], Dxx=H[3], Dxy=H[4], Dxz=H[5])
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, "Jmax", jmax, "seeds", len(seeds), os.path.getsize(os.path.join(HERE, name + ".npz")) // 1024, "KiB")
+    # 2-D mode (single-slice stack): Frangi::frangi2d / hessian2d / extractSeeds of the reference
+    for name, (w, h, seed, sigs, tol) in {"p2d_96x80_s2-3": (96, 80, 4, [2.0, 3.0], 5.0), "p2d_33x21_s2": (33, 21, 6, [2.0], 5.0)}.items():
+        img = np.ascontiguousarray(synth.synth(w, h, 9, seed=seed).max(0, keepdims=True))
+        J, jmin, jmax, Vx, Vy, Vz = orc.frangi2d(R, img.copy(), sigs, prefix="ref")
+        J8 = orc.j8(L, J, jmin, jmax)
+        seeds = orc.extract_seeds(R, tol, J8, Vx, Vy, Vz, prefix="ref")
+        D = [np.zeros(img.shape, np.float32) for _ in range(3)]
+        R.ref_hessian2d(img.copy(), w, h, np.float32(sigs[0]), *D)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), img=img, sigs=np.float32(sigs), tol=np.float32(tol), J=J, Jmin=np.float32(jmin),
+                            Jmax=np.float32(jmax), Vx=Vx, Vy=Vy, Vz=Vz, J8_restated=J8, seeds=seeds, Dyy=D[0], Dxy=D[1], Dxx=D[2])
+        print(name, "Jmax", jmax, "seeds", len(seeds))
+    # soma path: Frangi::imerode (xy) and the u8 Frangi::imgaussian of the reference
+    for name, (w, h, l, seed, rad, somas) in {"soma_64x56x32_r3": (64, 56, 32, 2, 3, ((20, 28, 16, 6), (48, 20, 14, 5))),
+                                              "soma_23x20x9_r2": (23, 20, 9, 3, 2, ((10, 10, 4, 4),))}.items():
+        img = synth.add_somas(synth.synth(w, h, l, seed=seed), somas)
+        E = np.zeros_like(img)
+        R.ref_imerode_xy(img.copy(), w, h, l, np.float32(rad), E)
+        G = E.copy()
+        R.ref_imgaussian_u8_xy(G, w, h, l, np.float32(rad))
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), img=img, rad=np.int32(rad), eroded=E, blurred=G)
+        print(name, "eroded max", E.max(), "blurred max", G.max())
     # eigen KATs: random symmetric matrices incl. degenerate / diagonal / zero cases
     rs = np.random.RandomState(7)
     A = rs.randn(512, 3, 3)

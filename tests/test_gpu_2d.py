@@ -127,3 +127,19 @@ def test_end_to_end_2d_vs_oracle(oracle):
     assert len(res["tree"]) == len(tree_o) and np.array_equal(res["parent"], par_o)
     for k in tree_o.dtype.names:
         assert np.array_equal(res["tree"][k], tree_o[k]), k
+
+
+@pytest.mark.parametrize("name", ["p2d_96x80_s2-3", "p2d_33x21_s2"])
+def test_frangi2d_seeds_vs_golden(name):
+    """the reference's own frangi2d / extractSeeds outputs (tests/golden/make_golden.py), bit for bit"""
+    import os
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz")))
+    c = pnr_amd.Context(pnr_amd.make_params(sigmas=[float(v) for v in g["sigs"]], tolerance=float(g["tol"]), np_=20, ni=5), 0)
+    c.set_volume(g["img"])
+    jmin, jmax = c.frangi()
+    f = c.get_frangi()
+    assert np.array_equal(f["J"], g["J"]) and jmin == g["Jmin"] and jmax == g["Jmax"]
+    assert np.array_equal(f["Vx"], g["Vx"]) and np.array_equal(f["Vy"], g["Vy"]) and np.array_equal(f["Vz"], g["Vz"])
+    assert np.array_equal(f["J8"], g["J8_restated"])
+    s = c.extract_seeds()
+    assert len(s) == len(g["seeds"]) and np.array_equal(mat(s)[:, :6], g["seeds"][:, :6], equal_nan=True)

@@ -103,3 +103,14 @@ def test_end_to_end_with_soma_vs_oracle(oracle, driver):
     T, stop, xc, _ = c.trace_batch(res["seeds"])
     n1, l1, _ = c.replay(res["seeds"], T, xc)
     assert len(n1) == len(nodes) and np.array_equal(l1, links)
+
+
+@pytest.mark.parametrize("name", ["soma_64x56x32_r3", "soma_23x20x9_r2"])
+def test_soma_filters_vs_golden(name):
+    """eroded + blurred stack against the reference's own Frangi::imerode / u8 Frangi::imgaussian (tests/golden)"""
+    import os
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz")))
+    c = pnr_amd.Context(pnr_amd.make_params(sigmas=[2.0], somaradius=int(g["rad"]), np_=20, ni=5), 0)
+    c.set_volume(g["img"])
+    s = c.soma(want_e8=True)
+    assert np.array_equal(s["E8"], g["blurred"])

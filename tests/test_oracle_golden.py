@@ -186,3 +186,36 @@ def test_frangi2d_vs_reference(oracle, ref, shape, sigs):
     assert np.array_equal(Vxo, Vxr) and np.array_equal(Vyo, Vyr) and np.array_equal(Vzo, Vzr) and not Vzo.any()
     if min(h, w) > 16:
         assert jMo > 0.05
+
+
+# ---- committed fixtures of the reference's 2-D Frangi and soma filters (tests/golden/make_golden.py) ----
+def _load(name):
+    return dict(np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz")))
+
+
+@pytest.mark.parametrize("name", ["p2d_96x80_s2-3", "p2d_33x21_s2"])
+def test_oracle_2d_matches_golden(oracle, name):
+    g = _load(name)
+    img = g["img"]; _, h, w = img.shape
+    D = [np.zeros(img.shape, np.float32) for _ in range(3)]
+    oracle.orc_hessian2d(img, w, h, float(g["sigs"][0]), *D)
+    for got, key in zip(D, ("Dyy", "Dxy", "Dxx")):
+        assert np.array_equal(got, g[key]), key
+    J, jmin, jmax, Vx, Vy, Vz = orc.frangi2d(oracle, img, g["sigs"])
+    assert np.array_equal(J, g["J"]) and jmin == g["Jmin"] and jmax == g["Jmax"]
+    assert np.array_equal(Vx, g["Vx"]) and np.array_equal(Vy, g["Vy"]) and np.array_equal(Vz, g["Vz"])
+    J8 = orc.j8(oracle, J, jmin, jmax)
+    assert np.array_equal(J8, g["J8_restated"])
+    s = orc.extract_seeds(oracle, float(g["tol"]), J8, Vx, Vy, Vz)
+    assert np.array_equal(s, g["seeds"], equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["soma_64x56x32_r3", "soma_23x20x9_r2"])
+def test_oracle_soma_filters_match_golden(oracle, name):
+    g = _load(name)
+    img = g["img"]; l, h, w = img.shape
+    E = np.zeros_like(img)
+    oracle.orc_imerode_xy(img, w, h, l, float(g["rad"]), E)
+    assert np.array_equal(E, g["eroded"])
+    oracle.orc_imgaussian_u8_xy(E, w, h, l, float(g["rad"]))
+    assert np.array_equal(E, g["blurred"])
