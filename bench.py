@@ -134,9 +134,14 @@ def main():
     def step():
         st = {}
         t0 = time.perf_counter()
-        ctx.frangi()
-        t1 = time.perf_counter()
-        s0 = ctx.extract_seeds()
+        if a.mode == "shard" and world > 1:  # one stack: z-slabs of Frangi + seeds per rank, 2-float all-reduce, seed all-gather
+            mine, _, _ = multigpu.frangi_seeds_sharded(ctx, img.data_ptr(), (S, S, S), dist, rank, world, device=torch.device("cuda", local))
+            t1 = time.perf_counter()
+            s0 = multigpu.gather_seeds(mine, dist, rank, world, torch.device("cuda", local))
+        else:
+            ctx.frangi()
+            t1 = time.perf_counter()
+            s0 = ctx.extract_seeds()
         t2 = time.perf_counter()
         s = ctx.score_filter_sort(s0)[:a.seeds]
         t3 = time.perf_counter()
@@ -217,7 +222,7 @@ def main():
             "config": {"workload": f"{S}^3 synthetic u8 stack (tests/synth.py seed {stack_seed}), scales={{2,4,6}}, zdist=2, np={a.np}, ni={a.ni}, "
                                    f"first {a.seeds} sorted seeds traced in both directions per stack, tolerance=5, znccth=0.3, step=2, kappa=3",
                        "parallelism": ("1 GPU" if world == 1 else (f"{world} independent stacks, one per GPU; RCCL gather of node graphs" if a.mode == "stacks"
-                                       else f"seeds of one stack round-robin over {world} GPUs; RCCL gather of trace records"))},
+                                       else f"one stack: Frangi + seeds in z-slabs, sorted seeds round-robin over {world} GPUs; RCCL all-reduce(min,max), all-gather of seeds and trace records"))},
             "roofline": {"kernel": kname, "bound": "hbm", "bytes_per_launch": bytes_launch, "avg_launch_ms": smc_ms / max(smc_n, 1), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "note": "algorithmic gather bytes 8*sum(M_sigma)=%d B per particle evaluation; served from L1/L2, see DESIGN.md" % (8 * Mtot)},

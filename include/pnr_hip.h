@@ -100,6 +100,14 @@ int pnr_set_volume_device(pnr_ctx *ctx, const void *dev_img, int64_t w, int64_t 
 /* Frangi::frangi3d (frangi.cpp:152-289; called at Advantra_plugin.cpp:2496) followed by the
  * J -> J8 rule (:2499-2512).  Results stay in HBM; Jmin/Jmax are returned. */
 int pnr_frangi(pnr_ctx *ctx, float *Jmin, float *Jmax);
+/* z-slab sharding of Frangi / seed extraction over several GPUs: the context's volume is a slab of the stack WITH a
+ * halo of ceil(3*sigma_max/zdist) + 2 planes on every cut side (the z pass of the Gaussian plus the radius-2 Hessian stencil), so
+ * that the planes [z_keep0, z_keep1) of the slab are exactly what the whole stack would give.  pnr_frangi_slab runs every scale and
+ * returns Jmin / Jmax over the kept planes only; after the ranks have reduced them to the global extremes, pnr_quantise_j8 applies
+ * the J -> J8 rule (Advantra_plugin.cpp:2499-2512) and pnr_extract_seeds_range(z_keep0, z_keep1) gives the slab's seeds. */
+int pnr_frangi_slab(pnr_ctx *ctx, int64_t z_keep0, int64_t z_keep1, float *Jmin, float *Jmax);
+int pnr_quantise_j8(pnr_ctx *ctx, float Jmin, float Jmax);
+
 /* Optional read-back of the Frangi outputs (any pointer may be NULL); N = w*h*l each. */
 int pnr_get_frangi(pnr_ctx *ctx, float *J, uint8_t *J8, uint8_t *Vx, uint8_t *Vy, uint8_t *Vz);
 /* Test taps: Frangi::imgaussian (frangi.cpp:647) and Frangi::hessian3d (:291) for one sigma.

@@ -252,6 +252,23 @@ int pnr_frangi(pnr_ctx *c, float *Jmin, float *Jmax)
     return pnr_frangi_run(c, Jmin, Jmax);
 }
 
+int pnr_frangi_slab(pnr_ctx *c, int64_t z_keep0, int64_t z_keep1, float *Jmin, float *Jmax)
+{
+    PNR_REQUIRE(c && c->d_img, PNR_E_STATE, "pnr_frangi_slab: no volume set");
+    PNR_REQUIRE(c->l > 1, PNR_E_ARG, "pnr_frangi_slab: a single-slice stack has no z-slabs");
+    PNR_REQUIRE(z_keep0 >= 0 && z_keep0 < z_keep1 && z_keep1 <= c->l, PNR_E_ARG, "kept planes [%lld,%lld) outside [0,%lld)", (long long)z_keep0,
+                (long long)z_keep1, (long long)c->l);
+    PNR_HIP(hipSetDevice(c->device));
+    return pnr_frangi_run_range(c, z_keep0, z_keep1, /*finish*/ false, Jmin, Jmax);
+}
+
+int pnr_quantise_j8(pnr_ctx *c, float Jmin, float Jmax)
+{
+    PNR_REQUIRE(c && c->d_img, PNR_E_STATE, "pnr_quantise_j8: no volume set");
+    PNR_HIP(hipSetDevice(c->device));
+    return pnr_j8_run(c, Jmin, Jmax);
+}
+
 int pnr_get_frangi(pnr_ctx *c, float *J, uint8_t *J8, uint8_t *Vx, uint8_t *Vy, uint8_t *Vz)
 {
     PNR_REQUIRE(c && c->have_j8 && c->d_J, PNR_E_STATE, "pnr_get_frangi: run pnr_frangi first");

@@ -173,6 +173,8 @@ struct pnr_ctx {
 
 // stage entry points implemented in the .hip files
 int pnr_frangi_run(pnr_ctx *c, float *Jmin, float *Jmax);
+int pnr_frangi_run_range(pnr_ctx *c, int64_t zs0, int64_t zs1, bool finish, float *Jmin, float *Jmax);
+int pnr_j8_run(pnr_ctx *c, float jmin, float jmax);
 int pnr_gaussian_run(pnr_ctx *c, float sig, float *d_out /*device N floats*/);
 int pnr_hessian_run(pnr_ctx *c, float sig, float *const d_out[6]);
 int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1);

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(HE_BLOCK, 8) void hessian_eigen(const float *__rest
                                                       unsigned char *__restrict__ Vx, unsigned char *__restrict__ Vy,
                                                       unsigned char *__restrict__ Vz, int w, int h, int l, int tiles_x,
                                                       float s2, float two_a2, float two_b2, float two_c2, int first,
-                                                      unsigned int *__restrict__ minmax, HessOut dump)
+                                                      unsigned int *__restrict__ minmax, HessOut dump, int zs0 = 0, int zs1 = 1 << 30)
 {
     const i64 b = blockIdx.x;
     const i64 row = b / tiles_x;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(HE_BLOCK, 8) void hessian_eigen(const float *__rest
                 Vx[i] = quant_dir(V[0][0]);
                 Vy[i] = quant_dir(V[1][0]);
                 Vz[i] = quant_dir(V[2][0]);
-                omin = omax = f2ord(jf);
+                if (z >= zs0 && z < zs1) omin = omax = f2ord(jf); // Jmin / Jmax over the planes this context owns (z-slab sharding)
             }
         }
     }
@@ -674,7 +674,32 @@ int pnr_hessian_run(pnr_ctx *c, float sig, float *const d_out[6])
     return PNR_OK;
 }
 
-int pnr_frangi_run(pnr_ctx *c, float *Jmin, float *Jmax)
+// J -> J8 with the given extremes (Advantra_plugin.cpp:2499-2512)
+int pnr_j8_run(pnr_ctx *c, float jmin, float jmax)
+{
+    PNR_REQUIRE(c->d_J && c->frangi_cap >= c->N, PNR_E_STATE, "no Frangi response to quantise");
+    c->Jmin = jmin;
+    c->Jmax = jmax;
+    const int flat = std::fabs(c->Jmax - c->Jmin) <= FLT_MIN;
+    c->tic();
+    {
+        i64 blocks = (c->N + 1023) / 1024;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(j8_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_J, c->d_J8, c->N, c->Jmin,
+                           c->Jmax, flat);
+    }
+    c->toc("j8");
+    PNR_HIP(hipGetLastError());
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    c->have_j8 = true;
+    return PNR_OK;
+}
+
+int pnr_frangi_run(pnr_ctx *c, float *Jmin, float *Jmax) { return pnr_frangi_run_range(c, 0, c->l, true, Jmin, Jmax); }
+
+// Frangi with Jmin / Jmax taken over the planes [zs0, zs1) only; finish = false leaves J unquantised (z-slab sharding: the
+// ranks first agree on the global extremes, then call pnr_j8_run)
+int pnr_frangi_run_range(pnr_ctx *c, int64_t zs0, int64_t zs1, bool finish, float *Jmin, float *Jmax)
 {
     int rc = check_grid(c);
     if (rc) return rc;
@@ -700,7 +725,7 @@ int pnr_frangi_run(pnr_ctx *c, float *Jmin, float *Jmax)
         } else
         hipLaunchKernelGGL(hessian_eigen<false>, dim3((unsigned)((i64)h * l * tiles_x)), dim3(HE_BLOCK), 0, c->stream, c->d_tmpA,
                            c->d_J, c->d_Vx, c->d_Vy, c->d_Vz, w, h, l, tiles_x, P.sig[s] * P.sig[s], two_a2, two_b2, two_c2,
-                           s == 0 ? 1 : 0, c->d_minmax, HessOut{});
+                           s == 0 ? 1 : 0, c->d_minmax, HessOut{}, (int)zs0, (int)zs1);
         c->toc("hessian_eigen");
     }
     unsigned int mm[2];
@@ -709,18 +734,11 @@ int pnr_frangi_run(pnr_ctx *c, float *Jmin, float *Jmax)
     hipFree(d_taps);
     c->Jmin = ord2f(mm[0]);
     c->Jmax = ord2f(mm[1]);
-    const int flat = std::fabs(c->Jmax - c->Jmin) <= FLT_MIN;
-    c->tic();
-    {
-        i64 blocks = (c->N + 1023) / 1024;
-        if (blocks > 256 * 16) blocks = 256 * 16;
-        hipLaunchKernelGGL(j8_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_J, c->d_J8, c->N, c->Jmin,
-                           c->Jmax, flat);
+    c->have_j8 = false;
+    if (finish) {
+        rc = pnr_j8_run(c, c->Jmin, c->Jmax);
+        if (rc) return rc;
     }
-    c->toc("j8");
-    PNR_HIP(hipGetLastError());
-    PNR_HIP(hipStreamSynchronize(c->stream));
-    c->have_j8 = true;
     if (Jmin) *Jmin = c->Jmin;
     if (Jmax) *Jmax = c->Jmax;
     return PNR_OK;

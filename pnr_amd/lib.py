@@ -82,6 +82,8 @@ def load():
     L.pnr_trace_replay.argtypes = [vp, vp, i64, i64, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.pnr_reconstruct.argtypes = [vp, i64, vp, i64, C.c_float, C.c_float, i32, C.c_float, C.c_float, i32, vp, vp, i64, C.POINTER(i64)]
     L.pnr_get_table.argtypes = [vp, C.c_char_p, vp, i64, C.POINTER(i64)]
+    L.pnr_frangi_slab.argtypes = [vp, i64, i64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.pnr_quantise_j8.argtypes = [vp, C.c_float, C.c_float]
     L.pnr_soma.argtypes = [vp, vp, C.POINTER(C.c_int32), C.POINTER(i64)]
     L.pnr_get_soma.argtypes = [vp, vp, i64, C.POINTER(i64), vp, vp, i64, C.POINTER(i64)]
     L.pnr_replay_traces_ctx.argtypes = [vp, vp, i64, vp, vp, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64)]
@@ -100,7 +102,7 @@ def load():
 EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", "pnr_set_stream", "pnr_synchronize",
            "pnr_set_volume", "pnr_set_volume_device", "pnr_frangi", "pnr_get_frangi", "pnr_gaussian", "pnr_hessian",
            "pnr_set_j8_v", "pnr_extract_seeds", "pnr_extract_seeds_range", "pnr_zncc_batch",
-           "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_replay_traces_ctx", "pnr_soma", "pnr_get_soma", "pnr_trace_replay", "pnr_reconstruct", "pnr_get_table", "pnr_set_profiling", "pnr_set_smc_driver",
+           "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_replay_traces_ctx", "pnr_frangi_slab", "pnr_quantise_j8", "pnr_soma", "pnr_get_soma", "pnr_trace_replay", "pnr_reconstruct", "pnr_get_table", "pnr_set_profiling", "pnr_set_smc_driver",
            "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch"]
 
 
@@ -173,6 +175,15 @@ class Context:
         a, b = C.c_float(), C.c_float()
         check(self.L.pnr_frangi(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def frangi_slab(self, z_keep0, z_keep1):
+        """Frangi of a slab with halo: (Jmin, Jmax) over the kept planes only, J not yet quantised (pnr_frangi_slab)"""
+        a, b = C.c_float(), C.c_float()
+        check(self.L.pnr_frangi_slab(self.h, z_keep0, z_keep1, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def quantise_j8(self, jmin, jmax):
+        check(self.L.pnr_quantise_j8(self.h, jmin, jmax))
 
     def get_frangi(self, J=True, J8=True, V=True):
         out = {}

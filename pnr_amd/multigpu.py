@@ -61,6 +61,61 @@ def trace_sharded(ctx, seeds, dist, rank, world, trace_fn=None, device=None, par
     return nodes, links, T_all
 
 
+def slab_bounds(l, rank, world, halo):
+    """planes [z0, z1) owned by `rank` and the slab [zlo, zhi) it has to filter to get them exactly"""
+    z0, z1 = (l * rank) // world, (l * (rank + 1)) // world
+    return z0, z1, max(0, z0 - halo), min(l, z1 + halo)
+
+
+def frangi_halo(params):
+    """planes a cut side needs: radius of the z pass of the widest Gaussian (sigma / zdist) + the radius-2 Hessian stencil"""
+    import math
+    smax = max(params.sig[i] for i in range(params.nsig))
+    return int(math.ceil(3 * (smax / params.zdist))) + 2
+
+
+def frangi_seeds_sharded(ctx, img_ptr, shape, dist, rank, world, device=None, reduce_fn=None):
+    """Frangi + seed extraction of ONE replicated stack split into z-slabs: each rank filters its slab (+ halo) from its own copy
+    of the image -- no halo exchange --, the ranks all-reduce Jmin / Jmax (2 floats), quantise J8 with the global extremes and
+    extract the seeds of their own layers (MaximumFinder works per layer, seed.cpp:574).  Returns this rank's seeds with global
+    z; the caller all-gathers them (concatenated by rank they are in the z-major order of the unsharded extraction).
+    `img_ptr` is the device pointer of the whole u8 stack; the context is left pointing at the whole stack again."""
+    l, h, w = shape
+    halo = frangi_halo(ctx.p)
+    z0, z1, zlo, zhi = slab_bounds(l, rank, world, halo)
+    seeds = np.zeros(0, SEED_DT)
+    jmin, jmax = np.float32(np.inf), np.float32(-np.inf)
+    if z1 > z0:
+        ctx.set_volume_device(img_ptr + zlo * h * w, (zhi - zlo, h, w))
+        jmin, jmax = ctx.frangi_slab(z0 - zlo, z1 - zlo)
+    if reduce_fn is not None:  # tests: emulate the all-reduce without a process group
+        jmin, jmax = reduce_fn(jmin, jmax)
+    elif world > 1:
+        dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
+        t = torch.tensor([-float(jmin), float(jmax)], dtype=torch.float32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        jmin, jmax = -float(t[0].item()), float(t[1].item())
+    if z1 > z0:
+        ctx.quantise_j8(jmin, jmax)
+        seeds = ctx.extract_seeds(z0 - zlo, z1 - zlo)
+        seeds["z"] += np.float32(zlo)
+    ctx.set_volume_device(img_ptr, (l, h, w))
+    return seeds, float(jmin), float(jmax)
+
+
+def gather_seeds(seeds, dist, rank, world, device):
+    """variable-length all-gather of the per-slab seed lists (counts first, then padded payloads); concatenated by rank they are
+    in the z-major order of the unsharded extraction"""
+    cnt = torch.tensor([len(seeds)], dtype=torch.int64, device=device)
+    cnts = torch.stack(_all_gather(dist, cnt, world)).cpu().numpy().reshape(-1)
+    m = int(cnts.max()) if len(cnts) else 0
+    buf = torch.zeros((max(m, 1), SEED_DT.itemsize // 4), dtype=torch.float32)
+    if len(seeds):
+        buf[:len(seeds)] = torch.from_numpy(np.ascontiguousarray(seeds).view(np.float32).reshape(len(seeds), -1))
+    parts = _all_gather(dist, buf.to(device), world)
+    return np.concatenate([parts[r].cpu().numpy()[:cnts[r]].copy().view(SEED_DT).reshape(-1) for r in range(world)])
+
+
 def gather_graphs(nodes, links, dist, rank, world, device):
     """Final node-graph gather for independent stacks: variable-length node / link lists of every
     rank to rank 0 (counts first, then padded payloads).  Returns [(nodes, links)] * world on

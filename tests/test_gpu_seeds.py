@@ -51,3 +51,37 @@ def test_seeds_require_frangi_first():
     c.set_volume(np.zeros((4, 8, 8), np.uint8))
     with pytest.raises(pnr_amd.PnrError, match="pnr_frangi"):
         c.extract_seeds()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_zslab_sharding_equals_whole_stack(world):
+    """Frangi + seeds of a stack cut into z-slabs with halo (pnr_frangi_slab / pnr_quantise_j8 / pnr_extract_seeds_range, one
+    'rank' after the other on this GPU): same Jmin / Jmax, same seeds in the same order as the unsharded extraction"""
+    import torch
+    from pnr_amd import multigpu
+    img = synth.synth(64, 56, 48, seed=3)
+    p = pnr_amd.make_params(sigmas=[2.0, 4.0], zdist=2.0, np_=20, ni=5)
+    c = pnr_amd.Context(p, 0)
+    c.set_volume(img)
+    jmin, jmax = c.frangi()
+    want = c.extract_seeds()
+    dimg = torch.from_numpy(img).cuda()
+    # pass 1: every rank's extremes; pass 2: quantise with the reduced ones (what the all-reduce does)
+    ext = []
+    for r in range(world):
+        ctx = pnr_amd.Context(p, 0)
+        _, a, b = multigpu.frangi_seeds_sharded(ctx, dimg.data_ptr(), img.shape, None, r, world, reduce_fn=lambda a, b: (a, b))
+        ext.append((a, b))
+        ctx.close()
+    gmin, gmax = min(e[0] for e in ext), max(e[1] for e in ext)
+    assert gmin == jmin and gmax == jmax
+    got = []
+    for r in range(world):
+        ctx = pnr_amd.Context(p, 0)
+        s, _, _ = multigpu.frangi_seeds_sharded(ctx, dimg.data_ptr(), img.shape, None, r, world, reduce_fn=lambda a, b: (gmin, gmax))
+        got.append(s)
+        ctx.close()
+    got = np.concatenate(got)
+    assert len(got) == len(want) > 20
+    for k in want.dtype.names:
+        assert np.array_equal(got[k], want[k], equal_nan=True), k

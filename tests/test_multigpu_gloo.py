@@ -51,11 +51,18 @@ def _worker(rank, world, port, q):
     nodes, links, T_all = multigpu.trace_sharded(None, seeds, dist, rank, world, trace_fn=trace_fn, device=torch.device("cpu"),
                                                  params=p, shape=img.shape)
     graphs = multigpu.gather_graphs(nodes, links, dist, rank, world, torch.device("cpu"))
+    # ragged seed all-gather (z-slab sharding of the seed extraction): rank r contributes seeds[r::world]... as contiguous slices
+    cut = [0, len(seeds) // 3, len(seeds)][: world + 1] if world == 2 else None
+    mine = seeds[cut[rank]:cut[rank + 1]]
+    allseeds = multigpu.gather_seeds(mine, dist, rank, world, torch.device("cpu"))
+    seeds_ok = len(allseeds) == len(seeds) and all(np.array_equal(allseeds[k], seeds[k], equal_nan=True) for k in seeds.dtype.names)
+    z0, z1, zlo, zhi = multigpu.slab_bounds(24, rank, world, multigpu.frangi_halo(p))
+    seeds_ok = seeds_ok and (z0, z1) == ((0, 12) if rank == 0 else (12, 24)) and zlo == max(0, z0 - 5) and zhi == min(24, z1 + 5)
     if rank == 0:
         Tf, _, xcf = trace_fn(seeds)  # unsharded
         n1, l1, _ = lib.replay(p, img.shape, seeds, Tf, xcf.view(lib.XEST_DT).reshape(len(Tf), ni))
         ok = np.array_equal(T_all, Tf) and np.array_equal(links, l1) and all(np.array_equal(nodes[k], n1[k]) for k in nodes.dtype.names)
-        ok = ok and len(graphs) == world and all(np.array_equal(g[1], links) and np.array_equal(g[0]["x"], nodes["x"]) for g in graphs)
+        ok = ok and seeds_ok and len(graphs) == world and all(np.array_equal(g[1], links) and np.array_equal(g[0]["x"], nodes["x"]) for g in graphs)
         q.put((ok, len(nodes), int(Tf.sum())))
     dist.barrier()
     dist.destroy_process_group()
