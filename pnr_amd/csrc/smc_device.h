@@ -548,7 +548,9 @@ __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash
         for (int j = 0; j < CH; j++) {
             const float di = cur[j] - ag;
             corra += di * wk[j];
-            corrb = (float)((double)corrb + (double)di * (double)di); // corrb += pow(f32,2)
+            // corrb += pow(f32,2): the f64 product of two f32 values is exact (48 bits), so one fused multiply-add rounds exactly
+            // like the multiply followed by the add -- one f64-rate instruction less per value
+            corrb = (float)__builtin_fma((double)di, (double)di, (double)corrb);
         }
 #pragma unroll
         for (int j = 0; j < CH; j++) cur[j] = nxt[j];
@@ -556,7 +558,7 @@ __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash
     for (int k = nfull * CH; k < M; k++) {
         const float di = stash_lane[(i64)k * STRIDE] - ag;
         corra += di * wd[k];
-        corrb = (float)((double)corrb + (double)di * (double)di);
+        corrb = (float)__builtin_fma((double)di, (double)di, (double)corrb);
     }
     (void)tail;
     const float prod = corrb * corrc;
