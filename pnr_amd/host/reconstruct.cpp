@@ -4,6 +4,7 @@
 #include <cfloat>
 #include <cmath>
 #include <numeric>
+#include <thread>
 #include <unordered_map>
 
 namespace advantra {
@@ -95,37 +96,52 @@ void mean_shift(const List &src, List &dst, float SIG2RAD, int MAXITER, float EP
     float smax = 0;
     for (size_t i = 1; i < src.size(); i++) smax = std::max(smax, src[i].sig);
     const Grid grid(src, std::max(4.0f, SIG2RAD * smax));
-    std::vector<int> cand;
-    for (size_t i = 1; i < dst.size(); i++) {
-        float conv[4] = {src[i].x, src[i].y, src[i].z, src[i].sig}, next[4];
-        int iter = 0, cnt;
-        float d2;
-        do {
-            cnt = 0;
-            next[0] = next[1] = next[2] = next[3] = 0;
-            const float r2 = (float)std::pow((double)(SIG2RAD * conv[3]), 2);
-            // candidates in ascending index: the accepted ones are summed in the order of the reference's full scan
-            grid.query(conv[0], conv[1], conv[2], std::sqrt(r2) * 1.0001f + 1e-3f, cand);
-            for (int j : cand) {
-                const float x2 = (float)std::pow((double)(src[j].x - conv[0]), 2);
-                if (x2 <= r2) {
-                    const float y2 = (float)std::pow((double)(src[j].y - conv[1]), 2);
-                    if (x2 + y2 <= r2) {
-                        const float z2 = (float)std::pow((double)(src[j].z - conv[2]), 2);
-                        if (x2 + y2 + z2 <= r2) {
-                            next[0] += src[j].x; next[1] += src[j].y; next[2] += src[j].z; next[3] += src[j].sig;
-                            cnt++;
+    // every node's trajectory only reads `src`: the nodes are independent and are spread over host threads
+    auto shift_range = [&](size_t i0, size_t i1) {
+        std::vector<int> cand;
+        for (size_t i = i0; i < i1; i++) {
+            float conv[4] = {src[i].x, src[i].y, src[i].z, src[i].sig}, next[4];
+            int iter = 0, cnt;
+            float d2;
+            do {
+                cnt = 0;
+                next[0] = next[1] = next[2] = next[3] = 0;
+                const float r2 = (float)std::pow((double)(SIG2RAD * conv[3]), 2);
+                // candidates in ascending index: the accepted ones are summed in the order of the reference's full scan
+                grid.query(conv[0], conv[1], conv[2], std::sqrt(r2) * 1.0001f + 1e-3f, cand);
+                for (int j : cand) {
+                    const float x2 = (float)std::pow((double)(src[j].x - conv[0]), 2);
+                    if (x2 <= r2) {
+                        const float y2 = (float)std::pow((double)(src[j].y - conv[1]), 2);
+                        if (x2 + y2 <= r2) {
+                            const float z2 = (float)std::pow((double)(src[j].z - conv[2]), 2);
+                            if (x2 + y2 + z2 <= r2) {
+                                next[0] += src[j].x; next[1] += src[j].y; next[2] += src[j].z; next[3] += src[j].sig;
+                                cnt++;
+                            }
                         }
                     }
                 }
-            }
-            next[0] /= cnt; next[1] /= cnt; next[2] /= cnt; next[3] /= cnt;
-            d2 = (float)(std::pow((double)(next[0] - conv[0]), 2) + std::pow((double)(next[1] - conv[1]), 2) + std::pow((double)(next[2] - conv[2]), 2));
-            for (int q = 0; q < 4; q++) conv[q] = next[q];
-            iter++;
-        } while (iter < MAXITER && d2 > EPS2);
-        dst[i].x = conv[0]; dst[i].y = conv[1]; dst[i].z = conv[2]; dst[i].sig = conv[3];
+                next[0] /= cnt; next[1] /= cnt; next[2] /= cnt; next[3] /= cnt;
+                d2 = (float)(std::pow((double)(next[0] - conv[0]), 2) + std::pow((double)(next[1] - conv[1]), 2) + std::pow((double)(next[2] - conv[2]), 2));
+                for (int q = 0; q < 4; q++) conv[q] = next[q];
+                iter++;
+            } while (iter < MAXITER && d2 > EPS2);
+            dst[i].x = conv[0]; dst[i].y = conv[1]; dst[i].z = conv[2]; dst[i].sig = conv[3];
+        }
+    };
+    const size_t n = dst.size();
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
+    if (n < 4096) nt = 1;
+    std::vector<std::thread> th;
+    const size_t chunk = (n - 1 + nt - 1) / nt;
+    for (unsigned t = 1; t < nt; t++) {
+        const size_t a = 1 + t * chunk, b = std::min(n, a + chunk);
+        if (a < b) th.emplace_back(shift_range, a, b);
     }
+    shift_range(1, std::min(n, 1 + chunk));
+    for (auto &t : th) t.join();
 }
 
 // :1532-1564 -- unique neighbour lists, no self links, links made bidirectional
