@@ -671,6 +671,8 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     E.h = h;
     E.max_split = 24;
     if (const char *e = getenv("PNR_MAX_SPLIT")) E.max_split = std::max(1, atoi(e));
+    PNR_REQUIRE(E.upd_lds <= 160 * 1024, PNR_E_ARG, "np=%d with %d scales needs %zu B of LDS in the update step (limit 160 KB)", np, S, E.upd_lds);
+    PNR_HIP(hipFuncSetAttribute((const void *)ph_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.upd_lds));
     PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
     PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
     return PNR_OK;

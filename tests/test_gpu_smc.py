@@ -247,6 +247,29 @@ def test_streaming_scheduler_edge_cases(monkeypatch, smc_driver, window, look0, 
         assert nt2 == maxtr + 1  # the loop ends after the trace that exceeds the cap (:2702)
 
 
+def test_many_particles_vs_oracle(oracle, smc_driver):
+    """np = 1200: 19 groups of 64 chains, more than 64 KB of LDS in the update step of the phased driver"""
+    if smc_driver != "phased":
+        pytest.skip("the persistent kernel keeps all particle state in LDS: np is limited there")
+    img = synth.synth(48, 40, 24, seed=1)
+    sigs, np_, ni = [2.0], 1200, 4
+    so = _seeds_for(oracle, img, sigs, 2.0, 1)
+    To = orc.Tracker(oracle, sigs, 2, np_, ni, 3.0, 0.3, zdist=2.0)
+    seeds = np.zeros(len(so), lib.SEED_DT)
+    for i, k in enumerate(lib.SEED_DT.names):
+        seeds[k] = so[:, i]
+    c = pnr_amd.Context(pnr_amd.make_params(sigmas=sigs, np_=np_, ni=ni, zdist=2.0), 0)
+    c.set_volume(img)
+    T, stop, xc, dbg = c.trace_batch(seeds, dbg_iters=ni)
+    for d, sgn in enumerate((1, -1)):
+        q = so[0][:6].copy(); q[3:] *= sgn
+        Tn, st, xco, xf, idx, neff = To.trace(img, q, max_dbg=ni)
+        assert T[d] == Tn and stop[d] == st
+        rows = min(Tn + 1, ni)
+        assert np.allclose(mat(xc[d])[:rows], xco[:rows], rtol=F32_RTOL, atol=F32_ATOL)
+        assert np.allclose(dbg["xfilt"][d, :rows], xf[:rows], rtol=F32_RTOL, atol=F32_ATOL)
+
+
 def test_small_stash_budget_gives_same_traces(monkeypatch, smc_driver):
     """a stash budget that holds only a few traces: pnr_trace_batch runs in several waves, pnr_trace_replay with a narrower
     window than asked for -- identical results"""
