@@ -247,6 +247,29 @@ def test_streaming_scheduler_edge_cases(monkeypatch, smc_driver, window, look0, 
         assert nt2 == maxtr + 1  # the loop ends after the trace that exceeds the cap (:2702)
 
 
+def test_large_sigma_templates_outside_the_cube(oracle):
+    """sigma = 12: the templates reach 36 voxels sideways, far beyond the LDS cube -- most corner groups take the HBM fallback"""
+    img = synth.synth(96, 80, 40, seed=7)
+    sigs, np_, ni = [3.0, 12.0], 40, 5
+    so = _seeds_for(oracle, img, [2.0], 2.0, 2)
+    To = orc.Tracker(oracle, sigs, 2, np_, ni, 3.0, 0.1, zdist=2.0)
+    seeds = np.zeros(len(so), lib.SEED_DT)
+    for i, k in enumerate(lib.SEED_DT.names):
+        seeds[k] = so[:, i]
+    c = pnr_amd.Context(pnr_amd.make_params(sigmas=sigs, np_=np_, ni=ni, zdist=2.0, znccth=0.1), 0)
+    c.set_volume(img)
+    T, stop, xc, dbg = c.trace_batch(seeds, dbg_iters=ni)
+    for i, sd in enumerate(so):
+        for d, sgn in enumerate((1, -1)):
+            q = sd[:6].copy(); q[3:] *= sgn
+            Tn, st, xco, xf, idx, neff = To.trace(img, q, max_dbg=ni)
+            j = 2 * i + d
+            assert T[j] == Tn and stop[j] == st
+            rows = min(Tn + 1, ni)
+            assert np.allclose(mat(xc[j])[:rows], xco[:rows], rtol=F32_RTOL, atol=F32_ATOL)
+            assert np.allclose(dbg["xfilt"][j, :rows], xf[:rows], rtol=F32_RTOL, atol=F32_ATOL)
+
+
 def test_many_particles_vs_oracle(oracle, smc_driver):
     """np = 1200: 19 groups of 64 chains, more than 64 KB of LDS in the update step of the phased driver"""
     if smc_driver != "phased":
