@@ -110,11 +110,20 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X (no CPU path)", file=sys.stderr)
         sys.exit(2)
+    # rehearsal on a box with fewer GPUs than ranks (never the measured configuration): PNR_BENCH_BACKEND=gloo puts the collectives
+    # on CPU tensors and lets the ranks share the visible GPUs
+    backend = os.environ.get("PNR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
+    coll_dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     import synth
     import pnr_amd
     from pnr_amd import multigpu
@@ -135,9 +144,9 @@ def main():
         st = {}
         t0 = time.perf_counter()
         if a.mode == "shard" and world > 1:  # one stack: z-slabs of Frangi + seeds per rank, 2-float all-reduce, seed all-gather
-            mine, _, _ = multigpu.frangi_seeds_sharded(ctx, img.data_ptr(), (S, S, S), dist, rank, world, device=torch.device("cuda", local))
+            mine, _, _ = multigpu.frangi_seeds_sharded(ctx, img.data_ptr(), (S, S, S), dist, rank, world, device=coll_dev)
             t1 = time.perf_counter()
-            s0 = multigpu.gather_seeds(mine, dist, rank, world, torch.device("cuda", local))
+            s0 = multigpu.gather_seeds(mine, dist, rank, world, coll_dev)
         else:
             ctx.frangi()
             t1 = time.perf_counter()
@@ -146,7 +155,7 @@ def main():
         s = ctx.score_filter_sort(s0)[:a.seeds]
         t3 = time.perf_counter()
         if a.mode == "shard" and world > 1:
-            nodes, links, T = multigpu.trace_sharded(ctx, s, dist, rank, world)
+            nodes, links, T = multigpu.trace_sharded(ctx, s, dist, rank, world, device=coll_dev)
             iters = int((T + (T < a.ni)).sum())
         else:
             if a.one_shot:
@@ -156,7 +165,7 @@ def main():
             else:
                 nodes, links, _, iters = ctx.trace_replay(s)
             if world > 1:
-                multigpu.gather_graphs(nodes, links, dist, rank, world, torch.device("cuda", local))
+                multigpu.gather_graphs(nodes, links, dist, rank, world, coll_dev)
         t5 = time.perf_counter()
         st.update(frangi_ms=1e3 * (t1 - t0), seeds_ms=1e3 * (t2 - t1), score_ms=1e3 * (t3 - t2), trace_replay_gather_ms=1e3 * (t5 - t3),
                   n_seeds_init=len(s0), n_seeds=len(s), iters=iters, nodes=len(nodes) - 1)
@@ -177,10 +186,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=f"cuda:{local}", dtype=torch.float64)
+        tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        it = torch.tensor([st["iters"]], device=f"cuda:{local}", dtype=torch.int64)
+        it = torch.tensor([st["iters"]], device=coll_dev, dtype=torch.int64)
         dist.all_reduce(it)
         iters_all = int(it.item())
     else:
