@@ -256,8 +256,6 @@ static std::string swc_comment(const std::vector<std::string> &paras, const pnr_
 bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *> &paras_c, int device, const std::string &raw_dims,
                    Result *result)
 {
-    using clk = std::chrono::steady_clock;
-    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     if (infiles.empty()) {
         fprintf(stderr, "Need input image. \n"); // :286-289
         return false;
@@ -275,18 +273,27 @@ bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *>
         fprintf(stderr, "%s\n", err.c_str()); // v3d_msg(...); return 0
         return true;
     }
-    p.rng_seed = getenv("PNR_RNG_SEED") ? (uint32_t)strtoul(getenv("PNR_RNG_SEED"), nullptr, 10) : 42u;
     Stack st;
     if (!load_stack(infiles[0], raw_dims, st, err)) {
         fprintf(stderr, "%s\n", err.c_str());
         return true;
     }
+    reconstruction_func(st.data.data(), st.w, st.h, st.l, infiles[0], paras, p, device, result);
+    return true;
+}
+
+bool reconstruction_func(const unsigned char *data1d, long long w, long long h, long long l, const std::string &inimg_file,
+                         const std::vector<std::string> &paras, pnr_params p, int device, Result *result)
+{
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    p.rng_seed = getenv("PNR_RNG_SEED") ? (uint32_t)strtoul(getenv("PNR_RNG_SEED"), nullptr, 10) : 42u;
     printf("-------------  ADVANTRA  -------------\n");
     pnr_ctx *ctx = nullptr;
-    if (pnr_create(&p, device, &ctx) != PNR_OK || pnr_set_volume(ctx, st.data.data(), st.w, st.h, st.l) != PNR_OK) {
+    if (pnr_create(&p, device, &ctx) != PNR_OK || pnr_set_volume(ctx, data1d, w, h, l) != PNR_OK) {
         fprintf(stderr, "%s\n", pnr_last_error());
         pnr_destroy(ctx);
-        return true;
+        return false;
     }
     Result R;
     bool ok = true;
@@ -332,7 +339,7 @@ bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *>
     if (!ok) {
         fprintf(stderr, "%s\n", pnr_last_error());
         pnr_destroy(ctx);
-        return true;
+        return false;
     }
     R.nodes.resize((size_t)nn);
     R.links.resize((size_t)(2 * nl));
@@ -347,7 +354,7 @@ bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *>
             if (pnr_reconstruct(R.nodes.data(), nn, R.links.data(), nl, 0, 0, 0, 0, 0, 0, R.tree.data(), R.parent.data(), cap, &nt) != PNR_OK) {
                 fprintf(stderr, "%s\n", pnr_last_error());
                 pnr_destroy(ctx);
-                return true;
+                return false;
             }
             if (nt <= cap) break;
             cap = nt;
@@ -357,9 +364,9 @@ bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *>
     }
     auto t5 = clk::now();
     R.t_recon = secs(t4, t5);
-    R.swc_path = std::string(infiles[0]) + "_Advantra.swc"; // :2164
+    R.swc_path = inimg_file + "_Advantra.swc"; // :2164
     save_treelist(R.tree, R.parent, R.swc_path, -1, 1.f, "Advantra", swc_comment(paras, p));
-    if (getenv("PNR_SAVE_MIDRES")) save_nodelist(R.nodes, R.links, std::string(infiles[0]) + "_n0_.swc"); // saveMidres tap (:2099)
+    if (getenv("PNR_SAVE_MIDRES")) save_nodelist(R.nodes, R.links, inimg_file + "_n0_.swc"); // saveMidres tap (:2099)
     printf("%s\n%lld trace nodes, %lld traces, %lld SMC iterations, %zu tree nodes | frangi %.3f s, seeds %.3f s, selection %.3f s, "
            "tracing %.3f s, reconstruct %.3f s\n",
            R.swc_path.c_str(), (long long)nn - 1, (long long)used, (long long)iters, R.tree.size() - 1, R.t_frangi, R.t_seeds, R.t_select,

@@ -41,6 +41,10 @@ bool save_treelist(const std::vector<pnr_node> &tree, const std::vector<int32_t>
                    float sig2r = 1.f, const std::string &name = "", const std::string &comment = "");
 // 0 = ok, -1 = usage error (dofunc returns false), -2 = range error (dofunc "return 0"), -3 = runtime failure
 int parse_params(const std::vector<std::string> &paras, pnr_params &p, std::string &err);
+// reconstruction_func (Advantra_plugin.cpp:2183-2731) from the point where the stack is in memory (:2255): the caller keeps
+// ownership of `data1d` (u8, x fastest).  Writes <inimg_file>_Advantra.swc; false = a library call failed (message printed).
+bool reconstruction_func(const unsigned char *data1d, long long w, long long h, long long l, const std::string &inimg_file,
+                         const std::vector<std::string> &paras, pnr_params p, int device = 0, Result *result = nullptr);
 bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *> &paras, int device = 0,
                    const std::string &raw_dims = "", Result *result = nullptr);
 
