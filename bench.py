@@ -218,7 +218,7 @@ def main():
         # a known byte count in the same access pattern: scripts/prof_traffic.sh), collected for THIS workload and
         # committed under profiles/; null for any other workload
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_1024_s2000.json" if a.driver == "persistent" else "r01g_traffic_1024_s2000.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_1024_s2000.json" if a.driver == "persistent" else "r01h_traffic_1024_s2000.json")
         if S == 1024 and a.seeds == 2000 and a.np == 200 and a.ni == 200 and not a.one_shot and a.mode == "stacks" and os.path.exists(tpath):
             tj = json.load(open(tpath)).get("smc_trace" if a.driver == "persistent" else "ph_sample", {})
             if "FETCH_SIZE" in tj and "WRITE_SIZE" in tj:

@@ -786,7 +786,7 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
     window = std::min<int64_t>(window, 2 * n);
     window += window & 1;
     // seeds are admitted at most this far beyond the replay frontier (a trace only sees the map of replayed seeds)
-    int64_t look0 = 128, look_pct = 100;
+    int64_t look0 = 128, look_pct = 50;
     if (const char *e = getenv("PNR_LOOK0")) look0 = std::max(1, atoi(e));
     if (const char *e = getenv("PNR_LOOK_PCT")) look_pct = std::max(0, atoi(e));
     int poll = 4;
