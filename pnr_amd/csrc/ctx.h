@@ -196,6 +196,6 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
 void pnr_phased_destroy(pnr_phased *h);
 int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::Replayer &r, int64_t *iters);
 int pnr_density_reset(pnr_ctx *c);                       // zero the device density map (allocating it on first use)
-int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r); // push the voxels touched since Replayer::touched was cleared
+int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, hipStream_t on = nullptr); // push the voxels touched since Replayer::touched was cleared
 int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y);
 int pnr_ensure_frangi_buffers(pnr_ctx *c);

@@ -713,9 +713,9 @@ int pnr_density_reset(pnr_ctx *c)
     return PNR_OK;
 }
 
-int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r)
+int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, hipStream_t on)
 {
-    hipStream_t st = c->stream;
+    hipStream_t st = on ? on : c->stream;
     const size_t n = r.touched.size();
     if (n == 0) return PNR_OK;
     std::vector<unsigned char> val(n);

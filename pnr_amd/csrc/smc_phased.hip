@@ -540,6 +540,9 @@ struct pnr_phased {
     pnr_xest *h_xc = nullptr; int *h_flags = nullptr; int *h_new = nullptr; float *h_new_s6 = nullptr;
     int *d_new = nullptr; float *d_new_s6 = nullptr;
     int64_t stream_cap = 0;
+    static constexpr int MAXG = 4;
+    hipStream_t stg[MAXG] = {}, st_den = nullptr; // [1..]: the further trace groups of the streaming tracer; density uploads
+    hipEvent_t ev_start = nullptr;
 };
 
 static void phased_free(pnr_phased *h)
@@ -565,6 +568,10 @@ void pnr_phased_destroy(pnr_phased *h)
     hipFree(h->d_new); hipFree(h->d_new_s6);
     for (int r = 0; r < pnr_phased::RING; r++)
         if (h->ev[r]) (void)hipEventDestroy(h->ev[r]);
+    for (int g = 1; g < pnr_phased::MAXG; g++)
+        if (h->stg[g]) (void)hipStreamDestroy(h->stg[g]);
+    if (h->st_den) (void)hipStreamDestroy(h->st_den);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     delete h;
 }
 
@@ -607,6 +614,9 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     if (!h->h_cnt) {
         PNR_HIP(hipHostMalloc(&h->h_cnt, sizeof(int) * pnr_phased::RING));
         for (int r = 0; r < pnr_phased::RING; r++) PNR_HIP(hipEventCreateWithFlags(&h->ev[r], hipEventDisableTiming));
+        for (int g = 1; g < pnr_phased::MAXG; g++) PNR_HIP(hipStreamCreateWithFlags(&h->stg[g], hipStreamNonBlocking));
+        PNR_HIP(hipStreamCreateWithFlags(&h->st_den, hipStreamNonBlocking));
+        PNR_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
     }
     const int ngf = (np + 1) / 64, rem = (np + 1) - 64 * ngf, R = (rem + 15) / 16 * 16, W = 64 * ngf + R;
     const long long Mtot = E.T.Mtot, trace_floats = Mtot * W;
@@ -635,8 +645,8 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
         PNR_HIP(hipMalloc(&h->P.xcs, (size_t)cap * 16 * 4));
         PNR_HIP(hipMalloc(&h->P.flags, (size_t)cap * FL_N * 4));
         PNR_HIP(hipMalloc(&h->P.stash, (size_t)cap * trace_floats * 4));
-        PNR_HIP(hipMalloc(&h->P.list, (size_t)cap * 2 * 4));
-        PNR_HIP(hipMalloc(&h->P.cnt, 2 * 4));
+        PNR_HIP(hipMalloc(&h->P.list, (size_t)cap * 2 * 4 * pnr_phased::MAXG)); // one pair of lists per trace group of the streaming tracer
+        PNR_HIP(hipMalloc(&h->P.cnt, 2 * 4 * pnr_phased::MAXG));
         PNR_HIP(hipMalloc(&h->P.ctr, (size_t)cap * 4));
         PNR_HIP(hipMalloc(&h->d_s6, (size_t)cap * 24));
         PNR_HIP(hipMalloc(&h->O.T, (size_t)cap * 4));
@@ -808,19 +818,45 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
         h->h_xc = nullptr; h->h_flags = nullptr; h->h_new = nullptr; h->h_new_s6 = nullptr; h->d_new = nullptr; h->d_new_s6 = nullptr;
         h->stream_cap = 0;
         PNR_HIP(hipHostMalloc(&h->h_xc, (size_t)NT * ni * sizeof(pnr_xest)));
-        PNR_HIP(hipHostMalloc(&h->h_flags, (size_t)NT * FL_N * 4));
-        PNR_HIP(hipHostMalloc(&h->h_new, (size_t)NT * 4));
-        PNR_HIP(hipHostMalloc(&h->h_new_s6, (size_t)NT * 24));
-        PNR_HIP(hipMalloc(&h->d_new, (size_t)NT * 4));
-        PNR_HIP(hipMalloc(&h->d_new_s6, (size_t)NT * 24));
+        constexpr int MG = pnr_phased::MAXG; // one set per trace group
+        PNR_HIP(hipHostMalloc(&h->h_flags, (size_t)NT * FL_N * 4 * MG));
+        PNR_HIP(hipHostMalloc(&h->h_new, (size_t)NT * 4 * MG));
+        PNR_HIP(hipHostMalloc(&h->h_new_s6, (size_t)NT * 24 * MG));
+        PNR_HIP(hipMalloc(&h->d_new, (size_t)NT * 4 * MG));
+        PNR_HIP(hipMalloc(&h->d_new_s6, (size_t)NT * 24 * MG));
         h->stream_cap = NT;
     }
-    hipStream_t st = c->stream;
-    PhState P = E.P;
     TraceOut O = h->O;
     O.xc = (float *)h->h_xc; // the per-iteration records go straight to pinned host memory (32 B per trace and iteration)
     O.dbg_iters = 0; O.xfilt = nullptr; O.idxres = nullptr; O.neff = nullptr;
-    PNR_HIP(hipMemsetAsync(P.cnt, 0, 2 * 4, st));
+    // The window can be shared by G groups of traces (PNR_GROUPS, 1..4) that step independently, each on its own stream with
+    // its own active list: while the host collects, replays and refills one group, the other groups' steps keep the GPU busy,
+    // and launches with few traces (a chain's ordered sums take 0.25 ms however few there are) overlap.  Results do not depend
+    // on the grouping: a trace is a function of its seed and of the replayed map (see above).  Two groups take 4 % off the
+    // bench step; the default stays one group, whose launches do not overlap, so that a kernel's duration -- HIP events or
+    // rocprofv3 -- is the time that kernel needs and the roofline figures built on it mean what they say.
+    int G = 1;
+    if (const char *e = getenv("PNR_GROUPS")) G = std::min(std::max(1, atoi(e)), (int)pnr_phased::MAXG);
+    if (NT < 4 * G) G = 1;
+    struct Grp {
+        PhState P; hipStream_t st; int lp = 0, active = 0; bool inflight = false; std::vector<int> busy;
+        int *h_flags, *h_cnt, *h_new, *d_new; float *h_new_s6, *d_new_s6;
+    };
+    Grp grp[pnr_phased::MAXG];
+    PNR_HIP(hipMemsetAsync(E.P.cnt, 0, 2 * 4 * pnr_phased::MAXG, c->stream));
+    PNR_HIP(hipEventRecord(h->ev_start, c->stream)); // everything queued so far (volume, density map) precedes the other streams
+    for (int g = 1; g < pnr_phased::MAXG; g++) PNR_HIP(hipStreamWaitEvent(h->stg[g], h->ev_start, 0));
+    PNR_HIP(hipStreamWaitEvent(h->st_den, h->ev_start, 0));
+    for (int g = 0; g < pnr_phased::MAXG; g++) {
+        Grp &q = grp[g];
+        q.P = E.P;
+        q.P.list = E.P.list + (size_t)g * 2 * E.P.cap;
+        q.P.cnt = E.P.cnt + 2 * g;
+        q.st = g == 0 ? c->stream : h->stg[g];
+        q.h_flags = h->h_flags + (size_t)g * NT * FL_N; q.h_cnt = h->h_cnt + g;
+        q.h_new = h->h_new + (size_t)g * NT; q.d_new = h->d_new + (size_t)g * NT;
+        q.h_new_s6 = h->h_new_s6 + (size_t)g * NT * 6; q.d_new_s6 = h->d_new_s6 + (size_t)g * NT * 6;
+    }
 
     enum : uint8_t { NOT_YET = 0, LAUNCHED = 1, SKIPPED = 2 };
     struct SeedRec { uint8_t state = NOT_YET; int pending = 0; int32_t T[2] = {0, 0}; std::vector<pnr_xest> xc; };
@@ -828,27 +864,81 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
     std::vector<int> free_slots;
     for (int k = NT - 1; k >= 0; k--) free_slots.push_back(k);
     std::vector<int64_t> slot_seed((size_t)NT, -1);
-    std::vector<int> slot_dir((size_t)NT, 0), busy;
+    std::vector<int> slot_dir((size_t)NT, 0);
     int64_t next = 0, frontier = 0, iters = 0;
-    int lp = 0, active = 0;
     const bool timing = getenv("PNR_TRACE_TIMING") != nullptr;
     int64_t steps = 0, polls = 0;
-    for (;;) {
-        // ---- admission
-        int m = 0;
-        while (!r.stopped && next < n && free_slots.size() >= 2 && next < frontier + std::max<int64_t>(look0, frontier * look_pct / 100)) {
+    int idle_turns = 0;
+    auto drain = [&]() { for (int g = 0; g < pnr_phased::MAXG; g++) (void)hipStreamSynchronize(grp[g].st); (void)hipStreamSynchronize(h->st_den); };
+    for (int g = 0;; g = (g + 1) % G) {
+        Grp &q = grp[g];
+        hipStream_t st = q.st;
+        // ---- the group's last poll: which of its traces have stopped?
+        if (q.inflight) {
+            PNR_HIP(hipStreamSynchronize(st)); // the stream carries this group's work only
+            PNR_HIP(hipGetLastError());
+            q.inflight = false;
+            polls++;
+            q.active = q.h_cnt[0];
+            size_t keep = 0;
+            for (size_t b = 0; b < q.busy.size(); b++) {
+                const int slot = q.busy[b];
+                const int *fl = q.h_flags + (size_t)slot * FL_N;
+                if (!fl[FL_DONE]) { q.busy[keep++] = slot; continue; }
+                SeedRec &sr = rec[(size_t)slot_seed[(size_t)slot]];
+                const int dir = slot_dir[(size_t)slot];
+                const int Tn = fl[FL_T];
+                sr.T[dir] = Tn;
+                const int rows = std::min(Tn, ni);
+                if (rows > 0) std::memcpy(sr.xc.data() + (size_t)dir * ni, h->h_xc + (size_t)slot * ni, (size_t)rows * sizeof(pnr_xest));
+                sr.pending--;
+                iters += std::min(Tn + 1, ni);
+                slot_seed[(size_t)slot] = -1;
+                free_slots.push_back(slot);
+            }
+            q.busy.resize(keep);
+        }
+        // ---- replay in seed order as far as the finished traces reach, push the new density to the GPU (its own stream: the
+        // kernels of either group may see a voxel before or after the update -- both are under-counts of the reference's map)
+        r.touched.clear();
+        while (frontier < n && !r.stopped) {
+            SeedRec &sr = rec[(size_t)frontier];
+            if (sr.state == NOT_YET || (sr.state == LAUNCHED && sr.pending > 0)) break;
+            if (sr.state == LAUNCHED) { // (a skipped seed sits on a saturated voxel: the replay would skip it as well)
+                r.add(&seeds[frontier], 1, sr.T, sr.xc.data());
+                std::vector<pnr_xest>().swap(sr.xc);
+            }
+            frontier++;
+        }
+        if (!r.touched.empty()) {
+            rc = pnr_density_update(c, r, G > 1 ? h->st_den : c->stream);
+            if (rc) { drain(); return rc; }
+        }
+        if (r.stopped) break; // MAX_TRACE_COUNT (:2702): whatever is still running is never looked at
+        if (frontier >= n) break;
+        // ---- admission into this group
+        int m = 0, m_max = 2 * NT;
+        if (G > 1) { // keep the groups the same size: this one is filled up to its share of what the window will hold
+            const int64_t room = std::min<int64_t>((int64_t)free_slots.size() / 2, frontier + std::max<int64_t>(look0, frontier * look_pct / 100) - next);
+            int64_t total = 2 * std::max<int64_t>(room, 0);
+            int least = q.active;
+            for (int k = 0; k < G; k++) { total += grp[k].active; least = std::min(least, grp[k].active); }
+            m_max = (int)std::max<int64_t>(0, (total + G - 1) / G - q.active);
+            if (q.active <= least) m_max = std::max(m_max, 2); // the smallest group can always take a seed
+        }
+        while (m + 2 <= m_max && next < n && free_slots.size() >= 2 && next < frontier + std::max<int64_t>(look0, frontier * look_pct / 100)) {
             const pnr_seed &sd = seeds[next];
-            SeedRec &q = rec[(size_t)next];
-            if (r.seed_saturated(sd)) { q.state = SKIPPED; next++; continue; }
-            q.state = LAUNCHED; q.pending = 2;
-            q.xc.resize((size_t)2 * ni);
+            SeedRec &sr = rec[(size_t)next];
+            if (r.seed_saturated(sd)) { sr.state = SKIPPED; next++; continue; }
+            sr.state = LAUNCHED; sr.pending = 2;
+            sr.xc.resize((size_t)2 * ni);
             for (int dir = 0; dir < 2; dir++) {
                 const int slot = free_slots.back();
                 free_slots.pop_back();
                 slot_seed[(size_t)slot] = next; slot_dir[(size_t)slot] = dir;
-                busy.push_back(slot);
-                h->h_new[m] = slot;
-                float *a = h->h_new_s6 + (size_t)m * 6;
+                q.busy.push_back(slot);
+                q.h_new[m] = slot;
+                float *a = q.h_new_s6 + (size_t)m * 6;
                 a[0] = sd.x; a[1] = sd.y; a[2] = sd.z;
                 a[3] = dir ? -sd.vx : sd.vx; a[4] = dir ? -sd.vy : sd.vy; a[5] = dir ? -sd.vz : sd.vz; // trackNeg (tracker.cpp:819-823)
                 m++;
@@ -856,14 +946,17 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
             next++;
         }
         if (m > 0) {
-            PNR_HIP(hipMemcpyAsync(h->d_new, h->h_new, (size_t)m * 4, hipMemcpyHostToDevice, st));
-            PNR_HIP(hipMemcpyAsync(h->d_new_s6, h->h_new_s6, (size_t)m * 24, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(ph_admit, dim3(1), dim3(256), 0, st, P, h->d_s6, (const int *)h->d_new, (const float *)h->d_new_s6, m, lp, ni);
-            active += m;
+            PNR_HIP(hipMemcpyAsync(q.d_new, q.h_new, (size_t)m * 4, hipMemcpyHostToDevice, st));
+            PNR_HIP(hipMemcpyAsync(q.d_new_s6, q.h_new_s6, (size_t)m * 24, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(ph_admit, dim3(1), dim3(256), 0, st, q.P, h->d_s6, (const int *)q.d_new, (const float *)q.d_new_s6, m, q.lp, ni);
+            q.active += m;
         }
-        if (active > 0) {
-            // ---- `poll` SMC steps over the active list (every trace at its own iteration)
+        if (q.active > 0) {
+            // ---- `poll` SMC steps over the group's active list (every trace at its own iteration)
+            const PhState &P = q.P;
+            const int active = q.active;
             for (int k = 0; k < poll; k++) {
+                const int lp = q.lp;
                 const int nsplit = pick_nsplit(active, E.ncu, E.max_split);
                 c->tic(st);
                 hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
@@ -881,53 +974,20 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
                 hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), E.upd_lds, st, E.V, E.T, P, np, np_pad, ni, -1, lp, c->prm.Kc, c->prm.znccth,
                                    c->prm.neff_ratio, c->d_den, c->prm.nodepervol, O);
                 c->toc("smc_update", 1, st);
-                lp ^= 1;
+                q.lp ^= 1;
                 steps++;
             }
-            // ---- poll: which traces have stopped?
-            PNR_HIP(hipMemcpyAsync(h->h_flags, P.flags, (size_t)NT * FL_N * 4, hipMemcpyDeviceToHost, st));
-            PNR_HIP(hipMemcpyAsync(h->h_cnt, P.cnt + lp, 4, hipMemcpyDeviceToHost, st));
-            PNR_HIP(hipStreamSynchronize(st));
-            PNR_HIP(hipGetLastError());
-            polls++;
-            active = h->h_cnt[0];
-            size_t keep = 0;
-            for (size_t b = 0; b < busy.size(); b++) {
-                const int slot = busy[b];
-                const int *fl = h->h_flags + (size_t)slot * FL_N;
-                if (!fl[FL_DONE]) { busy[keep++] = slot; continue; }
-                SeedRec &q = rec[(size_t)slot_seed[(size_t)slot]];
-                const int dir = slot_dir[(size_t)slot];
-                const int Tn = fl[FL_T];
-                q.T[dir] = Tn;
-                const int rows = std::min(Tn, ni);
-                if (rows > 0) std::memcpy(q.xc.data() + (size_t)dir * ni, h->h_xc + (size_t)slot * ni, (size_t)rows * sizeof(pnr_xest));
-                q.pending--;
-                iters += std::min(Tn + 1, ni);
-                slot_seed[(size_t)slot] = -1;
-                free_slots.push_back(slot);
-            }
-            busy.resize(keep);
+            PNR_HIP(hipMemcpyAsync(q.h_flags, P.flags, (size_t)NT * FL_N * 4, hipMemcpyDeviceToHost, st));
+            PNR_HIP(hipMemcpyAsync(q.h_cnt, P.cnt + q.lp, 4, hipMemcpyDeviceToHost, st));
+            q.inflight = true;
         }
-        // ---- replay in seed order as far as the finished traces reach, push the new density to the GPU
-        r.touched.clear();
-        while (frontier < n && !r.stopped) {
-            SeedRec &q = rec[(size_t)frontier];
-            if (q.state == NOT_YET || (q.state == LAUNCHED && q.pending > 0)) break;
-            if (q.state == LAUNCHED) { // (a skipped seed sits on a saturated voxel: the replay would skip it as well)
-                r.add(&seeds[frontier], 1, q.T, q.xc.data());
-                std::vector<pnr_xest>().swap(q.xc);
-            }
-            frontier++;
-        }
-        if (!r.touched.empty()) {
-            rc = pnr_density_update(c, r);
-            if (rc) return rc;
-        }
-        if (r.stopped) break; // MAX_TRACE_COUNT (:2702): whatever is still running is never looked at
-        if (frontier >= n) break;
-        PNR_REQUIRE(active > 0 || next < n, PNR_E_STATE, "trace scheduler stalled at seed %lld of %lld", (long long)frontier, (long long)n);
+        bool any = false;
+        for (int k = 0; k < G; k++) any = any || grp[k].inflight;
+        idle_turns = (any || m > 0) ? 0 : idle_turns + 1;
+        if (idle_turns > 2 * G) { drain(); PNR_REQUIRE(false, PNR_E_STATE, "trace scheduler stalled at seed %lld of %lld", (long long)frontier, (long long)n); }
     }
+    drain(); // the group that is still running is never looked at again, but it writes into buffers that outlive this call
+    PNR_HIP(hipGetLastError());
     if (timing)
         fprintf(stderr, "[pnr trace] streaming: %lld seeds, window %d slots, %lld steps, %lld polls, %lld iterations, %zu nodes\n", (long long)n, NT,
                 (long long)steps, (long long)polls, (long long)iters, r.nodes.size());

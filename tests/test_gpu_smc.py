@@ -221,10 +221,13 @@ def test_batched_trace_replay_equals_one_shot(first_batch, vol, npv):
     assert iters <= full
 
 
-@pytest.mark.parametrize("window,look0,look_pct,poll,maxtr", [(2, 1, 0, 1, 0), (6, 3, 50, 3, 0), (4096, 4096, 100, 7, 0), (64, 16, 100, 4, 12)])
-def test_streaming_scheduler_edge_cases(monkeypatch, smc_driver, window, look0, look_pct, poll, maxtr):
+@pytest.mark.parametrize("window,look0,look_pct,poll,maxtr,groups",
+                         [(2, 1, 0, 1, 0, 1), (6, 3, 50, 3, 0, 1), (4096, 4096, 100, 7, 0, 1), (64, 16, 100, 4, 12, 1),
+                          (64, 16, 50, 4, 0, 2), (48, 8, 100, 2, 0, 3), (4096, 4096, 100, 3, 0, 4), (32, 16, 100, 4, 12, 2)])
+def test_streaming_scheduler_edge_cases(monkeypatch, smc_driver, window, look0, look_pct, poll, maxtr, groups):
     """pnr_trace_replay_stream with a window of one seed, a lookahead of one seed, everything admitted at once, odd polling
-    periods and the MAX_TRACE_COUNT stop (Advantra_plugin.cpp:2702): always the one-shot node graph."""
+    periods, the MAX_TRACE_COUNT stop (Advantra_plugin.cpp:2702) and the window split into trace groups that step
+    concurrently on their own streams: always the one-shot node graph."""
     if smc_driver != "phased":
         pytest.skip("the streaming scheduler belongs to the phased driver")
     img = synth.synth(80, 64, 32, seed=4)
@@ -237,7 +240,7 @@ def test_streaming_scheduler_edge_cases(monkeypatch, smc_driver, window, look0, 
     assert len(seeds) > 30
     T, stop, xc, _ = c.trace_batch(seeds)
     n1, l1, nt1 = c.replay(seeds, T, xc)
-    for k, v in (("PNR_WINDOW", window), ("PNR_LOOK0", look0), ("PNR_LOOK_PCT", look_pct), ("PNR_POLL", poll)):
+    for k, v in (("PNR_WINDOW", window), ("PNR_LOOK0", look0), ("PNR_LOOK_PCT", look_pct), ("PNR_POLL", poll), ("PNR_GROUPS", groups)):
         monkeypatch.setenv(k, str(v))
     n2, l2, nt2, iters = c.trace_replay(seeds)
     assert nt1 == nt2 and len(n1) == len(n2) > 20 and np.array_equal(l1, l2)
