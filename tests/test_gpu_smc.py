@@ -345,13 +345,16 @@ def test_trace_config5_shape_vs_oracle(oracle):
             assert np.allclose(dbg["xfilt"][j, :rows], xf[:rows], rtol=F32_RTOL, atol=F32_ATOL)
 
 
-def test_full_size_properties_512():
-    """BASELINE configs[1] size (512^3, scales {2,4,6}, np=200): properties that do not need the oracle --
-    batched tracing gives the one-shot node graph; links are symmetric pairs of valid nodes; every trace start is
-    UNDEFINED(7), ends are END(6); seeds come out sorted by corr; J8 spans 0..255."""
+@pytest.mark.parametrize("S,seed,groups", [(512, 2, 1), (1024, 3, 2)])
+def test_full_size_properties(monkeypatch, smc_driver, S, seed, groups):
+    """BASELINE configs[1] and configs[2] sizes (512^3 / 1024^3 -- the bench stack --, scales {2,4,6}, np=200): properties
+    that do not need the oracle -- streamed tracing (one or two trace groups) gives the one-shot node graph; links are pairs
+    of valid nodes; every trace start is UNDEFINED(7), ends are END(6); seeds come out sorted by corr; J8 spans 0..255."""
     import torch
-    S = 512
-    img = synth.synth_torch(S, S, S, seed=2)
+    if S > 512 and smc_driver != "phased":
+        pytest.skip("once is enough at this size")
+    monkeypatch.setenv("PNR_GROUPS", str(groups))
+    img = synth.synth_torch(S, S, S, seed=seed)
     p = pnr_amd.make_params(sigmas=(2, 4, 6), np_=200, ni=200, zdist=2)
     c = pnr_amd.Context(p, 0)
     c.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
