@@ -1,0 +1,74 @@
+"""Randomised parity campaign: random small stacks and parameters, HIP path against the oracle stage by stage (run on the GPU
+box; the oracle is the checker).  Every comparison is for equality of bytes.  usage: fuzz_parity.py [seconds] [first_case]"""
+import os, sys, time, traceback
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+import numpy as np, orc, synth, pnr_amd
+from pnr_amd import lib
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+case = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+L = orc.load_oracle()
+mat = lambda a: np.stack([a[k] for k in a.dtype.names], -1)
+t_end = time.time() + budget
+nbad = ncases = 0
+stats = dict(traces=0, iters=0, seeds=0, voxels=0)
+while time.time() < t_end:
+    rs = np.random.RandomState(1000 + case)
+    two_d = rs.rand() < 0.12
+    w, h, l = int(rs.randint(40, 97)), int(rs.randint(32, 81)), (1 if two_d else int(rs.randint(12, 41)))
+    nsig = int(rs.randint(1, 4))
+    sigs = sorted(float(x) for x in rs.choice([1.5, 2.0, 2.5, 3.0, 4.0, 6.0], nsig, replace=False))
+    zdist = float(rs.choice([1.0, 2.0, 3.0, 4.0]))
+    np_ = int(rs.choice([20, 50, 63, 64, 100, 127, 200]))
+    ni = int(rs.randint(5, 41)); step = int(rs.choice([2, 2, 3])); kappa = float(rs.choice([2.0, 3.0, 4.0]))
+    tol = float(rs.choice([3, 5, 10])); znccth = float(rs.choice([0.2, 0.3, 0.5])); npv = int(rs.choice([3, 4, 6])); vol = int(rs.choice([1, 5]))
+    seed_img = int(rs.randint(1, 10_000))
+    desc = dict(case=case, shape=(w, h, l), sigs=sigs, zdist=zdist, np=np_, ni=ni, step=step, kappa=kappa, tol=tol, znccth=znccth, npv=npv, vol=vol, img=seed_img)
+    try:
+        img = synth.synth(w, h, l, seed=seed_img) if not two_d else synth.synth(w, h, 3, seed=seed_img)[1:2].copy()
+        p = pnr_amd.make_params(sigmas=sigs, step=step, kappa=kappa, zdist=zdist, np_=np_, ni=ni, tolerance=tol, znccth=znccth, nodepervol=npv, vol=vol)
+        c = pnr_amd.Context(p, 0)
+        c.set_volume(img)
+        c.frangi()
+        g = c.get_frangi(J=True, J8=True, V=True)
+        if two_d:
+            J, jmin, jmax, Vx, Vy, Vz = orc.frangi2d(L, img, sigs)
+        else:
+            J, jmin, jmax, Vx, Vy, Vz = orc.frangi3d(L, img, sigs, zdist)
+        J8 = orc.j8(L, J, jmin, jmax)
+        for k, want in (("J", J), ("J8", J8), ("Vx", Vx), ("Vy", Vy), ("Vz", Vz)):
+            assert np.array_equal(g[k].reshape(want.shape), want), f"frangi {k}: {(g[k].reshape(want.shape) != want).sum()} voxels differ"
+        so = orc.extract_seeds(L, tol, J8, Vx, Vy, Vz)
+        sg = c.extract_seeds()
+        assert len(sg) == len(so) and np.array_equal(mat(sg)[:, :6], so[:, :6]), "seeds"
+        T = orc.Tracker(L, sigs, step, np_, ni, kappa, znccth, zdist=zdist, nodespervol=npv, is2d=two_d)
+        ss = c.score_filter_sort(sg)
+        if len(so):
+            corr, sig = T.zncc(img, so[:, :6])
+            keep = corr >= np.float32(znccth)
+            order = np.argsort(-corr[keep], kind="stable")
+            assert len(ss) == keep.sum() and np.array_equal(ss["corr"], corr[keep][order]), "seed scores"
+        sel = ss[: int(rs.randint(2, 9))]
+        Tg, stop, xc, _ = c.trace_batch(sel)
+        for i in range(len(sel)):
+            for d_, sgn in enumerate((1, -1)):
+                q = np.array([sel[k][i] for k in lib.SEED_DT.names[:6]], np.float32); q[3:] *= sgn
+                Tn, st, xco, *_ = T.trace(img, q)
+                j = 2 * i + d_
+                assert Tg[j] == Tn and stop[j] == st, f"trace {j}: T {Tg[j]} vs {Tn}, stop {stop[j]} vs {st}"
+                rows = min(Tn + 1, ni)
+                assert np.array_equal(mat(xc[j])[:rows], xco[:rows], equal_nan=True), f"trace {j}: xc differs"
+                stats["iters"] += rows
+            stats["traces"] += 2
+        n1, l1, nt1 = c.replay(sel, Tg, xc)
+        n2, l2, nt2, _ = c.trace_replay(sel)
+        assert nt1 == nt2 and np.array_equal(l1, l2) and all(np.array_equal(n1[k], n2[k], equal_nan=True) for k in n1.dtype.names), "streamed vs one-shot graph"
+        stats["seeds"] += len(so); stats["voxels"] += img.size
+    except Exception as e:  # noqa
+        nbad += 1
+        print("MISMATCH", desc, "->", repr(e)[:300], flush=True)
+        if not isinstance(e, AssertionError): traceback.print_exc()
+    ncases += 1; case += 1
+    if ncases % 10 == 0: print(f"[{ncases} cases, {nbad} bad] {stats}", flush=True)
+print(f"done: {ncases} cases, {nbad} mismatches, {stats}, next case {case}")
+sys.exit(1 if nbad else 0)
