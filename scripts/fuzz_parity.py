@@ -23,12 +23,25 @@ while time.time() < t_end:
     ni = int(rs.randint(5, 41)); step = int(rs.choice([2, 2, 3])); kappa = float(rs.choice([2.0, 3.0, 4.0]))
     tol = float(rs.choice([3, 5, 10])); znccth = float(rs.choice([0.2, 0.3, 0.5])); npv = int(rs.choice([3, 4, 6])); vol = int(rs.choice([1, 5]))
     seed_img = int(rs.randint(1, 10_000))
-    desc = dict(case=case, shape=(w, h, l), sigs=sigs, zdist=zdist, np=np_, ni=ni, step=step, kappa=kappa, tol=tol, znccth=znccth, npv=npv, vol=vol, img=seed_img)
+    rad = int(rs.choice([2, 3, 4])) if (not two_d and rs.rand() < 0.3) else 0
+    groups = int(rs.choice([1, 1, 2, 3]))
+    desc = dict(case=case, shape=(w, h, l), sigs=sigs, zdist=zdist, np=np_, ni=ni, step=step, kappa=kappa, tol=tol, znccth=znccth, npv=npv, vol=vol, img=seed_img, somaradius=rad, groups=groups)
     try:
         img = synth.synth(w, h, l, seed=seed_img) if not two_d else synth.synth(w, h, 3, seed=seed_img)[1:2].copy()
-        p = pnr_amd.make_params(sigmas=sigs, step=step, kappa=kappa, zdist=zdist, np_=np_, ni=ni, tolerance=tol, znccth=znccth, nodepervol=npv, vol=vol)
+        if rad:
+            img = synth.add_somas(img, [(int(rs.randint(8, w - 8)), int(rs.randint(8, h - 8)), int(rs.randint(4, max(5, l - 4))), int(rs.randint(rad + 1, rad + 5)))
+                                        for _ in range(int(rs.randint(1, 3)))])
+        os.environ["PNR_GROUPS"] = str(groups)
+        p = pnr_amd.make_params(sigmas=sigs, somaradius=rad, step=step, kappa=kappa, zdist=zdist, np_=np_, ni=ni, tolerance=tol, znccth=znccth, nodepervol=npv, vol=vol)
         c = pnr_amd.Context(p, 0)
         c.set_volume(img)
+        smap, n4 = None, None
+        if rad:  # soma extraction (Advantra_plugin.cpp:2426-2486)
+            E8o, tho, smap, n4 = orc.soma_extract(L, img, rad)
+            sm = c.soma(want_e8=True)
+            fg = np.flatnonzero(smap.reshape(-1) > 0)
+            assert np.array_equal(sm["E8"], E8o) and sm["threshold"] == tho and np.array_equal(sm["vox"], fg) and np.array_equal(sm["lab"], smap.reshape(-1)[fg]), "soma"
+            stats["somas"] = stats.get("somas", 0) + len(n4)
         c.frangi()
         g = c.get_frangi(J=True, J8=True, V=True)
         if two_d:
@@ -41,6 +54,9 @@ while time.time() < t_end:
         so = orc.extract_seeds(L, tol, J8, Vx, Vy, Vz)
         sg = c.extract_seeds()
         assert len(sg) == len(so) and np.array_equal(mat(sg)[:, :6], so[:, :6]), "seeds"
+        if rad and len(so):  # seeds inside a soma are dropped (Advantra_plugin.cpp:2561-2564)
+            vx = np.round(so[:, 2]).astype(np.int64) * w * h + np.round(so[:, 1]).astype(np.int64) * w + np.round(so[:, 0]).astype(np.int64)
+            so = so[smap.reshape(-1)[vx] == 0]
         T = orc.Tracker(L, sigs, step, np_, ni, kappa, znccth, zdist=zdist, nodespervol=npv, is2d=two_d)
         ss = c.score_filter_sort(sg)
         if len(so):
@@ -63,6 +79,15 @@ while time.time() < t_end:
         n1, l1, nt1 = c.replay(sel, Tg, xc)
         n2, l2, nt2, _ = c.trace_replay(sel)
         assert nt1 == nt2 and np.array_equal(l1, l2) and all(np.array_equal(n1[k], n2[k], equal_nan=True) for k in n1.dtype.names), "streamed vs one-shot graph"
+        # the sequential bookkeeping (trackPos, trace loop) and the reconstruct chain against the oracle's
+        so_sel = np.stack([sel[k] for k in lib.SEED_DT.names], -1).astype(np.float32)
+        xcm = np.stack([mat(xc[j]) for j in range(len(Tg))]) if len(Tg) else np.zeros((0, ni, 8), np.float32)
+        no, lo, nto = orc.replay(L, so_sel, Tg.astype(np.int32), xcm, ni, img.shape, npv, vol, smap=smap, soma4=n4)
+        assert len(no) == len(n1) and np.array_equal(lo, l1) and all(np.array_equal(n1[k], no[k], equal_nan=True) for k in n1.dtype.names), "replay vs oracle"
+        tg, pg = lib.reconstruct(n1, l1)
+        to, po = orc.reconstruct(L, n1, l1)
+        assert np.array_equal(pg, po) and all(np.array_equal(tg[k], to[k], equal_nan=True) for k in to.dtype.names), "reconstruct vs oracle"
+        stats["nodes"] = stats.get("nodes", 0) + len(n1) - 1
         stats["seeds"] += len(so); stats["voxels"] += img.size
     except Exception as e:  # noqa
         nbad += 1
