@@ -14,7 +14,7 @@ nbad = ncases = 0
 stats = dict(traces=0, iters=0, seeds=0, voxels=0)
 while time.time() < t_end:
     rs = np.random.RandomState(1000 + case)
-    two_d = rs.rand() < 0.12
+    two_d = rs.rand() < 0.12 and os.environ.get("PNR_SMC_DRIVER") != "persistent"  # (the persistent driver is 3-D only)
     w, h, l = int(rs.randint(40, 97)), int(rs.randint(32, 81)), (1 if two_d else int(rs.randint(12, 41)))
     nsig = int(rs.randint(1, 4))
     sigs = sorted(float(x) for x in rs.choice([1.5, 2.0, 2.5, 3.0, 4.0, 6.0], nsig, replace=False))
