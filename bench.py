@@ -118,7 +118,7 @@ def main():
     torch.cuda.set_device(local)
     coll_dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PNR_BENCH_FORCE_DIST"):  # FORCE_DIST: one-rank rehearsal of the RCCL code path (RANK / WORLD_SIZE / MASTER_* set by hand)
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -143,7 +143,7 @@ def main():
     def step():
         st = {}
         t0 = time.perf_counter()
-        if a.mode == "shard" and world > 1:  # one stack: z-slabs of Frangi + seeds per rank, 2-float all-reduce, seed all-gather
+        if a.mode == "shard" and dist is not None:  # one stack: z-slabs of Frangi + seeds per rank, 2-float all-reduce, seed all-gather
             mine, _, _ = multigpu.frangi_seeds_sharded(ctx, img.data_ptr(), (S, S, S), dist, rank, world, device=coll_dev)
             t1 = time.perf_counter()
             s0 = multigpu.gather_seeds(mine, dist, rank, world, coll_dev)
@@ -154,7 +154,7 @@ def main():
         t2 = time.perf_counter()
         s = ctx.score_filter_sort(s0)[:a.seeds]
         t3 = time.perf_counter()
-        if a.mode == "shard" and world > 1:
+        if a.mode == "shard" and dist is not None:
             nodes, links, T = multigpu.trace_sharded(ctx, s, dist, rank, world, device=coll_dev)
             iters = int((T + (T < a.ni)).sum())
         else:
@@ -164,7 +164,7 @@ def main():
                 iters = int((T + (T < a.ni)).sum())
             else:
                 nodes, links, _, iters = ctx.trace_replay(s)
-            if world > 1:
+            if dist is not None:
                 multigpu.gather_graphs(nodes, links, dist, rank, world, coll_dev)
         t5 = time.perf_counter()
         st.update(frangi_ms=1e3 * (t1 - t0), seeds_ms=1e3 * (t2 - t1), score_ms=1e3 * (t3 - t2), trace_replay_gather_ms=1e3 * (t5 - t3),
