@@ -11,20 +11,20 @@
 #include <string>
 #include <vector>
 
-Q_EXPORT_PLUGIN2(Advantra, Advantra);
+Q_EXPORT_PLUGIN2(Advantra, AdvantraHipPlugin);
 
-QStringList Advantra::menulist() const { return QStringList() << tr("about"); }
+QStringList AdvantraHipPlugin::menulist() const { return QStringList() << tr("about"); }
 
-QStringList Advantra::funclist() const { return QStringList() << tr("advantra_func") << tr("help"); }
+QStringList AdvantraHipPlugin::funclist() const { return QStringList() << tr("advantra_func") << tr("help"); }
 
-void Advantra::domenu(const QString &, V3DPluginCallback2 &, QWidget *)
+void AdvantraHipPlugin::domenu(const QString &, V3DPluginCallback2 &, QWidget *)
 {
     // the reference's menu entry opens a parameter dialog over the current image window (Advantra_plugin.cpp:176-272);
     // the GPU build is driven through dofunc only
     v3d_msg(tr("Advantra (HIP build): use  vaa3d -x Advantra -f advantra_func -i <inimg_file> -p <11 parameters>"));
 }
 
-bool Advantra::dofunc(const QString &func_name, const V3DPluginArgList &input, V3DPluginArgList &, V3DPluginCallback2 &callback,
+bool AdvantraHipPlugin::dofunc(const QString &func_name, const V3DPluginArgList &input, V3DPluginArgList &, V3DPluginCallback2 &callback,
                       QWidget *)
 {
     if (func_name == tr("help")) {
