@@ -23,6 +23,9 @@ while time.time() < t_end:
     ni = int(rs.randint(5, 41)); step = int(rs.choice([2, 2, 3])); kappa = float(rs.choice([2.0, 3.0, 4.0]))
     tol = float(rs.choice([3, 5, 10])); znccth = float(rs.choice([0.2, 0.3, 0.5])); npv = int(rs.choice([3, 4, 6])); vol = int(rs.choice([1, 5]))
     seed_img = int(rs.randint(1, 10_000))
+    if rs.rand() < 0.15:  # BASELINE configs[4]-like parameters at a small size: four scales up to 8 (templates wider than the LDS cube), np 300 / 500
+        sigs = sorted(set(sigs) | {8.0}) if rs.rand() < 0.6 else [2.0, 4.0, 6.0, 8.0]
+        np_ = int(rs.choice([300, 500])); ni = int(rs.randint(4, 13)); zdist = float(rs.choice([2.0, 4.0]))
     rad = int(rs.choice([2, 3, 4])) if (not two_d and rs.rand() < 0.3) else 0
     groups = int(rs.choice([1, 1, 2, 3]))
     desc = dict(case=case, shape=(w, h, l), sigs=sigs, zdist=zdist, np=np_, ni=ni, step=step, kappa=kappa, tol=tol, znccth=znccth, npv=npv, vol=vol, img=seed_img, somaradius=rad, groups=groups)
