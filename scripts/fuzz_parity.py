@@ -15,7 +15,8 @@ stats = dict(traces=0, iters=0, seeds=0, voxels=0)
 while time.time() < t_end:
     rs = np.random.RandomState(1000 + case)
     two_d = rs.rand() < 0.12 and os.environ.get("PNR_SMC_DRIVER") != "persistent"  # (the persistent driver is 3-D only)
-    w, h, l = int(rs.randint(40, 97)), int(rs.randint(32, 81)), (1 if two_d else int(rs.randint(12, 41)))
+    big = 2 if os.environ.get("FUZZ_BIG") else 1  # FUZZ_BIG=1: stacks up to 192 x 160 x 80
+    w, h, l = int(rs.randint(40, 97 * big)), int(rs.randint(32, 81 * big)), (1 if two_d else int(rs.randint(12, 41 * big)))
     nsig = int(rs.randint(1, 4))
     sigs = sorted(float(x) for x in rs.choice([1.5, 2.0, 2.5, 3.0, 4.0, 6.0], nsig, replace=False))
     zdist = float(rs.choice([1.0, 2.0, 3.0, 4.0]))
