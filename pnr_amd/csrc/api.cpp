@@ -171,6 +171,10 @@ void pnr_destroy(pnr_ctx *c)
     pnr_job_destroy(c->job);
     pnr_phased_destroy(c->phased);
     if (c->h_j8) hipHostFree(c->h_j8);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (int k = 0; k < pnr_ctx::J8_CHUNKS; k++)
+        if (c->j8_ev[k]) (void)hipEventDestroy(c->j8_ev[k]);
+    if (c->j8_start) (void)hipEventDestroy(c->j8_start);
     hipFree(c->d_img_owned); hipFree(c->d_stash); hipFree(c->d_slot_busy); hipFree(c->d_den); hipFree(c->d_den_idx); hipFree(c->d_den_val);
     hipFree(c->d_tmpA); hipFree(c->d_tmpB); hipFree(c->d_J);
     hipFree(c->d_Vx); hipFree(c->d_Vy); hipFree(c->d_Vz); hipFree(c->d_J8); hipFree(c->d_minmax);

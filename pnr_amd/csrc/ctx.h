@@ -114,6 +114,9 @@ struct pnr_ctx {
     // seeds
     unsigned char *h_j8 = nullptr; // pinned staging buffer for the J8 download
     size_t h_j8_cap = 0;
+    static constexpr int J8_CHUNKS = 16;   // the download is cut into chunks of layers so that the flood fill starts on the first ones
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t j8_ev[J8_CHUNKS] = {}, j8_start = nullptr;
     std::vector<pnr_seed> seeds;
 
     // profiling: HIP event pairs recorded on the ctx stream around each kernel group, resolved

@@ -244,7 +244,23 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
         c->h_j8_cap = (size_t)(wh * nl);
     }
     unsigned char *h_j8 = c->h_j8;
-    PNR_HIP(hipMemcpyAsync(h_j8, c->d_J8 + z0 * wh, (size_t)(wh * nl), hipMemcpyDeviceToHost, c->stream));
+    // ... on a second stream, in chunks of layers with an event each: the kernels below run beside it, and the fill of a layer
+    // only waits for its own chunk (1 GiB takes 20 ms over PCIe, the fill of the first layers starts after ~6 ms)
+    constexpr int NCH = pnr_ctx::J8_CHUNKS;
+    if (!c->copy_stream) {
+        PNR_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        PNR_HIP(hipEventCreateWithFlags(&c->j8_start, hipEventDisableTiming));
+        for (int k = 0; k < NCH; k++) PNR_HIP(hipEventCreateWithFlags(&c->j8_ev[k], hipEventDisableTiming));
+    }
+    const int per_chunk = (nl + NCH - 1) / NCH;
+    PNR_HIP(hipEventRecord(c->j8_start, c->stream)); // J8 is complete at this point of the context's stream
+    PNR_HIP(hipStreamWaitEvent(c->copy_stream, c->j8_start, 0));
+    for (int k = 0; k < NCH; k++) {
+        const int l0 = k * per_chunk, l1 = std::min(nl, l0 + per_chunk);
+        if (l0 < l1)
+            PNR_HIP(hipMemcpyAsync(h_j8 + (size_t)l0 * wh, c->d_J8 + (z0 + l0) * wh, (size_t)(l1 - l0) * wh, hipMemcpyDeviceToHost, c->copy_stream));
+        PNR_HIP(hipEventRecord(c->j8_ev[k], c->copy_stream));
+    }
 
     c->tic();
     hipLaunchKernelGGL(layer_minmax, dim3(nl), dim3(256), 0, c->stream, c->d_J8, wh, (int)z0, d_min, d_max);
@@ -294,6 +310,7 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
                 const int k = next.fetch_add(1);
                 if (k >= nl) break;
                 if (cnt[k] == 0) continue;
+                (void)hipEventSynchronize(c->j8_ev[k / per_chunk]); // this layer's bytes have arrived
                 i64 *kb = keys.data() + off[k];
                 std::sort(kb, kb + cnt[k]); // unique keys: order fully defined (seed.cpp:632)
                 lf.run(h_j8 + (size_t)k * wh, kb, cnt[k], tol, acc[k]);
@@ -304,6 +321,7 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
         work();
         for (auto &t : th) t.join();
     }
+    PNR_HIP(hipStreamSynchronize(c->copy_stream)); // (layers without candidates never waited for their chunk)
     const double t_fill = now();
 
     // directions at the accepted voxels (seed.cpp:767-771)
@@ -338,7 +356,7 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     }
     hipFree(d_min); hipFree(d_max); hipFree(d_cnt); hipFree(d_vf); hipFree(d_off); hipFree(d_keys);
     if (timing)
-        fprintf(stderr, "[pnr seeds] kernels+download %.1f ms, host fill %.1f ms (%u threads, %lld candidates), dirs+free %.1f ms\n",
+        fprintf(stderr, "[pnr seeds] kernels + keys %.1f ms (J8 download overlapped), host fill %.1f ms (%u threads, %lld candidates), dirs+free %.1f ms\n",
                 1e3 * (t_gpu - t_start), 1e3 * (t_fill - t_gpu), std::thread::hardware_concurrency(), (long long)total, 1e3 * (now() - t_fill));
     return PNR_OK;
 }
