@@ -137,7 +137,7 @@ def main():
     ctx = pnr_amd.Context(p, local)
     ctx.set_smc_driver(a.driver)
     ctx.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
-    ctx.set_profiling(True)
+    ctx.set_profiling(not os.environ.get("PNR_BENCH_NOPROF"))  # NOPROF: how much do the HIP events of the kernel timers cost? (diagnostic; no roofline then)
     nvox = S * S * S
 
     def step():
@@ -199,6 +199,9 @@ def main():
         units = nvox * (world if a.mode == "stacks" else 1)
         ms_step = 1e3 * dt / a.steps
         value = units / (dt / a.steps) / 1e6
+        if os.environ.get("PNR_BENCH_NOPROF"):
+            print(json.dumps({"ms_per_step": ms_step, "value": value, "note": "kernel timers off: no roofline"}))
+            return
         km = {g: ctx.kernel_ms(g) for g in ("gauss", "hessian_eigen", "j8", "seed_maxima", "zncc", "smc", "smc_sums", "smc_predict", "smc_update")}
         # dominant kernel: the sampling kernel of the particle filter -- ph_sample (one launch per SMC step over all
         # active traces; the "smc" timer group) with the phased driver, smc_trace (one launch per batch, sampling +
