@@ -36,6 +36,8 @@ while time.time() < t_end:
             img = synth.add_somas(img, [(int(rs.randint(8, w - 8)), int(rs.randint(8, h - 8)), int(rs.randint(4, max(5, l - 4))), int(rs.randint(rad + 1, rad + 5)))
                                         for _ in range(int(rs.randint(1, 3)))])
         os.environ["PNR_GROUPS"] = str(groups)
+        for k, v in (("PNR_WINDOW", rs.choice([8, 32, 768])), ("PNR_LOOK0", rs.choice([2, 16, 128])), ("PNR_POLL", rs.choice([1, 4, 7]))):
+            os.environ[k] = str(int(v))  # the scheduler knobs never change a result
         p = pnr_amd.make_params(sigmas=sigs, somaradius=rad, step=step, kappa=kappa, zdist=zdist, np_=np_, ni=ni, tolerance=tol, znccth=znccth, nodepervol=npv, vol=vol)
         c = pnr_amd.Context(p, 0)
         c.set_volume(img)
