@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def built_tree():
+    """A fresh checkout has no binaries: compile the HIP library (hipcc cross-compiles without a GPU) and the head-less CLI once
+    per session, as __graft_entry__.build() does.  This only builds -- pnr_amd.lib.load() still fails loudly without the .so."""
+    import subprocess
+    import pnr_amd.lib as lib
+    if not os.path.exists(lib.LIB_PATH):
+        lib.build()
+    if not os.path.exists(os.path.join(ROOT, "pnr_amd", "host", "advantra_cli")):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "pnr_amd", "host")], check=True)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import orc
