@@ -5,30 +5,36 @@ One "step" = one pass of the hot path over one stack: Frangi (all scales) -> J8 
 extraction -> ZNCC seed scoring/filter/sort -> SMC tracing of the first `--seeds` sorted seeds
 (both directions) -> host replay.  The input stack is resident in HBM before the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N>1 (weak scaling): every rank owns an independent synthetic stack (seed 3+rank) and runs the
-whole path on it -- the unit of sharding is the stack, no data-path collective; the only
-collective is the final gather of the node graphs to rank 0 (RCCL over xGMI), inside the timed
-region.  `--mode shard` instead shards the sorted seeds of ONE replicated stack round-robin over
-the ranks (BASELINE configs[3]; strong scaling of the tracing stage).
+N > 1 without WORLD_SIZE in the environment: this process starts N ranks of itself with
+torch.distributed.run (one per GPU, RCCL) BEFORE anything touches a GPU, waits for them and exits
+with their code; launched by torch.distributed.run it is one of the ranks.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
-kernel, HIP-event time measured live on the kernel's stream) and `cpu_baseline` (oracle C
-restatement, 1 core, bounded sample).
+N > 1, default `--mode shard` = BASELINE configs[3] (strong scaling of ONE 1024^3 stack): every rank
+holds a replica of the u8 stack; Frangi + seed extraction run in z-slabs (2-float all-reduce of
+Jmin / Jmax, all-gather of the scored seeds), the sorted seeds are dealt round-robin and traced by
+pnr_trace_replay_sharded (per-poll all-gather of finished trace records, every rank replays them in
+global seed order: early DENSITY stops as on one GPU, every rank ends with the same node graph).
+`--mode stacks` is the replica mode: every rank owns an independent stack (weak scaling, no data-path
+collective, one final gather of the node graphs).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+HIP-event time measured live on the kernel's stream), `roofline_smc_group` (the whole particle-filter
+kernel group), `roofline_frangi`, and `cpu_baseline` (oracle C restatement, 1 core, bounded sample).
+Scheduler options for experiments: PNR_BENCH_OPTS="groups=2,window=1024" (pnr_set_option keys).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
@@ -42,8 +48,10 @@ def parse():
     ap.add_argument("--seeds", type=int, default=2000, help="sorted seeds traced per stack (configs[3]: 2000)")
     ap.add_argument("--np", type=int, default=200)
     ap.add_argument("--ni", type=int, default=200)
-    ap.add_argument("--mode", choices=["stacks", "shard"], default="stacks")
-    ap.add_argument("--one-shot", action="store_true", help="trace every seed to its map-free end + one replay (no early DENSITY stops)")
+    ap.add_argument("--mode", choices=["shard", "stacks"], default="shard", help="N > 1: one stack sharded over the ranks (configs[3]) or one stack per rank")
+    ap.add_argument("--one-shot", action="store_true", help="trace every seed to its map-free end + one replay (no early DENSITY stops; 1 GPU)")
+    ap.add_argument("--cpu-baseline", choices=["default", "survey", "off"], default="default",
+                    help="oracle on one host core: a 32-plane slab + 10 seeds (~1 min), SURVEY 8(d)'s 256-plane slab + 50 seeds (~10 min), or none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed full-occupancy measurement of the sampling kernel")
     ap.add_argument("--driver", choices=["phased", "persistent"], default="phased",
@@ -51,47 +59,84 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(img_dev, sigs, zdist, np_, n_iters_gpu, nvox, nseed_init):
-    """Oracle (C restatement, 1 thread) on a bounded sample of the same stack: Frangi + J8 + seeds
-    on a 160x160x80 crop around the stack centre, SMC on the crop's best seeds for ~150 iterations.
-    Scaled to the metric's unit with the GPU step's own work counts."""
+def launch_ranks(a):
+    """--gpus N given to a plain `python bench.py`: become the launcher of N ranks (nothing in this process has touched a GPU)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count()
+
+
+def cpu_baseline(img_dev, sigs, zdist, np_, ni, counts, nvox, kind):
+    """Oracle (oracle/pnr_oracle.c, the C restatement of the reference's scalar loops; 1 thread) on a bounded sample of the SAME
+    stack: Frangi + J8 + seed extraction on a z-slab of full xy extent (so the strided y / z passes see the real
+    row and plane pitches), seed scores on the slab's seeds, full-depth traces of the slab's best seeds until the time cap.
+    Scaled to the step: voxels x (Frangi + seeds per voxel) + seed scores + the SMC iterations the sequential reference would
+    run for the same graph (one per node + the stopping iteration of every trace -- no speculation)."""
+    import numpy as np
     import orc
     L = orc.load_oracle()
     S = img_dev.shape[0]
-    cw, ch, cl = min(160, S), min(160, S), min(80, S)
-    z0, y0, x0 = (S - cl) // 2, int(0.62 * S) - ch // 2, (S - cw) // 2
-    y0 = max(0, min(S - ch, y0))
-    crop = img_dev[z0:z0 + cl, y0:y0 + ch, x0:x0 + cw].contiguous().cpu().numpy()
+    planes, nseed, cap_s = (256, 50, 300.0) if kind == "survey" else (32, 10, 25.0)
+    planes = min(planes, S)
+    z0 = (S - planes) // 2
+    slab = img_dev[z0:z0 + planes].contiguous().cpu().numpy()
     t0 = time.perf_counter()
-    J, jmin, jmax, Vx, Vy, Vz = orc.frangi3d(L, crop, sigs, zdist)
+    J, jmin, jmax, Vx, Vy, Vz = orc.frangi3d(L, slab, sigs, zdist)
     J8 = orc.j8(L, J, jmin, jmax)
     t1 = time.perf_counter()
     seeds = orc.extract_seeds(L, 5, J8, Vx, Vy, Vz)
     t2 = time.perf_counter()
-    T = orc.Tracker(L, sigs, 2, np_, 25, 3.0, 0.3, zdist=zdist)
-    corr, _ = T.zncc(crop, seeds[:, :6]) if len(seeds) else (np.zeros(0), None)
+    del J, J8, Vx, Vy, Vz
+    T = orc.Tracker(L, sigs, 2, np_, ni, 3.0, 0.3, zdist=zdist)
+    nsc = min(len(seeds), 2000)
+    corr, _ = T.zncc(slab, seeds[:nsc, :6]) if nsc else (np.zeros(0), None)
     t3 = time.perf_counter()
-    order = np.argsort(-corr, kind="stable")[:3]
-    iters = 0
+    order = np.argsort(-corr, kind="stable")[:nseed]
+    iters = ntr = 0
     for i in order:
         for sgn in (1, -1):
+            if time.perf_counter() - t3 > cap_s:
+                break
             q = seeds[i, :6].copy()
             q[3:] *= sgn
-            Tn, stop, *_ = T.trace(crop, q)
-            iters += min(Tn + 1, 25)
+            Tn, stop, *_ = T.trace(slab, q)
+            iters += min(Tn + 1, ni)
+            ntr += 1
     t4 = time.perf_counter()
-    vs = crop.size
+    vs = slab.size
     t_frangi_vox = (t1 - t0) / vs
     t_seed_vox = (t2 - t1) / vs
-    t_eval = (t3 - t2) / max(len(seeds), 1)
+    t_eval = (t3 - t2) / max(nsc, 1)
     t_iter = (t4 - t3) / max(iters, 1)
-    total = nvox * (t_frangi_vox + t_seed_vox) + nseed_init * t_eval + n_iters_gpu * t_iter
+    seq_iters = counts["nodes"] + 2 * counts["traces_used"]
+    total = nvox * (t_frangi_vox + t_seed_vox) + counts["n_seeds_init"] * t_eval + seq_iters * t_iter
+    model, ncpu = cpu_info()
     return {
-        "value": nvox / total / 1e6, "unit": "Mvox/s", "cores": 1, "kind": "port",
-        "sample": (f"oracle/pnr_oracle.c, 1 thread: Frangi+J8 {t1 - t0:.2f}s and seeds {t2 - t1:.3f}s on a {cw}x{ch}x{cl} crop of "
-                   f"the same stack; {len(seeds)} znccBBB evals {t3 - t2:.2f}s; {iters} SMC iterations (np={np_}) {t4 - t3:.2f}s; "
-                   f"scaled to the step's {nvox} voxels, {nseed_init} seed scores and {n_iters_gpu} SMC iterations"),
-        "frangi_Mvox_s": 1e-6 / t_frangi_vox, "smc_ms_per_iter": 1e3 * t_iter,
+        "value": nvox / total / 1e6, "unit": "Mvox/s", "cores": 1, "cores_total": ncpu, "cpu_model": model, "kind": "port",
+        "sample": (f"oracle/pnr_oracle.c, 1 thread of {ncpu} ({model}): Frangi+J8 {t1 - t0:.1f}s and seeds {t2 - t1:.2f}s on the {planes}x{S}x{S} "
+                   f"slab z={z0}..{z0 + planes} of the same stack; {nsc} znccBBB seed scores {t3 - t2:.2f}s; {ntr} full-depth traces of the slab's best "
+                   f"seeds, {iters} SMC iterations (np={np_}) {t4 - t3:.1f}s (cap {cap_s:.0f}s); scaled to the step's {nvox} voxels, "
+                   f"{counts['n_seeds_init']} seed scores and {seq_iters} sequential SMC iterations (nodes + 2 per trace; the GPU ran {counts['iters_all']})"),
+        "frangi_Mvox_s": 1e-6 / t_frangi_vox, "seeds_Mvox_s": 1e-6 / max(t_seed_vox, 1e-12), "smc_ms_per_iter": 1e3 * t_iter,
+        "Mevals_per_s_smc": (np_ + 1) / t_iter / 1e6,
     }
 
 
@@ -104,17 +149,28 @@ def stash_row_floats(np_):
 
 def main():
     a = parse()
+    if a.no_cpu_baseline:
+        a.cpu_baseline = "off"
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))  # before torch / HIP are even imported
+    import numpy as np
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X (no CPU path)", file=sys.stderr)
         sys.exit(2)
     # rehearsal on a box with fewer GPUs than ranks (never the measured configuration): PNR_BENCH_BACKEND=gloo puts the collectives
     # on CPU tensors and lets the ranks share the visible GPUs
     backend = os.environ.get("PNR_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
     if backend != "nccl":
-        local = local % max(1, torch.cuda.device_count())
+        local = local % max(1, ndev)
+    elif local >= ndev:
+        print(f"bench.py: rank {rank} needs GPU {local} but only {ndev} are visible (PNR_BENCH_BACKEND=gloo rehearses N ranks on fewer GPUs)", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     coll_dev = torch.device("cuda", local) if backend == "nccl" else torch.device("cpu")
     dist = None
@@ -124,51 +180,62 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()  # the ranks the backend actually joined
     import synth
     import pnr_amd
     from pnr_amd import multigpu
 
     S = a.size
     sigs, zdist = (2.0, 4.0, 6.0), 2.0
-    stack_seed = 3 + (rank if a.mode == "stacks" else 0)
+    shard = world > 1 and a.mode == "shard"
+    stack_seed = 3 + (rank if (world > 1 and a.mode == "stacks") else 0)
     img = synth.synth_torch(S, S, S, seed=stack_seed, device=f"cuda:{local}")
     torch.cuda.synchronize()
     p = pnr_amd.make_params(sigmas=sigs, np_=a.np, ni=a.ni, zdist=zdist)
     ctx = pnr_amd.Context(p, local)
     ctx.set_smc_driver(a.driver)
+    ctx.set_option("local_ranks", local_world)  # the host threads of the seed flood fill are shared between the ranks of this node
+    opts = ctx.set_options(os.environ.get("PNR_BENCH_OPTS"))
     ctx.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
     ctx.set_profiling(not os.environ.get("PNR_BENCH_NOPROF"))  # NOPROF: how much do the HIP events of the kernel timers cost? (diagnostic; no roofline then)
     nvox = S * S * S
+    exchange = multigpu.make_exchange(dist, world, coll_dev) if shard else None
 
     def step():
         st = {}
         t0 = time.perf_counter()
-        if a.mode == "shard" and dist is not None:  # one stack: z-slabs of Frangi + seeds per rank, 2-float all-reduce, seed all-gather
+        if shard:  # one stack: z-slabs of Frangi + seeds per rank, 2-float all-reduce, scored seeds all-gathered
             mine, _, _ = multigpu.frangi_seeds_sharded(ctx, img.data_ptr(), (S, S, S), dist, rank, world, device=coll_dev)
             t1 = time.perf_counter()
+            n_init = len(mine)
+            mine = ctx.score_filter(mine)  # znccBBB of this slab's seeds on the whole stack, threshold
+            t2 = time.perf_counter()
             s0 = multigpu.gather_seeds(mine, dist, rank, world, coll_dev)
+            s = ctx.sort_seeds(s0)[:a.seeds]
+            t3 = time.perf_counter()
+            nodes, links, ntr, iters = ctx.trace_replay_sharded(s, rank, world, exchange)
         else:
             ctx.frangi()
             t1 = time.perf_counter()
             s0 = ctx.extract_seeds()
-        t2 = time.perf_counter()
-        s = ctx.score_filter_sort(s0)[:a.seeds]
-        t3 = time.perf_counter()
-        if a.mode == "shard" and dist is not None:
-            nodes, links, T = multigpu.trace_sharded(ctx, s, dist, rank, world, device=coll_dev)
-            iters = int((T + (T < a.ni)).sum())
-        else:
+            n_init = len(s0)
+            t2 = time.perf_counter()
+            s = ctx.score_filter_sort(s0)[:a.seeds]
+            t3 = time.perf_counter()
             if a.one_shot:
                 T, stop, xc, _ = ctx.trace_batch(s)
-                nodes, links, _ = ctx.replay(s, T, xc)
+                nodes, links, ntr = ctx.replay(s, T, xc)
                 iters = int((T + (T < a.ni)).sum())
             else:
-                nodes, links, _, iters = ctx.trace_replay(s)
-            if dist is not None:
+                nodes, links, ntr, iters = ctx.trace_replay(s)
+            if dist is not None and a.mode == "stacks":
                 multigpu.gather_graphs(nodes, links, dist, rank, world, coll_dev)
         t5 = time.perf_counter()
-        st.update(frangi_ms=1e3 * (t1 - t0), seeds_ms=1e3 * (t2 - t1), score_ms=1e3 * (t3 - t2), trace_replay_gather_ms=1e3 * (t5 - t3),
-                  n_seeds_init=len(s0), n_seeds=len(s), iters=iters, nodes=len(nodes) - 1)
+        if shard:
+            st.update(frangi_seeds_slab_ms=1e3 * (t1 - t0), score_slab_ms=1e3 * (t2 - t1), gather_sort_ms=1e3 * (t3 - t2), trace_replay_exchange_ms=1e3 * (t5 - t3))
+        else:
+            st.update(frangi_ms=1e3 * (t1 - t0), seeds_ms=1e3 * (t2 - t1), score_ms=1e3 * (t3 - t2), trace_replay_gather_ms=1e3 * (t5 - t3))
+        st.update(n_seeds_init=n_init, n_seeds=len(s), iters=iters, nodes=len(nodes) - 1, traces_used=int(ntr))
         return st
 
     def barrier():
@@ -189,58 +256,85 @@ def main():
         tt = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        it = torch.tensor([st["iters"]], device=coll_dev, dtype=torch.int64)
+        it = torch.tensor([st["iters"], st["n_seeds_init"]], device=coll_dev, dtype=torch.int64)
         dist.all_reduce(it)
-        iters_all = int(it.item())
+        iters_all = int(it[0].item())
+        if shard:
+            st["n_seeds_init"] = int(it[1].item())
     else:
         iters_all = st["iters"]
+    st["iters_all"] = iters_all
 
     if rank == 0:
-        units = nvox * (world if a.mode == "stacks" else 1)
+        units = nvox * (world if (world > 1 and a.mode == "stacks") else 1)
         ms_step = 1e3 * dt / a.steps
         value = units / (dt / a.steps) / 1e6
         if os.environ.get("PNR_BENCH_NOPROF"):
-            print(json.dumps({"ms_per_step": ms_step, "value": value, "note": "kernel timers off: no roofline"}))
+            print(json.dumps({"ms_per_step": ms_step, "value": value, "n_gpus": world, "note": "kernel timers off: no roofline"}))
+            if dist is not None:
+                dist.barrier()
+                dist.destroy_process_group()
             return
         km = {g: ctx.kernel_ms(g) for g in ("gauss", "hessian_eigen", "j8", "seed_maxima", "zncc", "smc", "smc_sums", "smc_predict", "smc_update")}
         # dominant kernel: the sampling kernel of the particle filter -- ph_sample (one launch per SMC step over all
         # active traces; the "smc" timer group) with the phased driver, smc_trace (one launch per batch, sampling +
         # sums + update) with the persistent one.  Algorithmic bytes: 8 corner bytes x sum(M_sigma)
-        # samples per particle evaluation, (np+1) evaluations per SMC iteration; ph_sample performs every one of them.
+        # samples per particle evaluation, (np+1) evaluations per SMC iteration; ph_sample performs every one of them
+        # (rank 0's kernels and rank 0's iterations when the seeds are sharded).
         kname = "ph_sample<54, false>" if a.driver == "phased" else "smc_trace"
         Mtot = sum(len(ctx.table(f"model_wgt{s}")) for s in range(len(sigs)))
         smc_ms, smc_n = km["smc"]
         smc_all_ms = sum(km[g][0] for g in ("smc", "smc_sums", "smc_predict", "smc_update"))
         evals = st["iters"] * (a.np + 1)
-        # several launches per step (seed-rank batches): bytes per launch / average launch duration
-        # = total bytes of the timed region / total smc_trace device time
+        # several launches per step: bytes per launch / average launch duration = total bytes of the timed region / total device time
         bytes_launch = 8.0 * Mtot * evals * a.steps / max(smc_n, 1)
         achieved = bytes_launch / (smc_ms / max(smc_n, 1) * 1e-3) / 1e9 if smc_ms > 0 else 0.0
         fr_ms = (km["gauss"][0] + km["hessian_eigen"][0] + km["j8"][0]) / a.steps
+        fr_vox = nvox if not shard else None  # a rank's slab + halo when sharded: no per-stack Frangi figure then
         # HBM traffic per launch: PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, calibrated on
         # a known byte count in the same access pattern: scripts/prof_traffic.sh), collected for THIS workload and
-        # committed under profiles/; null for any other workload
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_1024_s2000.json" if a.driver == "persistent" else "r01h_traffic_1024_s2000.json")
-        if S == 1024 and a.seeds == 2000 and a.np == 200 and a.ni == 200 and not a.one_shot and a.mode == "stacks" and os.path.exists(tpath):
-            tj = json.load(open(tpath)).get("smc_trace" if a.driver == "persistent" else "ph_sample", {})
-            if "FETCH_SIZE" in tj and "WRITE_SIZE" in tj:
-                traffic = tj["FETCH_SIZE"]["bytes_per_launch"] + tj["WRITE_SIZE"]["bytes_per_launch"]
+        # committed under profiles/ -- read from that file, not measured in this run; null for any other workload
+        traffic, traffic_src = None, None
+        for cand in ("r02_traffic_1024_s2000.json", "r01h_traffic_1024_s2000.json"):
+            tpath = os.path.join(ROOT, "profiles", cand if a.driver == "phased" else "r01_traffic_1024_s2000.json")
+            if S == 1024 and a.seeds == 2000 and a.np == 200 and a.ni == 200 and not a.one_shot and world == 1 and os.path.exists(tpath):
+                tj = json.load(open(tpath)).get("smc_trace" if a.driver == "persistent" else "ph_sample", {})
+                if "FETCH_SIZE" in tj and "WRITE_SIZE" in tj:
+                    traffic = tj["FETCH_SIZE"]["bytes_per_launch"] + tj["WRITE_SIZE"]["bytes_per_launch"]
+                    traffic_src = "profiles/" + os.path.basename(tpath)
+                    break
+        group_GBs = 8.0 * Mtot * evals * a.steps / (smc_all_ms * 1e-3) / 1e9 if smc_all_ms > 0 else None
+        if world == 1:
+            par = "1 GPU"
+        elif shard:
+            par = (f"one stack on {world} GPUs: Frangi + seeds + seed scores in z-slabs, sorted seeds round-robin; RCCL all-reduce(min,max), all-gather of "
+                   "seeds, per-poll all-gather of finished trace records; every rank replays in global seed order")
+        else:
+            par = f"{world} independent stacks, one per GPU; RCCL gather of node graphs"
         out = {
             "metric": "Mvox/s traced (Frangi+SMC step) on 1024^3 synthetic stack; % HBM roofline" if S == 1024 else f"Mvox/s traced (Frangi+SMC step) on {S}^3 synthetic stack; % HBM roofline",
             "value": value, "unit": "Mvox/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak" if a.mode == "stacks" else "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if (world > 1 and a.mode == "stacks") else "strong", "vs_baseline": None,
             "dtype": "f32 (+f64 3x3 eigen-solver)", "data": "synthetic",
             "config": {"workload": f"{S}^3 synthetic u8 stack (tests/synth.py seed {stack_seed}), scales={{2,4,6}}, zdist=2, np={a.np}, ni={a.ni}, "
                                    f"first {a.seeds} sorted seeds traced in both directions per stack, tolerance=5, znccth=0.3, step=2, kappa=3",
-                       "parallelism": ("1 GPU" if world == 1 else (f"{world} independent stacks, one per GPU; RCCL gather of node graphs" if a.mode == "stacks"
-                                       else f"one stack: Frangi + seeds in z-slabs, sorted seeds round-robin over {world} GPUs; RCCL all-reduce(min,max), all-gather of seeds and trace records"))},
-            "roofline": {"kernel": kname, "bound": "hbm", "bytes_per_launch": bytes_launch, "avg_launch_ms": smc_ms / max(smc_n, 1), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "algorithmic gather bytes 8*sum(M_sigma)=%d B per particle evaluation; served from L1/L2, see DESIGN.md" % (8 * Mtot)},
-            "roofline_frangi": {"kernels": "gauss_x_u8+gauss_axis(y,z)+hessian_eigen+j8", "bound": "hbm", "achieved": (len(sigs) + 12) * nvox / (fr_ms * 1e-3) / 1e9,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (len(sigs) + 12) * nvox / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "note": "(S+12) B/voxel compulsory bytes over the Frangi kernel group; fp64 eigen-solver is the limiter"},
+                       "parallelism": par, "backend": backend if world > 1 else None, "options": opts or None},
+            "roofline": {"kernel": kname, "bound": "lds-gather/valu", "bytes_per_launch": bytes_launch, "avg_launch_ms": smc_ms / max(smc_n, 1), "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "note": "ALGORITHMIC gather bytes, 8*sum(M_sigma)=%d B per particle evaluation, over the launch time of the sampling kernel alone, "
+                                 "priced against the HBM peak as SURVEY 8(d) prescribes; the gather is served from the LDS cube (PMC: VALU issue ~80 %%, LDS "
+                                 "bank conflicts ~60 %% of LDS cycles), so the kernel is VALU / LDS-gather bound, not HBM bound; `traffic` (real HBM bytes per "
+                                 "launch, PMC) is read from the committed profile named in traffic_source, not measured in this run; the ordered sums of "
+                                 "the same evaluations are the separate kernel ph_sums -- roofline_smc_group prices the whole evaluation" % (8 * Mtot)},
+            "roofline_smc_group": None if smc_all_ms <= 0 else {
+                "kernels": "ph_predict+ph_sample+ph_sums+ph_update" if a.driver == "phased" else "smc_trace", "bound": "lds-gather/valu + hbm (stash)",
+                "achieved": group_GBs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": group_GBs / HBM_PEAK_GBS,
+                "device_ms_per_step": smc_all_ms / a.steps, "Mevals_per_s": evals * a.steps / smc_all_ms / 1e3,
+                "note": "SURVEY 8(d): 8*sum(M) algorithmic bytes x particle evaluations / device time of the whole SMC kernel group (t_smc)"},
+            "roofline_frangi": None if not fr_vox or fr_ms <= 0 else {
+                "kernels": "gauss_xy_u8+gauss_z+hessian_eigen+j8", "bound": "hbm", "achieved": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "device_ms_per_step": fr_ms,
+                "note": "(S+12) B/voxel compulsory bytes over the Frangi kernel group; the fp64 JAMA eigen-solver (parity-mandated) is the limiter"},
             "roofline_sums": None if a.driver != "phased" or km["smc_sums"][0] <= 0 else {
                 "kernel": "ph_sums", "bound": "hbm", "launches": km["smc_sums"][1], "avg_launch_ms": km["smc_sums"][0] / max(km["smc_sums"][1], 1),
                 "achieved": 2.0 * 4 * Mtot * stash_row_floats(a.np) * st["iters"] * a.steps / (km["smc_sums"][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -249,11 +343,8 @@ def main():
             "stages_ms": {k: v for k, v in st.items() if k.endswith("_ms")},
             "kernel_ms_per_step": {g: km[g][0] / a.steps for g in km},
             "counts": {k: v for k, v in st.items() if not k.endswith("_ms")},
-            # particle evaluations / time of the whole SMC kernel group (sampling + sums + predict + update)
-            "Mevals_per_s_smc": evals * a.steps / smc_all_ms / 1e3 if smc_all_ms > 0 else None,
-            "smc_group_GBs": 8.0 * Mtot * evals * a.steps / (smc_all_ms * 1e-3) / 1e9 if smc_all_ms > 0 else None,
             "smc_launches_per_step": smc_n / a.steps,
-            "Mvox_per_s_frangi": nvox / (fr_ms * 1e-3) / 1e6,
+            "Mvox_per_s_frangi": (nvox / (fr_ms * 1e-3) / 1e6) if (fr_vox and fr_ms > 0) else None,
         }
         if world == 1 and not a.one_shot and not a.no_extra:
             # the same kernel with every CU busy: ONE launch over all traces (outside the timed region)
@@ -266,8 +357,8 @@ def main():
                 "kernel": kname, "launches": n1, "avg_launch_ms": ms1 / max(n1, 1), "achieved": 8.0 * Mtot * ev1 / (ms1 * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * Mtot * ev1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "Mevals_per_s": ev1 / ms1 / 1e3,
                 "note": "all %d traces started together, traced to their map-free end (no early DENSITY stops): %d SMC iterations; measured after the timed region" % (len(T1), ev1 // (a.np + 1))}
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(img, list(sigs), zdist, a.np, st["iters"], nvox, st["n_seeds_init"])
+        if a.cpu_baseline != "off" and world == 1:
+            out["cpu_baseline"] = cpu_baseline(img, list(sigs), zdist, a.np, a.ni, st, nvox, a.cpu_baseline)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -40,7 +40,7 @@ enum {
 typedef struct pnr_params {
     float sig[PNR_MAX_SIGMAS]; /* neuritesigmas, ascending (parse_csv_string :1885-1897) */
     int nsig;
-    int somaradius;  /* must be 0: soma path is out of scope */
+    int somaradius;  /* > 0: soma path, call pnr_soma after pnr_set_volume (Advantra_plugin.cpp:2426-2448) */
     float tolerance; /* MaximumFinder tolerance on J8 */
     float znccth;
     float kappa;
@@ -130,6 +130,11 @@ int pnr_zncc_batch(pnr_ctx *ctx, const float *pos_dir, int64_t n, float *corr, f
 /* Seed filter + sort (Advantra_plugin.cpp:2561-2586): corr = znccBBB(seed); drop corr < znccth;
  * sort by corr descending (ties: original order).  In place; *n_out <= n. */
 int pnr_score_filter_sort_seeds(pnr_ctx *ctx, pnr_seed *seeds, int64_t n, int64_t *n_out);
+/* The same in two halves, for one stack on several GPUs: every rank scores and filters the seeds of its own z-slab (order kept),
+ * the merged list -- in the z-major order of the unsharded extraction -- is then sorted on every rank: the result is the list
+ * pnr_score_filter_sort_seeds gives on one GPU (the sort is stable, ties keep the z-major order). */
+int pnr_score_filter_seeds(pnr_ctx *ctx, pnr_seed *seeds, int64_t n, int64_t *n_out);
+int pnr_sort_seeds(pnr_ctx *ctx, pnr_seed *seeds, int64_t n, int64_t *n_out);
 
 /* Map-independent part of Tracker::trackPos / trackNeg (tracker.cpp:819-933 -> iter0New :1001,
  * iterINew :1096) for n seeds x 2 directions, all on the GPU.  Trace j = 2*i + dir (dir 1 =
@@ -179,6 +184,38 @@ int pnr_trace_replay(pnr_ctx *ctx, const pnr_seed *seeds, int64_t n, int64_t fir
                      int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links,
                      int64_t *n_traces_used, int64_t *n_iterations);
 
+/* The node graph of the last pnr_trace_replay / pnr_trace_replay_sharded stays in the context: a caller whose buffers were too
+ * small (n_nodes > cap_nodes) allocates and fetches it here instead of tracing again. */
+int pnr_get_graph(pnr_ctx *ctx, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links,
+                  int64_t *n_links);
+
+/* ---- one stack, several GPUs: the sorted seeds sharded over `world` processes (one pnr_ctx per GPU; BASELINE configs[3]) ----
+ * The reference has no distributed code; what is kept is the result of its sequential trace loop
+ * (Advantra_plugin.cpp:2658-2710).  Rank r traces the seeds r, r + world, ... of the SAME sorted list in its own window of trace
+ * slots; after every poll the ranks all-gather the records of the traces that finished (one fixed-size block per rank) and every
+ * rank replays them in global seed order, so that every GPU's density map holds the replayed nodes of all ranks: the early
+ * DENSITY stops (tracker.cpp:855) and the seed skip rule (:2669-2670) work as on one GPU and every rank returns the same node
+ * graph -- the graph of pnr_trace_replay on one GPU.
+ *
+ * The transport is the host's: `exchange(user, send, recv, bytes)` must behave like an all-gather of `bytes` bytes per rank
+ * (recv = world x bytes, rank order) over whatever joins the processes -- RCCL / torch.distributed (pnr_amd/multigpu.py), MPI, a
+ * thread barrier in tests -- and return 0.  It is called once per poll by every rank, the same number of times on all of them.
+ * A rank that fails says so in one last exchange, so the others return PNR_E_STATE instead of waiting for it. */
+typedef int (*pnr_allgather_fn)(void *user, const void *send, void *recv, int64_t bytes_per_rank);
+int pnr_trace_replay_sharded(pnr_ctx *ctx, const pnr_seed *seeds, int64_t n, int rank, int world, pnr_allgather_fn exchange,
+                             void *user, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links,
+                             int64_t cap_links, int64_t *n_links, int64_t *n_traces_used, int64_t *n_iterations_here);
+
+/* The scheduler behind pnr_trace_replay[_sharded] (stream_sched.h) over a HOST engine that plays back map-free traces which
+ * `trace(user, pos_dir[6], &T, xc[ni])` supplies (0 = ok; rows 0..min(T, ni)-1 of xc valid) -- pure host code, no GPU: the
+ * multi-process tests drive the window / admission / exchange / replay logic with it, and a recorded workload can be
+ * re-scheduled offline.  Same outputs as pnr_trace_replay_sharded. */
+typedef int (*pnr_trace_fn)(void *user, const float *pos_dir, int32_t *T, pnr_xest *xc);
+int pnr_sched_playback(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n, int rank,
+                       int world, pnr_allgather_fn exchange, void *exchange_user, int64_t block_bytes, pnr_trace_fn trace,
+                       void *trace_user, int window, int groups, int poll, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes,
+                       int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used, int64_t *n_iterations_here);
+
 /* reconstruct() chain of the plugin (Advantra_plugin.cpp:2096-2181), pure host: link resampling
  * (TRACE_RSMPL) -> mean-shift refinement (SIG2RADIUS, REFINE_ITER, EPSILON2) -> sphere grouping (GROUP_RADIUS) ->
  * BFS trees -> drop trees < TREE_SIZE_MIN -> tree resampling.  Input: the node graph of pnr_trace_replay /
@@ -194,9 +231,19 @@ int pnr_reconstruct(const pnr_node *nodes, int64_t n_nodes, const int32_t *links
 int pnr_get_table(pnr_ctx *ctx, const char *name, void *out, int64_t cap, int64_t *n);
 
 /* How pnr_trace_batch / pnr_trace_replay schedule the particle filter on the GPU (results are bit-identical):
- * 0 = one launch per SMC phase over all active traces of a batch (default), 1 = one persistent work-group per trace.
- * The environment variable PNR_SMC_DRIVER=phased|persistent sets the initial choice of a new context. */
+ * 0 = one launch per SMC phase over all active traces of a batch (default), 1 = one persistent work-group per trace. */
 int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
+
+/* Scheduling and host-side knobs of a context; none of them changes a result (the library reads no environment variable).
+ *   window (768) trace slots kept busy | look0, look_pct (0 / -1 = automatic) admission lookahead max(look0, frontier*look_pct/100)
+ *   poll (4) SMC steps between polls | groups (1..4) trace groups on separate streams | split_x10 (40), max_split (24) sampling
+ *   work-groups per CU x 10 / per trace | stash_mb (65536) sample-stash budget | host_threads (0 = CPUs of this process /
+ *   local_ranks) workers of the seed flood fill and of pnr_reconstruct_ctx | local_ranks (1) processes sharing this host |
+ *   trace_timing, seed_timing (0/1) statistics on stderr | replay_batches (0/1), batch_growth, batch_max: rank batches instead
+ *   of the streaming window | no_stash (0/1) persistent driver without the sample stash | exchange_block (65536) bytes per rank
+ *   and exchange of pnr_trace_replay_sharded.   pnr_get_option also knows "host_threads_effective". */
+int pnr_set_option(pnr_ctx *ctx, const char *key, int64_t value);
+int pnr_get_option(pnr_ctx *ctx, const char *key, int64_t *value);
 
 /* Per-kernel-group device time (HIP events on the ctx stream) accumulated since the last reset:
  * groups: "gauss","hessian_eigen","j8","seed_maxima","soma","zncc","smc" (sampling kernel; the whole trace kernel of the persistent driver),"smc_sums","smc_predict","smc_update".  Enabled by set_profiling. */

@@ -4,6 +4,7 @@
 // (tracker.cpp:825-933 + Advantra_plugin.cpp:2602-2710).
 #include "ctx.h"
 #include "replay.h"
+#include "stream_sched.h"
 #include "../host/reconstruct.h"
 #include <algorithm>
 #include <cfloat>
@@ -12,6 +13,9 @@
 #include <cstring>
 #include <numeric>
 #include <unordered_map>
+#include <fstream>
+#include <thread>
+#include <sched.h>
 
 namespace pnr {
 static thread_local char g_err[512] = "";
@@ -21,6 +25,26 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// worker threads for the host-side stages (seed flood fill, reconstruct()): the CPUs this process may run on (affinity mask,
+// cgroup quota), shared between the ranks of this host (one process per GPU)
+int host_threads(const Options &o)
+{
+    if (o.host_threads > 0) return o.host_threads;
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    std::ifstream f("/sys/fs/cgroup/cpu.max"); // "<quota> <period>" or "max <period>"
+    std::string q;
+    long long per = 0;
+    if (f >> q >> per && q != "max" && per > 0) {
+        const long long lim = (atoll(q.c_str()) + per - 1) / per;
+        if (lim > 0 && lim < n) n = (int)lim;
+    }
+    n /= std::max(1, o.local_ranks);
+    return std::min(std::max(n, 1), 32); // the fills of a stack's layers stop scaling long before that
 }
 } // namespace pnr
 
@@ -149,7 +173,6 @@ int pnr_create(const pnr_params *p, int device, pnr_ctx **out)
         return PNR_E_HIP;
     }
     c->stream = c->own_stream;
-    if (const char *e = getenv("PNR_SMC_DRIVER")) c->smc_driver = (strcmp(e, "persistent") == 0) ? 1 : 0;
     (void)hipEventCreate(&c->ev0);
     (void)hipEventCreate(&c->ev1);
     rc = load_tables(c, /*is2d*/ false);
@@ -229,9 +252,14 @@ int pnr_set_volume(pnr_ctx *c, const uint8_t *img, int64_t w, int64_t h, int64_t
     PNR_REQUIRE(img, PNR_E_ARG, "null image");
     int rc = set_dims(c, w, h, l);
     if (rc) return rc;
-    hipFree(c->d_img_owned);
-    c->d_img_owned = nullptr;
-    PNR_HIP(hipMalloc(&c->d_img_owned, (size_t)c->N));
+    c->d_img = nullptr; // never leave the context pointing at a freed image if the allocation below fails
+    if (c->img_owned_cap < (size_t)c->N) {
+        hipFree(c->d_img_owned);
+        c->d_img_owned = nullptr;
+        c->img_owned_cap = 0;
+        PNR_HIP(hipMalloc(&c->d_img_owned, (size_t)c->N));
+        c->img_owned_cap = (size_t)c->N;
+    }
     PNR_HIP(hipMemcpyAsync(c->d_img_owned, img, (size_t)c->N, hipMemcpyHostToDevice, c->stream));
     PNR_HIP(hipStreamSynchronize(c->stream));
     c->d_img = c->d_img_owned;
@@ -363,12 +391,14 @@ int pnr_zncc_batch(pnr_ctx *c, const float *pos_dir, int64_t n, float *corr, flo
     return pnr_zncc_run(c, pos_dir, n, corr, sig);
 }
 
-int pnr_score_filter_sort_seeds(pnr_ctx *c, pnr_seed *seeds, int64_t n, int64_t *n_out)
+// the three steps of the seed filter (Advantra_plugin.cpp:2561-2586); score_only / presorted let several GPUs score their own
+// seeds and sort the merged list
+static int seed_filter(pnr_ctx *c, pnr_seed *seeds, int64_t n, int64_t *n_out, bool score, bool sort)
 {
     PNR_REQUIRE(c && n_out && (n == 0 || seeds), PNR_E_ARG, "null argument");
     *n_out = 0;
     if (n == 0) return PNR_OK;
-    if (c->prm.somaradius > 0) { // seeds inside a soma are dropped before they are scored (:2561-2564)
+    if (score && c->prm.somaradius > 0) { // seeds inside a soma are dropped before they are scored (:2561-2564)
         PNR_REQUIRE(c->have_soma, PNR_E_STATE, "somaradius > 0: call pnr_soma before the seeds are filtered");
         int64_t m = 0;
         for (int64_t i = 0; i < n; i++) {
@@ -378,27 +408,32 @@ int pnr_score_filter_sort_seeds(pnr_ctx *c, pnr_seed *seeds, int64_t n, int64_t 
         n = m;
         if (n == 0) return PNR_OK;
     }
-    std::vector<float> pd((size_t)n * 6), corr((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
-        float *q = &pd[(size_t)i * 6];
-        q[0] = seeds[i].x; q[1] = seeds[i].y; q[2] = seeds[i].z;
-        q[3] = seeds[i].vx; q[4] = seeds[i].vy; q[5] = seeds[i].vz;
+    if (score) {
+        std::vector<float> pd((size_t)n * 6), corr((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            float *q = &pd[(size_t)i * 6];
+            q[0] = seeds[i].x; q[1] = seeds[i].y; q[2] = seeds[i].z;
+            q[3] = seeds[i].vx; q[4] = seeds[i].vy; q[5] = seeds[i].vz;
+        }
+        int rc = pnr_zncc_batch(c, pd.data(), n, corr.data(), nullptr);
+        if (rc) return rc;
+        for (int64_t i = 0; i < n; i++) seeds[i].corr = corr[i];
     }
-    int rc = pnr_zncc_batch(c, pd.data(), n, corr.data(), nullptr);
-    if (rc) return rc;
     std::vector<pnr_seed> kept;
-    for (int64_t i = 0; i < n; i++) {
-        seeds[i].corr = corr[i];
+    for (int64_t i = 0; i < n; i++)
         if (!(seeds[i].corr < c->prm.znccth)) kept.push_back(seeds[i]); // erase if corr < znccth (:2571)
-    }
     std::vector<int64_t> order(kept.size());
     std::iota(order.begin(), order.end(), 0);
     // std::sort with CompareSeedCorr is unstable in the reference; ties are broken by original index here
-    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return kept[a].corr > kept[b].corr; });
+    if (sort) std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return kept[a].corr > kept[b].corr; });
     for (size_t i = 0; i < order.size(); i++) seeds[i] = kept[order[i]];
     *n_out = (int64_t)kept.size();
     return PNR_OK;
 }
+
+int pnr_score_filter_sort_seeds(pnr_ctx *c, pnr_seed *seeds, int64_t n, int64_t *n_out) { return seed_filter(c, seeds, n, n_out, true, true); }
+int pnr_score_filter_seeds(pnr_ctx *c, pnr_seed *seeds, int64_t n, int64_t *n_out) { return seed_filter(c, seeds, n, n_out, true, false); }
+int pnr_sort_seeds(pnr_ctx *c, pnr_seed *seeds, int64_t n, int64_t *n_out) { return seed_filter(c, seeds, n, n_out, false, true); }
 
 int pnr_trace_batch(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T, int32_t *stop, pnr_xest *xc, int dbg_iters,
                     float *xfilt, int32_t *idxres, float *neff)
@@ -467,32 +502,54 @@ int pnr_replay_traces(const pnr_params *p, int64_t w, int64_t h, int64_t l, cons
     return PNR_OK;
 }
 
-// Trace + replay in seed-rank batches (the production form of the trace loop, Advantra_plugin.cpp:2658-2710).
-// Tracing every seed to its map-free end wastes most GPU iterations: in the reference a trace stops as
-// soon as it runs into voxels that earlier traces already filled (DENSITY stop, tracker.cpp:855,870-882),
-// and a seed on a filled voxel is never traced (:2669-2670).  Here the density map produced by the
-// replay of batches 0..b-1 is uploaded before batch b; the kernel ends a trace at the first iteration
-// whose centroid voxel is already saturated in that (stale) map.  A stale map only under-counts, so a
-// trace is never cut earlier than the sequential reference would cut it, and the replay -- which applies
-// the true map -- produces exactly the same nodes and links as the one-shot form.
-int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first_batch, pnr_node *nodes, int64_t cap_nodes,
-                     int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used,
-                     int64_t *n_iterations)
+// the graph of the last pnr_trace_replay / pnr_trace_replay_sharded stays in the context (pnr_get_graph): a caller whose buffers
+// were too small fetches it again instead of tracing again
+static int store_graph(pnr_ctx *c, pnr::Replayer &r, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links,
+                       int64_t *n_links, int64_t *n_traces_used)
+{
+    c->graph_nodes.swap(r.nodes);
+    c->graph_links.swap(r.links);
+    c->graph_traces = r.trace_count;
+    c->have_graph = true;
+    *n_nodes = (int64_t)c->graph_nodes.size();
+    *n_links = (int64_t)c->graph_links.size() / 2;
+    if (nodes) std::memcpy(nodes, c->graph_nodes.data(), sizeof(pnr_node) * (size_t)std::min<int64_t>(cap_nodes, *n_nodes));
+    if (links) std::memcpy(links, c->graph_links.data(), 8 * (size_t)std::min<int64_t>(cap_links, *n_links));
+    if (n_traces_used) *n_traces_used = c->graph_traces;
+    return PNR_OK;
+}
+
+int pnr_get_graph(pnr_ctx *c, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links)
+{
+    PNR_REQUIRE(c && n_nodes && n_links, PNR_E_ARG, "null argument");
+    PNR_REQUIRE(c->have_graph, PNR_E_STATE, "no node graph: pnr_trace_replay has not run");
+    *n_nodes = (int64_t)c->graph_nodes.size();
+    *n_links = (int64_t)c->graph_links.size() / 2;
+    if (nodes) std::memcpy(nodes, c->graph_nodes.data(), sizeof(pnr_node) * (size_t)std::min<int64_t>(cap_nodes, *n_nodes));
+    if (links) std::memcpy(links, c->graph_links.data(), 8 * (size_t)std::min<int64_t>(cap_links, *n_links));
+    return PNR_OK;
+}
+
+static int trace_replay_impl(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first_batch, const pnr::ShardSpec &sh, pnr_node *nodes,
+                             int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used,
+                             int64_t *n_iterations)
 {
     PNR_REQUIRE(c && n_nodes && n_links && (n == 0 || seeds), PNR_E_ARG, "null argument");
     PNR_REQUIRE(c->d_img, PNR_E_STATE, "no volume set");
     PNR_HIP(hipSetDevice(c->device));
     const int ni = c->prm.ni;
     PNR_REQUIRE(c->prm.somaradius == 0 || c->have_soma, PNR_E_STATE, "somaradius > 0: call pnr_soma first");
+    c->have_graph = false;
     pnr::Replayer r(c->prm, c->w, c->h, c->l);
     r.set_soma(&c->soma_map, c->soma_nodes);
     int rc = pnr_density_reset(c);
     if (rc) return rc;
     int64_t iters = 0;
     // phased driver: a window of trace slots refilled as traces stop (smc_phased.hip); `first_batch` has no meaning there
-    const bool streaming = c->smc_driver == 0 && !getenv("PNR_REPLAY_BATCHES");
+    const bool streaming = c->smc_driver == 0 && !c->opt.replay_batches;
+    PNR_REQUIRE(streaming || sh.world <= 1, PNR_E_STATE, "sharded tracing needs the phased driver with the streaming scheduler");
     if (streaming) {
-        rc = pnr_trace_replay_stream(c, seeds, n, r, &iters);
+        rc = pnr_trace_replay_stream(c, seeds, n, r, sh, &iters);
         if (rc) return rc;
         n = 0; // nothing left for the batch loop below
     }
@@ -500,8 +557,8 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
     // have.  (Several batches in flight on separate streams were slower: they must be collected in rank order, so the in-flight
     // count collapses behind every slow batch, and a staler map costs iterations.)
     int64_t batch = first_batch > 0 ? first_batch : 128;
-    const int64_t growth_pct = getenv("PNR_BATCH_GROWTH") ? std::max(100, atoi(getenv("PNR_BATCH_GROWTH"))) : 200;
-    const int64_t batch_max = getenv("PNR_BATCH_MAX") ? std::max(1, atoi(getenv("PNR_BATCH_MAX"))) : 1024;
+    const int64_t growth_pct = std::max(100, c->opt.batch_growth);
+    const int64_t batch_max = std::max(1, c->opt.batch_max);
     std::vector<pnr_seed> bs;
     std::vector<int32_t> T, stop;
     std::vector<pnr_xest> xc;
@@ -525,7 +582,7 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
             bmax = std::max(bmax, e);
         }
         iters += bi;
-        if (getenv("PNR_TRACE_TIMING"))
+        if (c->opt.trace_timing)
             fprintf(stderr, "[pnr trace] batch of %lld seeds launched: %lld iterations, longest trace %lld, nodes so far %zu\n", (long long)m,
                     (long long)bi, (long long)bmax, r.nodes.size());
         r.touched.clear();
@@ -533,13 +590,172 @@ int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first
         rc = pnr_density_update(c, r);
         if (rc) return rc;
     }
+    if (n_iterations) *n_iterations = iters;
+    return store_graph(c, r, nodes, cap_nodes, n_nodes, links, cap_links, n_links, n_traces_used);
+}
+
+// Trace + replay with early DENSITY stops (the production form of the trace loop, Advantra_plugin.cpp:2658-2710).
+// Tracing every seed to its map-free end wastes most GPU iterations: in the reference a trace stops as
+// soon as it runs into voxels that earlier traces already filled (DENSITY stop, tracker.cpp:855,870-882),
+// and a seed on a filled voxel is never traced (:2669-2670).  The density map produced by the replay of
+// lower-ranked seeds is kept on the GPU; the kernel ends a trace at the first iteration whose centroid
+// voxel is already saturated in that (stale) map.  A stale map only under-counts, so a trace is never cut
+// earlier than the sequential reference would cut it, and the replay -- which applies the true map --
+// produces exactly the same nodes and links as the one-shot form.
+int pnr_trace_replay(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first_batch, pnr_node *nodes, int64_t cap_nodes,
+                     int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used,
+                     int64_t *n_iterations)
+{
+    return trace_replay_impl(c, seeds, n, first_batch, pnr::ShardSpec{}, nodes, cap_nodes, n_nodes, links, cap_links, n_links, n_traces_used, n_iterations);
+}
+
+int pnr_trace_replay_sharded(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int rank, int world, pnr_allgather_fn exchange, void *user,
+                             pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links,
+                             int64_t *n_traces_used, int64_t *n_iterations)
+{
+    PNR_REQUIRE(c, PNR_E_ARG, "null ctx");
+    PNR_REQUIRE(world >= 1 && rank >= 0 && rank < world, PNR_E_ARG, "rank %d outside a world of %d", rank, world);
+    PNR_REQUIRE(world == 1 || exchange, PNR_E_ARG, "sharded tracing needs an exchange callback");
+    pnr::ShardSpec sh;
+    sh.rank = rank; sh.world = world; sh.exchange = exchange; sh.user = user; sh.block_bytes = c->opt.exchange_block;
+    return trace_replay_impl(c, seeds, n, 0, sh, nodes, cap_nodes, n_nodes, links, cap_links, n_links, n_traces_used, n_iterations);
+}
+
+// ---- the scheduler of pnr_trace_replay[_sharded] over a HOST engine that plays map-free traces (no GPU involved) -----------
+namespace {
+struct PlaybackEngine final : pnr::StreamEngine {
+    struct Slot { bool used = false, done = false; int it = 0, T = 0, Tfree = 0; std::vector<pnr_xest> xc; };
+    const pnr_params &prm;
+    int64_t W, H;
+    int ni, nslots;
+    pnr_trace_fn fn;
+    void *user;
+    std::vector<Slot> sl;
+    std::vector<std::vector<int>> active; // per group
+    std::unordered_map<int64_t, uint8_t> den;
+    std::string msg;
+    int64_t steps = 0;
+    PlaybackEngine(const pnr_params &p, int64_t w, int64_t h, int window, pnr_trace_fn f, void *u)
+        : prm(p), W(w), H(h), ni(p.ni), nslots(window), fn(f), user(u), sl((size_t)window), active(4) {}
+    const char *error() const override { return msg.c_str(); }
+    int slots() const override { return nslots; }
+    int max_groups() const override { return 4; }
+    int admit(int g, const int *slots, const float *s6, int m) override
+    {
+        for (int j = 0; j < m; j++) {
+            Slot &s = sl[(size_t)slots[j]];
+            s = Slot();
+            s.used = true;
+            s.xc.assign((size_t)ni, pnr_xest{});
+            int32_t T = 0;
+            const int rc = fn(user, s6 + (size_t)j * 6, &T, s.xc.data());
+            if (rc) { msg = "trace callback failed"; return PNR_E_STATE; }
+            s.Tfree = T;
+            active[(size_t)g].push_back(slots[j]);
+        }
+        return PNR_OK;
+    }
+    int launch(int g, int, int poll) override
+    {
+        // what ph_update does with a trace, on the recorded map-free result: iteration `it` fails (T = it), or succeeds and its
+        // centroid voxel is saturated in the replayed map (DENSITY stop, T = it + 1), or the trace goes on
+        for (int k = 0; k < poll; k++) {
+            std::vector<int> keep;
+            for (int slot : active[(size_t)g]) {
+                Slot &s = sl[(size_t)slot];
+                if (s.it >= s.Tfree || s.it >= ni) { s.T = s.Tfree; s.done = true; continue; }
+                const pnr_xest &e = s.xc[(size_t)s.it];
+                const int64_t v = (int64_t)(int)std::round(e.z) * W * H + (int64_t)(int)std::round(e.y) * W + (int)std::round(e.x);
+                auto f = den.find(v);
+                s.it++;
+                if (f != den.end() && (int)f->second >= prm.nodepervol) { s.T = s.it; s.done = true; continue; }
+                keep.push_back(slot);
+            }
+            active[(size_t)g].swap(keep);
+            steps++;
+        }
+        return PNR_OK;
+    }
+    int wait(int g, int *act) override { *act = (int)active[(size_t)g].size(); return PNR_OK; }
+    bool finished(int, int slot, int *T) const override { *T = sl[(size_t)slot].T; return sl[(size_t)slot].done; }
+    const pnr_xest *rows(int slot) const override { return sl[(size_t)slot].xc.data(); }
+    int density_update(const pnr::Replayer &r, bool) override
+    {
+        for (int64_t v : r.touched) den[v] = (uint8_t)r.den_at(v);
+        return PNR_OK;
+    }
+    void drain() override {}
+};
+} // namespace
+
+int pnr_sched_playback(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n, int rank, int world,
+                       pnr_allgather_fn exchange, void *xuser, int64_t block_bytes, pnr_trace_fn trace, void *tuser, int window, int groups,
+                       int poll, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links,
+                       int64_t *n_traces_used, int64_t *n_iterations)
+{
+    PNR_REQUIRE(p && trace && n_nodes && n_links && (n == 0 || seeds), PNR_E_ARG, "null argument");
+    PNR_REQUIRE(w > 0 && h > 0 && l > 0, PNR_E_ARG, "bad dimensions");
+    PNR_REQUIRE(world >= 1 && rank >= 0 && rank < world && (world == 1 || exchange), PNR_E_ARG, "bad rank / world / exchange");
+    pnr::Replayer r(*p, w, h, l);
+    window = std::max(2, window) & ~1;
+    PlaybackEngine eng(*p, w, h, window, trace, tuser);
+    pnr::SchedOptions o;
+    o.window = window; o.groups = std::max(1, groups); o.poll = std::max(1, poll);
+    pnr::ShardSpec sh;
+    sh.rank = rank; sh.world = world; sh.exchange = exchange; sh.user = xuser; sh.block_bytes = block_bytes;
+    pnr::SchedStats st;
+    std::string err;
+    const int rc = pnr::run_stream(eng, seeds, n, p->ni, o, sh, r, &st, err);
+    if (rc) { set_error("%s", err.c_str()); return rc; }
     *n_nodes = (int64_t)r.nodes.size();
     *n_links = (int64_t)r.links.size() / 2;
     if (nodes) std::memcpy(nodes, r.nodes.data(), sizeof(pnr_node) * (size_t)std::min<int64_t>(cap_nodes, *n_nodes));
     if (links) std::memcpy(links, r.links.data(), 8 * (size_t)std::min<int64_t>(cap_links, *n_links));
     if (n_traces_used) *n_traces_used = r.trace_count;
-    if (n_iterations) *n_iterations = iters;
+    if (n_iterations) *n_iterations = st.iters;
     return PNR_OK;
+}
+
+// ---- options ----------------------------------------------------------------------------
+namespace {
+struct OptEntry { const char *key; int pnr::Options::*i32; int64_t pnr::Options::*i64; int64_t lo, hi; };
+const OptEntry OPTS[] = {
+    {"window", &pnr::Options::window, nullptr, 2, 1 << 20},      {"look0", &pnr::Options::look0, nullptr, 0, 1 << 24},
+    {"look_pct", &pnr::Options::look_pct, nullptr, -1, 100000},   {"poll", &pnr::Options::poll, nullptr, 1, 1024},
+    {"groups", &pnr::Options::groups, nullptr, 1, 4},            {"split_x10", &pnr::Options::split_x10, nullptr, 1, 10000},
+    {"max_split", &pnr::Options::max_split, nullptr, 1, 4096},   {"stash_mb", nullptr, &pnr::Options::stash_mb, 1, 1 << 20},
+    {"host_threads", &pnr::Options::host_threads, nullptr, 0, 1024}, {"local_ranks", &pnr::Options::local_ranks, nullptr, 1, 1024},
+    {"trace_timing", &pnr::Options::trace_timing, nullptr, 0, 1}, {"seed_timing", &pnr::Options::seed_timing, nullptr, 0, 1},
+    {"replay_batches", &pnr::Options::replay_batches, nullptr, 0, 1}, {"batch_growth", &pnr::Options::batch_growth, nullptr, 100, 100000},
+    {"batch_max", &pnr::Options::batch_max, nullptr, 1, 1 << 24}, {"no_stash", &pnr::Options::no_stash, nullptr, 0, 1},
+    {"exchange_block", nullptr, &pnr::Options::exchange_block, 1024, 1 << 28},
+};
+} // namespace
+
+int pnr_set_option(pnr_ctx *c, const char *key, int64_t value)
+{
+    PNR_REQUIRE(c && key, PNR_E_ARG, "null argument");
+    for (const OptEntry &e : OPTS)
+        if (std::strcmp(e.key, key) == 0) {
+            PNR_REQUIRE(value >= e.lo && value <= e.hi, PNR_E_ARG, "option %s = %lld outside [%lld, %lld]", key, (long long)value, (long long)e.lo, (long long)e.hi);
+            if (e.i32) c->opt.*(e.i32) = (int)value; else c->opt.*(e.i64) = value;
+            return PNR_OK;
+        }
+    set_error("unknown option '%s'", key);
+    return PNR_E_ARG;
+}
+
+int pnr_get_option(pnr_ctx *c, const char *key, int64_t *value)
+{
+    PNR_REQUIRE(c && key && value, PNR_E_ARG, "null argument");
+    if (std::strcmp(key, "host_threads_effective") == 0) { *value = pnr::host_threads(c->opt); return PNR_OK; }
+    for (const OptEntry &e : OPTS)
+        if (std::strcmp(e.key, key) == 0) {
+            *value = e.i32 ? (int64_t)(c->opt.*(e.i32)) : c->opt.*(e.i64);
+            return PNR_OK;
+        }
+    set_error("unknown option '%s'", key);
+    return PNR_E_ARG;
 }
 
 int pnr_reconstruct(const pnr_node *nodes, int64_t n_nodes, const int32_t *links, int64_t n_links, float trace_rsmpl,
@@ -555,6 +771,7 @@ int pnr_reconstruct(const pnr_node *nodes, int64_t n_nodes, const int32_t *links
     if (epsilon2 > 0) rp.epsilon2 = epsilon2;
     if (group_radius > 0) rp.group_radius = group_radius;
     if (tree_size_min > 0) rp.tree_size_min = tree_size_min;
+    rp.threads = pnr::host_threads(pnr::Options()); // rank 0 post-processes alone: every CPU this process may use
     std::vector<pnr_node> in(nodes, nodes + n_nodes), out;
     std::vector<int32_t> lk(links, links + 2 * n_links), par;
     advantra::reconstruct(in, lk, rp, out, par);

@@ -54,6 +54,25 @@ void build_tables(const pnr_params &p, bool is2d, Tables &t);
 void glibc_rand_stream(uint32_t seed, int n, uint32_t *out);
 int gaussian_taps(float sig, std::vector<float> &g); // returns radius L
 
+// scheduler / host-side knobs of one context (pnr_set_option); none of them changes a result
+struct Options {
+    int window = 768;         // trace slots the streaming tracer keeps busy
+    int look0 = 0, look_pct = -1; // admission lookahead max(look0, frontier * look_pct / 100); 0 / -1 = automatic (stream_sched.h)
+    int poll = 4;             // SMC steps between two polls
+    int groups = 1;           // trace groups on separate streams
+    int split_x10 = 40;       // sampling work-groups per CU x 10
+    int max_split = 24;       // ... and at most this many per trace
+    int64_t stash_mb = 65536; // sample-stash budget
+    int host_threads = 0;     // host worker threads of the seed flood fill / reconstruct(); 0 = hardware threads / local_ranks
+    int local_ranks = 1;      // processes that share this host (one per GPU)
+    int trace_timing = 0, seed_timing = 0; // statistics on stderr
+    int replay_batches = 0;   // 1: seed-rank batches instead of the streaming window (always so with the persistent driver)
+    int batch_growth = 200, batch_max = 1024;
+    int no_stash = 0;         // persistent driver: in-lane two-pass sums
+    int64_t exchange_block = 65536; // bytes per rank and exchange of the sharded tracer
+};
+int host_threads(const Options &o); // worker threads to use on this host
+
 struct KernelTimer {
     double ms = 0;
     int64_t launches = 0;
@@ -63,6 +82,7 @@ struct KernelTimer {
 
 struct pnr_ctx {
     pnr_params prm;
+    pnr::Options opt;
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     pnr::Tables tab;
@@ -71,6 +91,7 @@ struct pnr_ctx {
     int64_t w = 0, h = 0, l = 0, N = 0;
     const uint8_t *d_img = nullptr; // device
     uint8_t *d_img_owned = nullptr;
+    size_t img_owned_cap = 0;
 
     // Frangi state (HBM)
     float *d_tmpA = nullptr, *d_tmpB = nullptr, *d_J = nullptr;
@@ -118,6 +139,12 @@ struct pnr_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t j8_ev[J8_CHUNKS] = {}, j8_start = nullptr;
     std::vector<pnr_seed> seeds;
+
+    // node graph of the last pnr_trace_replay[_sharded] (pnr_get_graph)
+    std::vector<pnr_node> graph_nodes;
+    std::vector<int32_t> graph_links;
+    int graph_traces = 0;
+    bool have_graph = false;
 
     // profiling: HIP event pairs recorded on the ctx stream around each kernel group, resolved
     // lazily (no host sync inside the timed region)
@@ -186,7 +213,7 @@ int pnr_gauss_x_u8_launch(pnr_ctx *c, const uint8_t *src, float *dst, const floa
 int pnr_zncc_run(pnr_ctx *c, const float *h_pos_dir, int64_t n, float *h_corr, float *h_sig);
 int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T, int32_t *stop, pnr_xest *xc,
                   int dbg_iters, float *xfilt, int32_t *idxres, float *neff, int use_density);
-namespace pnr { struct Replayer; }
+namespace pnr { struct Replayer; struct ShardSpec; }
 struct pnr_trace_job;
 pnr_trace_job *pnr_job_create(pnr_ctx *c, bool own_stream);
 void pnr_job_destroy(pnr_trace_job *j);
@@ -197,7 +224,7 @@ struct pnr_phased;
 int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T, int32_t *stop, pnr_xest *xc, int dbg_iters,
                          float *xfilt, int32_t *idxres, float *neff, int use_density);
 void pnr_phased_destroy(pnr_phased *h);
-int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::Replayer &r, int64_t *iters);
+int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::Replayer &r, const pnr::ShardSpec &sh, int64_t *iters);
 int pnr_density_reset(pnr_ctx *c);                       // zero the device density map (allocating it on first use)
 int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, hipStream_t on = nullptr); // push the voxels touched since Replayer::touched was cleared
 int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y);

@@ -213,7 +213,7 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     PNR_REQUIRE(c->have_j8, PNR_E_STATE, "pnr_extract_seeds: run pnr_frangi (or pnr_set_j8_v) first");
     PNR_REQUIRE(z0 >= 0 && z1 <= c->l && z0 <= z1, PNR_E_ARG, "layer range [%lld,%lld) outside [0,%lld)", (long long)z0, (long long)z1, (long long)c->l);
     c->seeds.clear();
-    const bool timing = getenv("PNR_SEED_TIMING") != nullptr;
+    const bool timing = c->opt.seed_timing != 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     const int w = (int)c->w, h = (int)c->h;
@@ -298,9 +298,7 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     // host: per-layer flood-fill on a thread pool; results kept per layer to preserve z-major order
     std::vector<std::vector<int>> acc(nl);
     {
-        unsigned nt = std::thread::hardware_concurrency();
-        if (nt == 0) nt = 4;
-        if (nt > 16) nt = 16; // the GPU box gives one GPU a share of 16 host threads
+        unsigned nt = (unsigned)pnr::host_threads(c->opt); // this process's share of the host's CPUs (options host_threads / local_ranks)
         if ((int)nt > nl) nt = nl;
         std::atomic<int> next(0);
         const float tol = (float)(double)c->prm.tolerance;
@@ -357,6 +355,6 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     hipFree(d_min); hipFree(d_max); hipFree(d_cnt); hipFree(d_vf); hipFree(d_off); hipFree(d_keys);
     if (timing)
         fprintf(stderr, "[pnr seeds] kernels + keys %.1f ms (J8 download overlapped), host fill %.1f ms (%u threads, %lld candidates), dirs+free %.1f ms\n",
-                1e3 * (t_gpu - t_start), 1e3 * (t_fill - t_gpu), std::thread::hardware_concurrency(), (long long)total, 1e3 * (now() - t_fill));
+                1e3 * (t_gpu - t_start), 1e3 * (t_fill - t_gpu), (unsigned)pnr::host_threads(c->opt), (long long)total, 1e3 * (now() - t_fill));
     return PNR_OK;
 }

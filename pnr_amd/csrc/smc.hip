@@ -571,11 +571,12 @@ int pnr_job_launch(pnr_ctx *c, pnr_trace_job *j, const pnr_seed *seeds, int64_t 
         const int nslots = prop.multiProcessorCount + 64;
         const long long wave_floats = (long long)Mmax * 64, slot_floats = wave_floats * S * (np_pad / 64);
         const size_t need = (size_t)nslots * slot_floats * 4;
-        if (c->stash_bytes < need || c->stash_slots != nslots) {
+        const bool want_stash = !c->opt.no_stash; // option "no_stash": the in-lane two-pass form
+        if ((want_stash && (c->stash_bytes < need || c->stash_slots != nslots)) || (!want_stash && c->d_stash)) {
             PNR_HIP(hipDeviceSynchronize()); // no trace kernel may still hold a slot
             hipFree(c->d_stash); hipFree(c->d_slot_busy);
             c->d_stash = nullptr; c->d_slot_busy = nullptr; c->stash_bytes = 0;
-            if (!getenv("PNR_NO_STASH") && hipMalloc(&c->d_stash, need) == hipSuccess && hipMalloc(&c->d_slot_busy, nslots * 4) == hipSuccess) {
+            if (want_stash && hipMalloc(&c->d_stash, need) == hipSuccess && hipMalloc(&c->d_slot_busy, nslots * 4) == hipSuccess) {
                 c->stash_bytes = need;
                 c->stash_slots = nslots;
                 // flags are cleared once: every work-group releases its slot, also with several launches in flight

@@ -15,6 +15,7 @@
 // order, bit-identical traces (tests run both drivers against the oracle and against each other).
 #include "ctx.h"
 #include "replay.h"
+#include "stream_sched.h"
 #include "smc_device.h"
 #include <algorithm>
 #include <cstdlib>
@@ -540,6 +541,7 @@ struct pnr_phased {
     pnr_xest *h_xc = nullptr; int *h_flags = nullptr; int *h_new = nullptr; float *h_new_s6 = nullptr;
     int *d_new = nullptr; float *d_new_s6 = nullptr;
     int64_t stream_cap = 0;
+    int stream_ni = 0;
     static constexpr int MAXG = 4;
     hipStream_t stg[MAXG] = {}, st_den = nullptr; // [1..]: the further trace groups of the streaming tracer; density uploads
     hipEvent_t ev_start = nullptr;
@@ -578,9 +580,8 @@ void pnr_phased_destroy(pnr_phased *h)
 // Work-groups per trace for the sampling launch.  One work-group per CU is resident (the cube fills the LDS); all
 // work-groups of a trace pull items from its counter, so what matters is that there are a few times more work-groups
 // than CUs (the dispatcher keeps every CU busy until the items run out) without paying the cube staging too often.
-static int pick_nsplit(int active, int ncu, int max_split)
+static int pick_nsplit(int active, int ncu, int max_split, int x10 /* work-groups per CU x 10 */)
 {
-    static const int x10 = getenv("PNR_SPLIT_X10") ? std::max(1, atoi(getenv("PNR_SPLIT_X10"))) : 40; // work-groups per CU x 10
     int ns = (int)(((long long)x10 * ncu / 10 + active - 1) / active);
     return ns < 1 ? 1 : (ns > max_split ? max_split : ns);
 }
@@ -595,7 +596,7 @@ struct PhEnv {
 };
 
 // device state for up to `want` concurrent traces (fewer if their sample stash exceeds the budget: PNR_STASH_GB,
-// default 64 GB or half of the free HBM) and everything the four kernels take as arguments
+// default 64 GB, or half of the free HBM) and everything the four kernels take as arguments
 static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool idxres, bool neff, PhEnv &E)
 {
     int rc = make_vol(c, E.V);
@@ -622,9 +623,7 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     const long long Mtot = E.T.Mtot, trace_floats = Mtot * W;
     size_t free_b = 0, total_b = 0;
     PNR_HIP(hipMemGetInfo(&free_b, &total_b));
-    size_t budget = (size_t)64 << 30;
-    if (const char *e = getenv("PNR_STASH_GB")) budget = (size_t)std::max(1, atoi(e)) << 30;
-    if (const char *e = getenv("PNR_STASH_MB")) budget = (size_t)std::max(1, atoi(e)) << 20; // tests: force several waves / a narrow window
+    size_t budget = (size_t)std::max<int64_t>(1, c->opt.stash_mb) << 20; // option "stash_mb" (tests: force several waves / a narrow window)
     const size_t have = (size_t)h->cap_traces * (size_t)h->trace_floats * 4; // our own stash counts as free
     budget = std::min(budget, (free_b + have) / 2);
     const int64_t nt_max = (int64_t)(budget / ((size_t)trace_floats * 4));
@@ -679,8 +678,7 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     E.trace_floats = trace_floats;
     E.NT = NT;
     E.h = h;
-    E.max_split = 24;
-    if (const char *e = getenv("PNR_MAX_SPLIT")) E.max_split = std::max(1, atoi(e));
+    E.max_split = std::max(1, c->opt.max_split);
     PNR_REQUIRE(E.upd_lds <= 160 * 1024, PNR_E_ARG, "np=%d with %d scales needs %zu B of LDS in the update step (limit 160 KB)", np, S, E.upd_lds);
     PNR_HIP(hipFuncSetAttribute((const void *)ph_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.upd_lds));
     PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
@@ -742,7 +740,7 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
                 active = h->h_cnt[(it - LAG) % RING];
                 if (active <= 0) break;
             }
-            const int nsplit = pick_nsplit(active, ncu, max_split);
+            const int nsplit = pick_nsplit(active, ncu, max_split, c->opt.split_x10);
             c->tic(st);
             hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, T, X, P, (const float *)h->d_s6, V, np, ni, it, it & 1, CS);
             c->toc("smc_predict", 1, st);
@@ -775,222 +773,182 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Streaming trace + replay (the production form of the trace loop, Advantra_plugin.cpp:2658-2710).
+// Streaming trace + replay (the production form of the trace loop, Advantra_plugin.cpp:2658-2710): the scheduler is
+// stream_sched.h (host logic, shared with the sharded multi-GPU form); this is its engine -- a window of trace slots stepped
+// by the four phase kernels above, every trace at its own iteration, the per-iteration records written straight into pinned
+// host memory by ph_update.
 //
-// A window of trace slots is kept full: every few SMC steps the host collects the traces that have stopped, replays --
-// strictly in seed order, as far as the finished traces reach -- the bookkeeping of Tracker::trackPos (replay.h), pushes
-// the voxels that replay filled to the density map on the GPU, and hands the free slots to the next seeds (a seed on a
-// voxel the replayed map already saturates is never traced, :2669-2670).  The kernels end a trace at the first
-// iteration whose centroid voxel is saturated in that map (DENSITY stop, tracker.cpp:855).  The map on the GPU only
-// holds replayed -- final -- nodes of lower-ranked seeds, so it can only under-count what the sequential reference
-// would see: no trace is cut earlier than the reference cuts it, and the replay, which applies the true map, yields
-// exactly the node graph of tracing everything to its map-free end (tests: equal to the one-shot graph).
-// Compared with rank batches there is no batch tail during which most CUs idle, and later seeds see a fresher map.
+// The window can be shared by G groups of traces (option "groups", 1..4) that step independently, each on its own stream with
+// its own active list: while the host collects, replays and refills one group, the other groups' steps keep the GPU busy, and
+// launches with few traces (a chain's ordered sums take 0.25 ms however few there are) overlap.  Results do not depend on the
+// grouping: a trace is a function of its seed and of the replayed map.  Two groups take 4 % off the bench step; the default
+// stays one group, whose launches do not overlap, so that a kernel's duration -- HIP events or rocprofv3 -- is the time that
+// kernel needs and the roofline figures built on it mean what they say.
 // ---------------------------------------------------------------------------------------------------------
-int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::Replayer &r, int64_t *iters_out)
-{
-    if (iters_out) *iters_out = 0;
-    if (n == 0) return PNR_OK;
-    int64_t window = 768;
-    if (const char *e = getenv("PNR_WINDOW")) window = std::max(2, atoi(e));
-    window = std::min<int64_t>(window, 2 * n);
-    window += window & 1;
-    // seeds are admitted at most this far beyond the replay frontier (a trace only sees the map of replayed seeds)
-    int64_t look0 = 128, look_pct = 50;
-    if (const char *e = getenv("PNR_LOOK0")) look0 = std::max(1, atoi(e));
-    if (const char *e = getenv("PNR_LOOK_PCT")) look_pct = std::max(0, atoi(e));
-    int poll = 4;
-    if (const char *e = getenv("PNR_POLL")) poll = std::max(1, atoi(e));
+namespace {
+
+struct PhasedEngine final : pnr::StreamEngine {
+    pnr_ctx *c;
     PhEnv E;
-    int rc = phased_env(c, window, 0, false, false, false, E);
-    if (rc) return rc;
-    pnr_phased *h = E.h;
-    const int NT = (int)(E.NT - (E.NT & 1)); // slots come in pairs (the two directions of a seed)
-    PNR_REQUIRE(NT >= 2, PNR_E_HIP, "not enough device memory for two trace slots");
-    const int np = E.np, ni = E.ni, S = E.S, np_pad = E.np_pad, ng = E.ng;
-    if (h->stream_cap < NT || h->ni != ni) {
-        PNR_HIP(hipDeviceSynchronize());
-        if (h->h_xc) hipHostFree(h->h_xc);
-        if (h->h_flags) hipHostFree(h->h_flags);
-        if (h->h_new) hipHostFree(h->h_new);
-        if (h->h_new_s6) hipHostFree(h->h_new_s6);
-        hipFree(h->d_new); hipFree(h->d_new_s6);
-        h->h_xc = nullptr; h->h_flags = nullptr; h->h_new = nullptr; h->h_new_s6 = nullptr; h->d_new = nullptr; h->d_new_s6 = nullptr;
-        h->stream_cap = 0;
-        PNR_HIP(hipHostMalloc(&h->h_xc, (size_t)NT * ni * sizeof(pnr_xest)));
-        constexpr int MG = pnr_phased::MAXG; // one set per trace group
-        PNR_HIP(hipHostMalloc(&h->h_flags, (size_t)NT * FL_N * 4 * MG));
-        PNR_HIP(hipHostMalloc(&h->h_new, (size_t)NT * 4 * MG));
-        PNR_HIP(hipHostMalloc(&h->h_new_s6, (size_t)NT * 24 * MG));
-        PNR_HIP(hipMalloc(&h->d_new, (size_t)NT * 4 * MG));
-        PNR_HIP(hipMalloc(&h->d_new_s6, (size_t)NT * 24 * MG));
-        h->stream_cap = NT;
-    }
-    TraceOut O = h->O;
-    O.xc = (float *)h->h_xc; // the per-iteration records go straight to pinned host memory (32 B per trace and iteration)
-    O.dbg_iters = 0; O.xfilt = nullptr; O.idxres = nullptr; O.neff = nullptr;
-    // The window can be shared by G groups of traces (PNR_GROUPS, 1..4) that step independently, each on its own stream with
-    // its own active list: while the host collects, replays and refills one group, the other groups' steps keep the GPU busy,
-    // and launches with few traces (a chain's ordered sums take 0.25 ms however few there are) overlap.  Results do not depend
-    // on the grouping: a trace is a function of its seed and of the replayed map (see above).  Two groups take 4 % off the
-    // bench step; the default stays one group, whose launches do not overlap, so that a kernel's duration -- HIP events or
-    // rocprofv3 -- is the time that kernel needs and the roofline figures built on it mean what they say.
-    int G = 1;
-    if (const char *e = getenv("PNR_GROUPS")) G = std::min(std::max(1, atoi(e)), (int)pnr_phased::MAXG);
-    if (NT < 4 * G) G = 1;
+    pnr_phased *h = nullptr;
+    int NT = 0;
+    TraceOut O{};
     struct Grp {
-        PhState P; hipStream_t st; int lp = 0, active = 0; bool inflight = false; std::vector<int> busy;
+        PhState P; hipStream_t st; int lp = 0;
         int *h_flags, *h_cnt, *h_new, *d_new; float *h_new_s6, *d_new_s6;
     };
     Grp grp[pnr_phased::MAXG];
-    PNR_HIP(hipMemsetAsync(E.P.cnt, 0, 2 * 4 * pnr_phased::MAXG, c->stream));
-    PNR_HIP(hipEventRecord(h->ev_start, c->stream)); // everything queued so far (volume, density map) precedes the other streams
-    for (int g = 1; g < pnr_phased::MAXG; g++) PNR_HIP(hipStreamWaitEvent(h->stg[g], h->ev_start, 0));
-    PNR_HIP(hipStreamWaitEvent(h->st_den, h->ev_start, 0));
-    for (int g = 0; g < pnr_phased::MAXG; g++) {
-        Grp &q = grp[g];
-        q.P = E.P;
-        q.P.list = E.P.list + (size_t)g * 2 * E.P.cap;
-        q.P.cnt = E.P.cnt + 2 * g;
-        q.st = g == 0 ? c->stream : h->stg[g];
-        q.h_flags = h->h_flags + (size_t)g * NT * FL_N; q.h_cnt = h->h_cnt + g;
-        q.h_new = h->h_new + (size_t)g * NT; q.d_new = h->d_new + (size_t)g * NT;
-        q.h_new_s6 = h->h_new_s6 + (size_t)g * NT * 6; q.d_new_s6 = h->d_new_s6 + (size_t)g * NT * 6;
-    }
+    std::string msg;
 
-    enum : uint8_t { NOT_YET = 0, LAUNCHED = 1, SKIPPED = 2 };
-    struct SeedRec { uint8_t state = NOT_YET; int pending = 0; int32_t T[2] = {0, 0}; std::vector<pnr_xest> xc; };
-    std::vector<SeedRec> rec((size_t)n);
-    std::vector<int> free_slots;
-    for (int k = NT - 1; k >= 0; k--) free_slots.push_back(k);
-    std::vector<int64_t> slot_seed((size_t)NT, -1);
-    std::vector<int> slot_dir((size_t)NT, 0);
-    int64_t next = 0, frontier = 0, iters = 0;
-    const bool timing = getenv("PNR_TRACE_TIMING") != nullptr;
-    int64_t steps = 0, polls = 0;
-    int idle_turns = 0;
-    auto drain = [&]() { for (int g = 0; g < pnr_phased::MAXG; g++) (void)hipStreamSynchronize(grp[g].st); (void)hipStreamSynchronize(h->st_den); };
-    for (int g = 0;; g = (g + 1) % G) {
+    explicit PhasedEngine(pnr_ctx *ctx) : c(ctx) {}
+    const char *error() const override { return msg.c_str(); }
+    int hip_fail(hipError_t e, const char *what)
+    {
+        msg = std::string(what) + " failed: " + hipGetErrorString(e);
+        return PNR_E_HIP;
+    }
+#define PE_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_, #call); } while (0)
+
+    int init(int64_t window)
+    {
+        int rc = phased_env(c, window, 0, false, false, false, E);
+        if (rc) { msg = pnr_last_error(); return rc; }
+        h = E.h;
+        NT = (int)(E.NT - (E.NT & 1)); // slots come in pairs (the two directions of a seed)
+        if (NT < 2) { msg = "not enough device memory for two trace slots"; return PNR_E_HIP; }
+        const int ni = E.ni;
+        if (h->stream_cap < NT || h->stream_ni != ni) {
+            PE_HIP(hipDeviceSynchronize());
+            if (h->h_xc) hipHostFree(h->h_xc);
+            if (h->h_flags) hipHostFree(h->h_flags);
+            if (h->h_new) hipHostFree(h->h_new);
+            if (h->h_new_s6) hipHostFree(h->h_new_s6);
+            hipFree(h->d_new); hipFree(h->d_new_s6);
+            h->h_xc = nullptr; h->h_flags = nullptr; h->h_new = nullptr; h->h_new_s6 = nullptr; h->d_new = nullptr; h->d_new_s6 = nullptr;
+            h->stream_cap = 0;
+            PE_HIP(hipHostMalloc(&h->h_xc, (size_t)NT * ni * sizeof(pnr_xest)));
+            constexpr int MG = pnr_phased::MAXG; // one set per trace group
+            PE_HIP(hipHostMalloc(&h->h_flags, (size_t)NT * FL_N * 4 * MG));
+            PE_HIP(hipHostMalloc(&h->h_new, (size_t)NT * 4 * MG));
+            PE_HIP(hipHostMalloc(&h->h_new_s6, (size_t)NT * 24 * MG));
+            PE_HIP(hipMalloc(&h->d_new, (size_t)NT * 4 * MG));
+            PE_HIP(hipMalloc(&h->d_new_s6, (size_t)NT * 24 * MG));
+            h->stream_cap = NT;
+            h->stream_ni = ni;
+        }
+        O = h->O;
+        O.xc = (float *)h->h_xc; // the per-iteration records go straight to pinned host memory (32 B per trace and iteration)
+        O.dbg_iters = 0; O.xfilt = nullptr; O.idxres = nullptr; O.neff = nullptr;
+        PE_HIP(hipMemsetAsync(E.P.cnt, 0, 2 * 4 * pnr_phased::MAXG, c->stream));
+        PE_HIP(hipEventRecord(h->ev_start, c->stream)); // everything queued so far (volume, density map) precedes the other streams
+        for (int g = 1; g < pnr_phased::MAXG; g++) PE_HIP(hipStreamWaitEvent(h->stg[g], h->ev_start, 0));
+        PE_HIP(hipStreamWaitEvent(h->st_den, h->ev_start, 0));
+        for (int g = 0; g < pnr_phased::MAXG; g++) {
+            Grp &q = grp[g];
+            q.P = E.P;
+            q.P.list = E.P.list + (size_t)g * 2 * E.P.cap;
+            q.P.cnt = E.P.cnt + 2 * g;
+            q.st = g == 0 ? c->stream : h->stg[g];
+            q.h_flags = h->h_flags + (size_t)g * h->stream_cap * FL_N; q.h_cnt = h->h_cnt + g;
+            q.h_new = h->h_new + (size_t)g * h->stream_cap; q.d_new = h->d_new + (size_t)g * h->stream_cap;
+            q.h_new_s6 = h->h_new_s6 + (size_t)g * h->stream_cap * 6; q.d_new_s6 = h->d_new_s6 + (size_t)g * h->stream_cap * 6;
+        }
+        return PNR_OK;
+    }
+    int slots() const override { return NT; }
+    int max_groups() const override { return pnr_phased::MAXG; }
+    int admit(int g, const int *slots, const float *s6, int m) override
+    {
+        Grp &q = grp[g];
+        std::memcpy(q.h_new, slots, (size_t)m * 4);     // pinned staging of this group: its previous admission was consumed before
+        std::memcpy(q.h_new_s6, s6, (size_t)m * 24);    // the wait() that precedes every admission
+        PE_HIP(hipMemcpyAsync(q.d_new, q.h_new, (size_t)m * 4, hipMemcpyHostToDevice, q.st));
+        PE_HIP(hipMemcpyAsync(q.d_new_s6, q.h_new_s6, (size_t)m * 24, hipMemcpyHostToDevice, q.st));
+        hipLaunchKernelGGL(ph_admit, dim3(1), dim3(256), 0, q.st, q.P, h->d_s6, (const int *)q.d_new, (const float *)q.d_new_s6, m, q.lp, E.ni);
+        return PNR_OK;
+    }
+    int launch(int g, int active, int poll) override
+    {
         Grp &q = grp[g];
         hipStream_t st = q.st;
-        // ---- the group's last poll: which of its traces have stopped?
-        if (q.inflight) {
-            PNR_HIP(hipStreamSynchronize(st)); // the stream carries this group's work only
-            PNR_HIP(hipGetLastError());
-            q.inflight = false;
-            polls++;
-            q.active = q.h_cnt[0];
-            size_t keep = 0;
-            for (size_t b = 0; b < q.busy.size(); b++) {
-                const int slot = q.busy[b];
-                const int *fl = q.h_flags + (size_t)slot * FL_N;
-                if (!fl[FL_DONE]) { q.busy[keep++] = slot; continue; }
-                SeedRec &sr = rec[(size_t)slot_seed[(size_t)slot]];
-                const int dir = slot_dir[(size_t)slot];
-                const int Tn = fl[FL_T];
-                sr.T[dir] = Tn;
-                const int rows = std::min(Tn, ni);
-                if (rows > 0) std::memcpy(sr.xc.data() + (size_t)dir * ni, h->h_xc + (size_t)slot * ni, (size_t)rows * sizeof(pnr_xest));
-                sr.pending--;
-                iters += std::min(Tn + 1, ni);
-                slot_seed[(size_t)slot] = -1;
-                free_slots.push_back(slot);
-            }
-            q.busy.resize(keep);
+        const PhState &P = q.P;
+        const int np = E.np, ni = E.ni, S = E.S, np_pad = E.np_pad, ng = E.ng;
+        for (int k = 0; k < poll; k++) { // `poll` SMC steps over the group's active list (every trace at its own iteration)
+            const int lp = q.lp;
+            const int nsplit = pick_nsplit(active, E.ncu, E.max_split, c->opt.split_x10);
+            c->tic(st);
+            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
+            c->toc("smc_predict", 1, st);
+            c->tic(st);
+            if (E.V.l == 1)
+                hipLaunchKernelGGL((ph_sample<PH_CS, true>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
+            else
+                hipLaunchKernelGGL((ph_sample<PH_CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
+            c->toc("smc", 1, st);
+            c->tic(st);
+            hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp);
+            c->toc("smc_sums", 1, st);
+            c->tic(st);
+            hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), E.upd_lds, st, E.V, E.T, P, np, np_pad, ni, -1, lp, c->prm.Kc, c->prm.znccth,
+                               c->prm.neff_ratio, c->d_den, c->prm.nodepervol, O);
+            c->toc("smc_update", 1, st);
+            q.lp ^= 1;
         }
-        // ---- replay in seed order as far as the finished traces reach, push the new density to the GPU (its own stream: the
-        // kernels of either group may see a voxel before or after the update -- both are under-counts of the reference's map)
-        r.touched.clear();
-        while (frontier < n && !r.stopped) {
-            SeedRec &sr = rec[(size_t)frontier];
-            if (sr.state == NOT_YET || (sr.state == LAUNCHED && sr.pending > 0)) break;
-            if (sr.state == LAUNCHED) { // (a skipped seed sits on a saturated voxel: the replay would skip it as well)
-                r.add(&seeds[frontier], 1, sr.T, sr.xc.data());
-                std::vector<pnr_xest>().swap(sr.xc);
-            }
-            frontier++;
-        }
-        if (!r.touched.empty()) {
-            rc = pnr_density_update(c, r, G > 1 ? h->st_den : c->stream);
-            if (rc) { drain(); return rc; }
-        }
-        if (r.stopped) break; // MAX_TRACE_COUNT (:2702): whatever is still running is never looked at
-        if (frontier >= n) break;
-        // ---- admission into this group
-        int m = 0, m_max = 2 * NT;
-        if (G > 1) { // keep the groups the same size: this one is filled up to its share of what the window will hold
-            const int64_t room = std::min<int64_t>((int64_t)free_slots.size() / 2, frontier + std::max<int64_t>(look0, frontier * look_pct / 100) - next);
-            int64_t total = 2 * std::max<int64_t>(room, 0);
-            int least = q.active;
-            for (int k = 0; k < G; k++) { total += grp[k].active; least = std::min(least, grp[k].active); }
-            m_max = (int)std::max<int64_t>(0, (total + G - 1) / G - q.active);
-            if (q.active <= least) m_max = std::max(m_max, 2); // the smallest group can always take a seed
-        }
-        while (m + 2 <= m_max && next < n && free_slots.size() >= 2 && next < frontier + std::max<int64_t>(look0, frontier * look_pct / 100)) {
-            const pnr_seed &sd = seeds[next];
-            SeedRec &sr = rec[(size_t)next];
-            if (r.seed_saturated(sd)) { sr.state = SKIPPED; next++; continue; }
-            sr.state = LAUNCHED; sr.pending = 2;
-            sr.xc.resize((size_t)2 * ni);
-            for (int dir = 0; dir < 2; dir++) {
-                const int slot = free_slots.back();
-                free_slots.pop_back();
-                slot_seed[(size_t)slot] = next; slot_dir[(size_t)slot] = dir;
-                q.busy.push_back(slot);
-                q.h_new[m] = slot;
-                float *a = q.h_new_s6 + (size_t)m * 6;
-                a[0] = sd.x; a[1] = sd.y; a[2] = sd.z;
-                a[3] = dir ? -sd.vx : sd.vx; a[4] = dir ? -sd.vy : sd.vy; a[5] = dir ? -sd.vz : sd.vz; // trackNeg (tracker.cpp:819-823)
-                m++;
-            }
-            next++;
-        }
-        if (m > 0) {
-            PNR_HIP(hipMemcpyAsync(q.d_new, q.h_new, (size_t)m * 4, hipMemcpyHostToDevice, st));
-            PNR_HIP(hipMemcpyAsync(q.d_new_s6, q.h_new_s6, (size_t)m * 24, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(ph_admit, dim3(1), dim3(256), 0, st, q.P, h->d_s6, (const int *)q.d_new, (const float *)q.d_new_s6, m, q.lp, ni);
-            q.active += m;
-        }
-        if (q.active > 0) {
-            // ---- `poll` SMC steps over the group's active list (every trace at its own iteration)
-            const PhState &P = q.P;
-            const int active = q.active;
-            for (int k = 0; k < poll; k++) {
-                const int lp = q.lp;
-                const int nsplit = pick_nsplit(active, E.ncu, E.max_split);
-                c->tic(st);
-                hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
-                c->toc("smc_predict", 1, st);
-                c->tic(st);
-                if (E.V.l == 1)
-                    hipLaunchKernelGGL((ph_sample<PH_CS, true>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
-                else
-                    hipLaunchKernelGGL((ph_sample<PH_CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
-                c->toc("smc", 1, st);
-                c->tic(st);
-                hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp);
-                c->toc("smc_sums", 1, st);
-                c->tic(st);
-                hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), E.upd_lds, st, E.V, E.T, P, np, np_pad, ni, -1, lp, c->prm.Kc, c->prm.znccth,
-                                   c->prm.neff_ratio, c->d_den, c->prm.nodepervol, O);
-                c->toc("smc_update", 1, st);
-                q.lp ^= 1;
-                steps++;
-            }
-            PNR_HIP(hipMemcpyAsync(q.h_flags, P.flags, (size_t)NT * FL_N * 4, hipMemcpyDeviceToHost, st));
-            PNR_HIP(hipMemcpyAsync(q.h_cnt, P.cnt + q.lp, 4, hipMemcpyDeviceToHost, st));
-            q.inflight = true;
-        }
-        bool any = false;
-        for (int k = 0; k < G; k++) any = any || grp[k].inflight;
-        idle_turns = (any || m > 0) ? 0 : idle_turns + 1;
-        if (idle_turns > 2 * G) { drain(); PNR_REQUIRE(false, PNR_E_STATE, "trace scheduler stalled at seed %lld of %lld", (long long)frontier, (long long)n); }
+        PE_HIP(hipMemcpyAsync(q.h_flags, P.flags, (size_t)NT * FL_N * 4, hipMemcpyDeviceToHost, st));
+        PE_HIP(hipMemcpyAsync(q.h_cnt, P.cnt + q.lp, 4, hipMemcpyDeviceToHost, st));
+        return PNR_OK;
     }
-    drain(); // the group that is still running is never looked at again, but it writes into buffers that outlive this call
+    int wait(int g, int *active) override
+    {
+        PE_HIP(hipStreamSynchronize(grp[g].st)); // the stream carries this group's work only
+        PE_HIP(hipGetLastError());
+        *active = grp[g].h_cnt[0];
+        return PNR_OK;
+    }
+    bool finished(int g, int slot, int *T) const override
+    {
+        const int *fl = grp[g].h_flags + (size_t)slot * FL_N;
+        *T = fl[FL_T];
+        return fl[FL_DONE] != 0;
+    }
+    const pnr_xest *rows(int slot) const override { return h->h_xc + (size_t)slot * E.ni; }
+    int density_update(const pnr::Replayer &r, bool concurrent) override
+    {
+        // its own stream when groups overlap: the kernels of either group may see a voxel before or after the update -- both are
+        // under-counts of the reference's map
+        const int rc = pnr_density_update(c, r, concurrent ? h->st_den : c->stream);
+        if (rc) msg = pnr_last_error();
+        return rc;
+    }
+    void drain() override
+    {
+        if (!h) return;
+        for (int g = 0; g < pnr_phased::MAXG; g++) (void)hipStreamSynchronize(g == 0 ? c->stream : h->stg[g]);
+        (void)hipStreamSynchronize(h->st_den);
+    }
+#undef PE_HIP
+};
+
+} // namespace
+
+int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::Replayer &r, const pnr::ShardSpec &sh, int64_t *iters_out)
+{
+    if (iters_out) *iters_out = 0;
+    if (n == 0 && sh.world <= 1) return PNR_OK;
+    pnr::SchedOptions o;
+    o.window = c->opt.window; o.look0 = c->opt.look0; o.look_pct = c->opt.look_pct; o.poll = c->opt.poll; o.groups = c->opt.groups;
+    o.timing = c->opt.trace_timing;
+    const int64_t own = sh.world > 1 ? (n - sh.rank + sh.world - 1) / sh.world : n; // seeds of this rank
+    int64_t window = std::min<int64_t>(std::max(2, o.window), std::max<int64_t>(2, 2 * own));
+    window += window & 1;
+    PhasedEngine eng(c);
+    int rc = eng.init(window);
+    if (rc) { pnr::set_error("%s", eng.error()); return rc; }
+    pnr::SchedStats st;
+    std::string err;
+    rc = pnr::run_stream(eng, seeds, n, c->prm.ni, o, sh, r, &st, err);
+    if (rc) { pnr::set_error("%s", err.c_str()); return rc; }
     PNR_HIP(hipGetLastError());
-    if (timing)
-        fprintf(stderr, "[pnr trace] streaming: %lld seeds, window %d slots, %lld steps, %lld polls, %lld iterations, %zu nodes\n", (long long)n, NT,
-                (long long)steps, (long long)polls, (long long)iters, r.nodes.size());
-    if (iters_out) *iters_out = iters;
+    if (iters_out) *iters_out = st.iters;
     return PNR_OK;
 }

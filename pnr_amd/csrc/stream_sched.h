@@ -1,0 +1,310 @@
+// stream_sched.h -- the streaming trace scheduler: the production form of the trace loop of reconstruction_func
+// (Advantra_plugin.cpp:2658-2710) for one GPU or for the sorted seeds sharded over several ranks.  Host-only logic; the
+// particle filters behind it are a StreamEngine (the phased HIP kernels in smc_phased.hip; tests put a host engine that plays
+// recorded map-free traces in their place to exercise this file and the exchange without a GPU).
+//
+// A window of trace slots is kept full.  Every `poll` SMC steps the host collects the traces that have stopped, replays --
+// strictly in seed order, as far as the finished traces reach -- the bookkeeping of Tracker::trackPos (replay.h), pushes the
+// voxels that replay filled into the engine's density map, and hands the free slots to the next seeds (a seed on a voxel the
+// replayed map already saturates is never traced, :2669-2670).  The engine ends a trace at the first iteration whose centroid
+// voxel is saturated in its map (DENSITY stop, tracker.cpp:855).  That map only ever holds replayed -- final -- nodes of
+// lower-ranked seeds, so it can only under-count what the sequential reference would see: no trace is cut earlier than the
+// reference cuts it, and the replay, which applies the true map, yields exactly the node graph of tracing everything to its
+// map-free end.
+//
+// Sharded (world > 1): rank r owns the sorted seeds r, r + world, ...  After every poll the ranks all-gather the records of the
+// traces that finished on them (one fixed-size block per rank and poll; what does not fit is carried to the next poll) and
+// EVERY rank replays the same records in global seed order, so every rank holds the same replayed map -- still only final nodes
+// of lower-ranked seeds, so the argument above carries over -- and ends with the same node graph.  The replay is not sharded:
+// it is order-dependent by definition.  The reference has no counterpart.
+#pragma once
+#include "replay.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace pnr {
+
+struct SchedOptions {
+    int window = 768;  // trace slots kept busy on this rank
+    int look0 = 0;     // seeds admitted at most max(look0, frontier * look_pct / 100) ranks beyond the replay frontier;
+    int look_pct = -1; // look0 = 0 / look_pct < 0: automatic, max(128, 64 * world) / min(400, 50 * world) (scripts/sim_sharded.py)
+    int poll = 4;      // SMC steps between two polls
+    int groups = 1;    // trace groups stepping independently (engine permitting)
+    int timing = 0;    // one line of statistics on stderr
+};
+
+struct ShardSpec {
+    int rank = 0, world = 1;
+    pnr_allgather_fn exchange = nullptr;
+    void *user = nullptr;
+    int64_t block_bytes = 0; // bytes every rank contributes per exchange (0: default)
+};
+
+struct SchedStats {
+    int64_t steps = 0, polls = 0, iters = 0, exchanges = 0, carried = 0, launched = 0, skipped = 0;
+};
+
+class StreamEngine {
+public:
+    virtual ~StreamEngine() {}
+    virtual int slots() const = 0;      // trace slots (even)
+    virtual int max_groups() const = 0; // independent trace groups the engine can step
+    // queue: hand `m` slots to new traces of group g (s6 = m x (x, y, z, vx, vy, vz))
+    virtual int admit(int g, const int *slots, const float *s6, int m) = 0;
+    // queue: `poll` SMC steps over the active traces of group g (at most `active`), then the read-back of the slot states
+    virtual int launch(int g, int active, int poll) = 0;
+    // block until the last launch of group g has landed; *active = traces of the group still running
+    virtual int wait(int g, int *active) = 0;
+    // after wait(g): has the trace in `slot` stopped?  *T = its successful iterations; rows() = its min(T, ni) estimates
+    virtual bool finished(int g, int slot, int *T) const = 0;
+    virtual const pnr_xest *rows(int slot) const = 0;
+    // push the density of the voxels in r.touched (final values r.den_at) to the engine's map
+    virtual int density_update(const Replayer &r, bool concurrent) = 0;
+    virtual void drain() = 0;
+    virtual const char *error() const { return ""; }
+};
+
+namespace sched_detail {
+enum { HDR_WORDS = 4 }; // payload words, busy, abort, reserved
+}
+
+// Returns 0 or a PNR_E_* code (message in `err`).  `r` ends up holding the node graph; *stats the local counters.
+inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni, SchedOptions o, const ShardSpec &sh, Replayer &r,
+                      SchedStats *stats, std::string &err)
+{
+    using namespace sched_detail;
+    SchedStats st;
+    if (stats) *stats = st;
+    if (n == 0) return PNR_OK;
+    const int world = std::max(1, sh.world), rank = sh.rank;
+    if (world > 1 && !sh.exchange) { err = "sharded tracing needs an exchange callback"; return PNR_E_ARG; }
+    if (rank < 0 || rank >= world) { err = "rank out of range"; return PNR_E_ARG; }
+    if (o.look0 <= 0) o.look0 = std::max(128, 64 * world);
+    if (o.look_pct < 0) o.look_pct = std::min(400, 50 * world);
+    o.poll = std::max(1, o.poll);
+    const int NT = E.slots() - (E.slots() & 1);
+    if (NT < 2) { err = "no trace slots"; return PNR_E_STATE; }
+    int G = std::min(std::max(1, o.groups), E.max_groups());
+    if (NT < 4 * G) G = 1;
+    const int64_t look0 = o.look0, look_pct = o.look_pct;
+
+    struct SeedRec {
+        uint8_t have = 0;      // directions whose record has arrived
+        bool skipped = false;  // sits on a saturated voxel: never traced (:2669-2670)
+        int32_t T[2] = {0, 0};
+        std::vector<pnr_xest> xc; // [2][ni], allocated when the first record arrives, dropped after the replay
+    };
+    std::vector<SeedRec> rec((size_t)n);
+    struct Grp { int active = 0; bool inflight = false; std::vector<int> busy; };
+    std::vector<Grp> grp((size_t)G);
+    std::vector<int> free_slots;
+    for (int k = NT - 1; k >= 0; k--) free_slots.push_back(k);
+    std::vector<int64_t> slot_seed((size_t)NT, -1);
+    std::vector<int> slot_dir((size_t)NT, 0);
+    std::vector<int> new_slots;
+    std::vector<float> new_s6;
+    int64_t next = rank, frontier = 0;
+
+    // ---- records: [seed, dir (-1 = skipped), T, rows] + rows x 8 floats, as 32-bit words
+    std::vector<int32_t> outbox; // finished on this rank, not yet applied / sent
+    size_t out_head = 0;
+    const size_t rec_max_words = 4 + (size_t)ni * 8;
+    int64_t block = sh.block_bytes > 0 ? sh.block_bytes : 65536;
+    block = std::max<int64_t>(block, (int64_t)(HDR_WORDS + rec_max_words) * 4);
+    block = (block + 15) / 16 * 16;
+    const size_t block_words = (size_t)block / 4;
+    std::vector<int32_t> sendbuf, recvbuf;
+    if (world > 1) { sendbuf.assign(block_words, 0); recvbuf.assign(block_words * (size_t)world, 0); }
+
+    auto apply = [&](const int32_t *w, size_t nw) -> bool { // one rank's block of whole records
+        size_t k = 0;
+        while (k < nw) {
+            if (k + 4 > nw) return false;
+            const int64_t s = w[k];
+            const int dir = w[k + 1], Tn = w[k + 2], rows = w[k + 3];
+            if (s < 0 || s >= n || rows < 0 || rows > ni || k + 4 + (size_t)rows * 8 > nw) return false;
+            SeedRec &sr = rec[(size_t)s];
+            if (dir < 0) {
+                sr.skipped = true;
+            } else {
+                if (dir > 1 || sr.have >= 2) return false;
+                if (sr.xc.empty()) sr.xc.resize((size_t)2 * ni);
+                sr.T[dir] = Tn;
+                if (rows > 0) std::memcpy(sr.xc.data() + (size_t)dir * ni, w + k + 4, (size_t)rows * sizeof(pnr_xest));
+                sr.have++;
+            }
+            k += 4 + (size_t)rows * 8;
+        }
+        return true;
+    };
+    auto out_record_words = [&](size_t at) { return 4 + (size_t)outbox[at + 3] * 8; };
+
+    int rc = PNR_OK;
+    int idle_turns = 0;
+    bool aborted = false;
+    // one exchange: what fits of the outbox + this rank's busy / abort flags; *busy_all = ranks with traces in flight or records
+    // still to send (the same number on every rank)
+    auto exchange = [&](int busy, int abort_flag, int *busy_all, int *abort_rank) -> int {
+        size_t nw = 0;
+        if (out_head < outbox.size()) busy = 1;
+        if (!abort_flag)
+            while (out_head + nw < outbox.size()) {
+                const size_t rw = out_record_words(out_head + nw);
+                if (HDR_WORDS + nw + rw > block_words) break;
+                nw += rw;
+            }
+        sendbuf[0] = (int32_t)nw; sendbuf[1] = busy; sendbuf[2] = abort_flag; sendbuf[3] = 0;
+        if (nw) std::memcpy(sendbuf.data() + HDR_WORDS, outbox.data() + out_head, nw * 4);
+        out_head += nw;
+        if (out_head < outbox.size()) st.carried++;
+        else { outbox.clear(); out_head = 0; }
+        const int xrc = sh.exchange(sh.user, sendbuf.data(), recvbuf.data(), block);
+        st.exchanges++;
+        if (xrc) { err = "exchange callback failed (" + std::to_string(xrc) + ")"; return PNR_E_STATE; }
+        *busy_all = 0; *abort_rank = -1;
+        for (int q = 0; q < world; q++) {
+            const int32_t *b = recvbuf.data() + (size_t)q * block_words;
+            if (b[2]) { *abort_rank = q; continue; }
+            *busy_all += b[1] ? 1 : 0;
+            if (b[0] < 0 || (size_t)b[0] > block_words - HDR_WORDS || !apply(b + HDR_WORDS, (size_t)b[0])) {
+                err = "malformed trace records from rank " + std::to_string(q);
+                return PNR_E_STATE;
+            }
+        }
+        return PNR_OK;
+    };
+    // a failing rank tells the others in one last exchange, so that nobody is left waiting for it
+    auto fail = [&](int code) -> int {
+        E.drain();
+        if (world > 1 && !aborted) { int b = 0, a = -1; std::string keep = err; (void)exchange(0, 1, &b, &a); err = keep; }
+        return code;
+    };
+
+    for (int g = 0;; g = (g + 1) % G) {
+        Grp &q = grp[(size_t)g];
+        // ---- the group's last poll: which of its traces have stopped?
+        if (q.inflight) {
+            rc = E.wait(g, &q.active);
+            if (rc) { err = E.error(); return fail(rc); }
+            q.inflight = false;
+            st.polls++;
+            size_t keep = 0;
+            for (size_t b = 0; b < q.busy.size(); b++) {
+                const int slot = q.busy[b];
+                int Tn = 0;
+                if (!E.finished(g, slot, &Tn)) { q.busy[keep++] = slot; continue; }
+                const int rows = std::min(std::max(Tn, 0), ni);
+                const size_t at = outbox.size();
+                outbox.resize(at + 4 + (size_t)rows * 8);
+                outbox[at] = (int32_t)slot_seed[(size_t)slot]; outbox[at + 1] = slot_dir[(size_t)slot]; outbox[at + 2] = Tn; outbox[at + 3] = rows;
+                if (rows > 0) std::memcpy(&outbox[at + 4], E.rows(slot), (size_t)rows * sizeof(pnr_xest));
+                st.iters += std::min(Tn + 1, ni);
+                slot_seed[(size_t)slot] = -1;
+                free_slots.push_back(slot);
+            }
+            q.busy.resize(keep);
+        }
+        // ---- the finished records reach the replay: directly, or through the all-gather of every rank's block
+        int busy_all = 0;
+        if (world == 1) {
+            if (!apply(outbox.data(), outbox.size())) { err = "malformed trace record"; return fail(PNR_E_STATE); }
+            outbox.clear();
+        } else {
+            int busy = 0, abort_rank = -1;
+            for (int k = 0; k < G; k++) busy |= (grp[(size_t)k].inflight || grp[(size_t)k].active > 0) ? 1 : 0;
+            rc = exchange(busy, 0, &busy_all, &abort_rank);
+            if (rc) { aborted = true; return fail(rc); }
+            if (abort_rank >= 0) { aborted = true; err = "rank " + std::to_string(abort_rank) + " aborted the sharded trace"; return fail(PNR_E_STATE); }
+        }
+        // ---- replay in seed order as far as the finished traces reach, push the new density to the engine
+        const int64_t frontier_was = frontier;
+        r.touched.clear();
+        while (frontier < n && !r.stopped) {
+            SeedRec &sr = rec[(size_t)frontier];
+            if (!sr.skipped && sr.have < 2) break;
+            if (!sr.skipped) { // (a skipped seed sits on a saturated voxel: the replay would skip it as well)
+                r.add(&seeds[frontier], 1, sr.T, sr.xc.data());
+                std::vector<pnr_xest>().swap(sr.xc);
+            }
+            frontier++;
+        }
+        if (!r.touched.empty()) {
+            rc = E.density_update(r, G > 1);
+            if (rc) { err = E.error(); return fail(rc); }
+        }
+        if (r.stopped) break; // MAX_TRACE_COUNT (:2702): whatever is still running is never looked at
+        if (frontier >= n) break;
+        // ---- admission into this group: this rank's seeds inside the lookahead
+        const int64_t lim = frontier + std::max<int64_t>(look0, frontier * look_pct / 100);
+        int m = 0, m_max = 2 * NT;
+        if (G > 1) { // keep the groups the same size: this one is filled up to its share of what the window will hold
+            const int64_t ahead = next < lim ? (std::min<int64_t>(lim, n) - next + world - 1) / world : 0;
+            const int64_t room = std::min<int64_t>((int64_t)free_slots.size() / 2, ahead);
+            int64_t total = 2 * std::max<int64_t>(room, 0);
+            int least = q.active;
+            for (int k = 0; k < G; k++) { total += grp[(size_t)k].active; least = std::min(least, grp[(size_t)k].active); }
+            m_max = (int)std::max<int64_t>(0, (total + G - 1) / G - q.active);
+            if (q.active <= least) m_max = std::max(m_max, 2); // the smallest group can always take a seed
+        }
+        new_slots.clear(); new_s6.clear();
+        while (m + 2 <= m_max && next < n && free_slots.size() >= 2 && next < lim) {
+            const pnr_seed &sd = seeds[next];
+            if (r.seed_saturated(sd)) {
+                outbox.insert(outbox.end(), {(int32_t)next, -1, 0, 0});
+                st.skipped++;
+                next += world;
+                continue;
+            }
+            for (int dir = 0; dir < 2; dir++) {
+                const int slot = free_slots.back();
+                free_slots.pop_back();
+                slot_seed[(size_t)slot] = next; slot_dir[(size_t)slot] = dir;
+                q.busy.push_back(slot);
+                new_slots.push_back(slot);
+                const float sg = dir ? -1.f : 1.f; // trackNeg starts from the negated seed direction (tracker.cpp:819-823)
+                const float a[6] = {sd.x, sd.y, sd.z, sg * sd.vx, sg * sd.vy, sg * sd.vz};
+                new_s6.insert(new_s6.end(), a, a + 6);
+                m++;
+            }
+            st.launched++;
+            next += world;
+        }
+        if (m > 0) {
+            rc = E.admit(g, new_slots.data(), new_s6.data(), m);
+            if (rc) { err = E.error(); return fail(rc); }
+            q.active += m;
+        }
+        if (q.active > 0) {
+            rc = E.launch(g, q.active, o.poll);
+            if (rc) { err = E.error(); return fail(rc); }
+            st.steps += o.poll;
+            q.inflight = true;
+        }
+        // ---- nothing running anywhere and nothing admitted: the frontier cannot move any more
+        bool any = frontier > frontier_was;
+        if (world > 1) {
+            any = any || busy_all > 0; // only what every rank knows: all ranks count the same idle turns
+        } else {
+            any = any || m > 0 || !outbox.empty();
+            for (int k = 0; k < G; k++) any = any || grp[(size_t)k].inflight;
+        }
+        idle_turns = any ? 0 : idle_turns + 1;
+        if (idle_turns > 2 * G + 2) {
+            E.drain();
+            err = "trace scheduler stalled at seed " + std::to_string((long long)frontier) + " of " + std::to_string((long long)n);
+            return PNR_E_STATE; // every rank sees the same counters and stops in the same turn
+        }
+    }
+    E.drain(); // what is still running is never looked at again, but it writes into buffers that outlive this call
+    if (o.timing)
+        fprintf(stderr, "[pnr trace] rank %d/%d: %lld seeds, window %d slots, lookahead max(%d, %d%%), %lld steps, %lld polls, %lld iterations here, "
+                        "%lld exchanges (%lld carried), %zu nodes\n", rank, world, (long long)n, NT, o.look0, o.look_pct, (long long)st.steps,
+                (long long)st.polls, (long long)st.iters, (long long)st.exchanges, (long long)st.carried, r.nodes.size());
+    if (stats) *stats = st;
+    return PNR_OK;
+}
+
+} // namespace pnr

@@ -4,6 +4,7 @@
 #include <cfloat>
 #include <cmath>
 #include <numeric>
+#include <sched.h>
 #include <thread>
 #include <unordered_map>
 
@@ -89,8 +90,16 @@ struct Grid {
     }
 };
 
+// CPUs this process may run on (affinity mask), at most 32
+unsigned usable_cpus()
+{
+    cpu_set_t set;
+    int n = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+    return (unsigned)std::min(std::max(n, 1), 32);
+}
+
 // :968-1052 -- non-blurring mean-shift of (x,y,z,sig) with a kernel radius SIG2RAD*sig
-void mean_shift(const List &src, List &dst, float SIG2RAD, int MAXITER, float EPS2)
+void mean_shift(const List &src, List &dst, float SIG2RAD, int MAXITER, float EPS2, int threads)
 {
     dst = src;
     float smax = 0;
@@ -131,8 +140,7 @@ void mean_shift(const List &src, List &dst, float SIG2RAD, int MAXITER, float EP
         }
     };
     const size_t n = dst.size();
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
+    unsigned nt = threads > 0 ? (unsigned)threads : usable_cpus();
     if (n < 4096) nt = 1;
     std::vector<std::thread> th;
     const size_t chunk = (n - 1 + nt - 1) / nt;
@@ -309,7 +317,7 @@ void reconstruct(const std::vector<pnr_node> &nodes, const std::vector<int32_t> 
     }
     List n1, n2, forest, kept;
     resample_links(n0, rp.trace_rsmpl);
-    mean_shift(n0, n1, rp.sig2radius, rp.refine_iter, rp.epsilon2);
+    mean_shift(n0, n1, rp.sig2radius, rp.refine_iter, rp.epsilon2, rp.threads);
     group_spheres(n1, n2, rp.group_radius);
     bfs_forest(n2, forest);
     drop_small_trees(forest, kept, rp.tree_size_min);

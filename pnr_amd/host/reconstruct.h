@@ -19,6 +19,7 @@ struct ReconParams {          // Advantra_plugin.cpp:72-83
     float epsilon2 = 0.0001f;  // EPSILON2
     float group_radius = 2.0f; // GROUP_RADIUS
     int tree_size_min = 10;    // TREE_SIZE_MIN
+    int threads = 0;           // host threads of the mean-shift (its nodes are independent); 0 = one per CPU this process may use
 };
 
 // nodes[0] is the dummy; links = pairs (a,b): a.nbr.push_back(b); b.nbr.push_back(a).

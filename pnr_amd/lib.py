@@ -29,6 +29,11 @@ class PnrError(RuntimeError):
     pass
 
 
+# pnr_allgather_fn / pnr_trace_fn (include/pnr_hip.h)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+TRACE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p)
+
+
 def build(force=False):
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     src = os.path.join(HERE, "csrc")
@@ -76,6 +81,8 @@ def load():
     L.pnr_extract_seeds_range.argtypes = [vp, i64, i64, C.POINTER(vp), C.POINTER(i64)]
     L.pnr_zncc_batch.argtypes = [vp, vp, i64, vp, vp]
     L.pnr_score_filter_sort_seeds.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.pnr_score_filter_seeds.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.pnr_sort_seeds.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.pnr_trace_batch.argtypes = [vp, vp, i64, vp, vp, vp, i32, vp, vp, vp]
     L.pnr_replay_traces.argtypes = [C.POINTER(Params), i64, i64, i64, vp, i64, vp, vp, vp, i64, C.POINTER(i64), vp, i64,
                                     C.POINTER(i64), C.POINTER(i64)]
@@ -92,6 +99,13 @@ def load():
     L.pnr_get_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
     L.pnr_reset_kernel_ms.argtypes = [vp]
     L.pnr_expf_batch.argtypes = [vp, vp, i64, vp]
+    L.pnr_get_graph.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64)]
+    L.pnr_trace_replay_sharded.argtypes = [vp, vp, i64, i32, i32, ALLGATHER_FN, vp, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64),
+                                           C.POINTER(i64), C.POINTER(i64)]
+    L.pnr_sched_playback.argtypes = [C.POINTER(Params), i64, i64, i64, vp, i64, i32, i32, ALLGATHER_FN, vp, i64, TRACE_FN, vp, i32, i32, i32,
+                                     vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    L.pnr_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.pnr_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     for name in EXPORTS:
         if name not in ("pnr_last_error", "pnr_default_params", "pnr_destroy"):
             getattr(L, name).restype = C.c_int
@@ -103,7 +117,8 @@ EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", 
            "pnr_set_volume", "pnr_set_volume_device", "pnr_frangi", "pnr_get_frangi", "pnr_gaussian", "pnr_hessian",
            "pnr_set_j8_v", "pnr_extract_seeds", "pnr_extract_seeds_range", "pnr_zncc_batch",
            "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_replay_traces_ctx", "pnr_frangi_slab", "pnr_quantise_j8", "pnr_soma", "pnr_get_soma", "pnr_trace_replay", "pnr_reconstruct", "pnr_get_table", "pnr_set_profiling", "pnr_set_smc_driver",
-           "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch"]
+           "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch", "pnr_get_graph", "pnr_trace_replay_sharded", "pnr_sched_playback",
+           "pnr_set_option", "pnr_get_option", "pnr_score_filter_seeds", "pnr_sort_seeds"]
 
 
 def check(rc):
@@ -128,6 +143,11 @@ def make_params(sigmas=(2, 4, 6), somaradius=0, tolerance=5, znccth=0.3, kappa=3
     return p
 
 
+# what a new Context starts with (tests run every case with both SMC drivers by patching this; the library itself reads no
+# environment variable): {"smc_driver": "phased" | "persistent", "options": {key: value}}
+DEFAULTS = {"smc_driver": None, "options": {}}
+
+
 class Context:
     """One GPU worth of PNR hot path (pnr_ctx)."""
 
@@ -139,6 +159,10 @@ class Context:
         self.h = h
         self.shape = None
         self._keep = None
+        if DEFAULTS.get("smc_driver"):
+            self.set_smc_driver(DEFAULTS["smc_driver"])
+        for k, v in (DEFAULTS.get("options") or {}).items():
+            self.set_option(k, v)
 
     def close(self):
         if getattr(self, "h", None):
@@ -231,11 +255,19 @@ class Context:
         check(self.L.pnr_zncc_batch(self.h, pd.ctypes.data, len(pd), corr.ctypes.data, sig.ctypes.data))
         return corr, sig
 
-    def score_filter_sort(self, seeds):
+    def score_filter_sort(self, seeds, fn="pnr_score_filter_sort_seeds"):
         s = np.ascontiguousarray(seeds, SEED_DT).copy()
         n = C.c_int64()
-        check(self.L.pnr_score_filter_sort_seeds(self.h, s.ctypes.data, len(s), C.byref(n)))
+        check(getattr(self.L, fn)(self.h, s.ctypes.data, len(s), C.byref(n)))
         return s[:n.value].copy()
+
+    def score_filter(self, seeds):
+        """score + threshold, order kept (a rank's own z-slab of seeds)"""
+        return self.score_filter_sort(seeds, "pnr_score_filter_seeds")
+
+    def sort_seeds(self, seeds):
+        """stable sort by corr of already scored seeds (the merged list of all ranks)"""
+        return self.score_filter_sort(seeds, "pnr_sort_seeds")
 
     # ---- tracing ----
     def trace_batch(self, seeds, dbg_iters=0):
@@ -291,19 +323,53 @@ class Context:
             out["E8"] = E8
         return out
 
-    def trace_replay(self, seeds, first_batch=0, cap_nodes=None):
-        """batched trace + replay (pnr_trace_replay): nodes, links, traces used, SMC iterations run"""
+    def get_graph(self):
+        """node graph of the last trace_replay / trace_replay_sharded (pnr_get_graph)"""
+        nn, nl = C.c_int64(), C.c_int64()
+        check(self.L.pnr_get_graph(self.h, None, 0, C.byref(nn), None, 0, C.byref(nl)))
+        nodes = np.zeros(nn.value, NODE_DT)
+        links = np.zeros((nl.value, 2), np.int32)
+        check(self.L.pnr_get_graph(self.h, nodes.ctypes.data, len(nodes), C.byref(nn), links.ctypes.data, len(links), C.byref(nl)))
+        return nodes, links
+
+    def trace_replay(self, seeds, first_batch=0):
+        """streamed trace + replay (pnr_trace_replay): nodes, links, traces used, SMC iterations run"""
         s = np.ascontiguousarray(seeds, SEED_DT)
-        cap = int(cap_nodes or (2 * len(s) * self.p.ni + 2))
-        while True:
-            nodes = np.zeros(cap, NODE_DT)
-            links = np.zeros((2 * cap + 2, 2), np.int32)
-            nn, nl, nt, it = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
-            check(self.L.pnr_trace_replay(self.h, s.ctypes.data, len(s), first_batch, nodes.ctypes.data, cap, C.byref(nn),
-                                          links.ctypes.data, len(links), C.byref(nl), C.byref(nt), C.byref(it)))
-            if nn.value <= cap and nl.value <= len(links):
-                return nodes[:nn.value].copy(), links[:nl.value].copy(), nt.value, it.value
-            cap = int(nn.value) + 2
+        nn, nl, nt, it = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.L.pnr_trace_replay(self.h, s.ctypes.data, len(s), first_batch, None, 0, C.byref(nn), None, 0, C.byref(nl), C.byref(nt), C.byref(it)))
+        nodes, links = self.get_graph()
+        return nodes, links, nt.value, it.value
+
+    def trace_replay_sharded(self, seeds, rank, world, exchange):
+        """this rank's part of tracing ONE sorted seed list on `world` GPUs (pnr_trace_replay_sharded); `exchange` is an ALLGATHER_FN.
+        Every rank returns the same graph; the iteration count is this rank's."""
+        s = np.ascontiguousarray(seeds, SEED_DT)
+        nn, nl, nt, it = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.L.pnr_trace_replay_sharded(self.h, s.ctypes.data, len(s), rank, world, exchange, None, None, 0, C.byref(nn), None, 0,
+                                              C.byref(nl), C.byref(nt), C.byref(it)))
+        nodes, links = self.get_graph()
+        return nodes, links, nt.value, it.value
+
+    def have_soma(self):
+        nn, nv = C.c_int64(), C.c_int64()
+        return self.L.pnr_get_soma(self.h, None, 0, C.byref(nn), None, None, 0, C.byref(nv)) == 0
+
+    def set_option(self, key, value):
+        check(self.L.pnr_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int64()
+        check(self.L.pnr_get_option(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    def set_options(self, spec):
+        """'window=512,groups=2' (bench.py / tests: PNR_BENCH_OPTS); returns what was set"""
+        out = {}
+        for kv in filter(None, (spec or "").split(",")):
+            k, v = kv.split("=")
+            self.set_option(k.strip(), int(v))
+            out[k.strip()] = int(v)
+        return out
 
     def table(self, name):
         n = C.c_int64()
@@ -350,6 +416,38 @@ def replay(params, shape, seeds, T, xc):
     check(L.pnr_replay_traces(C.byref(params), w, h, l, s.ctypes.data, len(s), T.ctypes.data, xc.ctypes.data,
                               nodes.ctypes.data, cap, C.byref(nn), links.ctypes.data, len(links), C.byref(nl), C.byref(nt)))
     return nodes[:nn.value].copy(), links[:nl.value].copy(), nt.value
+
+
+def sched_playback(params, shape, seeds, trace_fn, rank=0, world=1, exchange=None, block_bytes=0, window=768, groups=1, poll=4):
+    """The streaming scheduler over a host engine that plays back map-free traces (pnr_sched_playback; no GPU): `trace_fn(pos_dir6)`
+    -> (T, xc[ni][8]).  Returns nodes, links, traces used, iterations on this rank."""
+    L = load()
+    l, h, w = shape
+    s = np.ascontiguousarray(seeds, SEED_DT)
+    ni = params.ni
+
+    def _tr(user, pd, T, xc):
+        try:
+            Tn, rows = trace_fn(np.ctypeslib.as_array(pd, (6,)).copy())
+            T[0] = int(Tn)
+            out = np.ctypeslib.as_array(C.cast(xc, C.POINTER(C.c_float)), (ni, 8))
+            k = min(int(Tn), ni)
+            out[:k] = np.asarray(rows, np.float32).reshape(-1, 8)[:k]
+            return 0
+        except Exception:  # noqa: BLE001 -- must not propagate through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    tcb = TRACE_FN(_tr)
+    xcb = exchange if exchange is not None else C.cast(None, ALLGATHER_FN)
+    nn, nl, nt, it = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    cap = 2 * len(s) * ni + 2
+    nodes = np.zeros(cap, NODE_DT)
+    links = np.zeros((2 * cap + 2, 2), np.int32)
+    check(L.pnr_sched_playback(C.byref(params), w, h, l, s.ctypes.data, len(s), rank, world, xcb, None, block_bytes, tcb, None, window, groups, poll,
+                               nodes.ctypes.data, cap, C.byref(nn), links.ctypes.data, len(links), C.byref(nl), C.byref(nt), C.byref(it)))
+    return nodes[:nn.value].copy(), links[:nl.value].copy(), nt.value, it.value
 
 
 def reconstruct(nodes, links, trace_rsmpl=0.0, sig2radius=0.0, refine_iter=0, epsilon2=0.0, group_radius=0.0, tree_size_min=0):

@@ -1,19 +1,28 @@
 """Multi-GPU host logic: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI
 on the GPU box, "gloo" in the CPU tests).  The reference has no distributed code at all
-(SURVEY.md 2.1); the decomposition is new:
+(SURVEY.md 2.1); the decomposition of ONE stack (BASELINE configs[3]) is new:
 
-  * independent seed traces are dealt round-robin over the ranks (rank r takes sorted seeds
-    r, r+G, ...: every GPU gets the same mix of strong and weak seeds); every rank holds a replica
-    of the u8 stack, so there is NO data-path collective while tracing;
-  * one collective at the end: the (fixed-stride, padded) trace records are all-gathered and
-    rank 0 replays the sequential bookkeeping in global seed order -- the replay itself must not
-    be sharded (it is order-dependent by definition).  Records are tiny (<= 2*ni*32 B per seed):
-    latency-bound over xGMI, not per-link-bandwidth-bound.
+  * Frangi + seed extraction in z-slabs cut from every rank's replica of the u8 stack (no halo
+    exchange), one 2-float all-reduce for Jmin / Jmax, one variable-length all-gather of the seeds;
+  * tracing: the sorted seeds are dealt round-robin (rank r takes r, r+G, ...: every GPU gets the
+    same mix of strong and weak seeds) and every rank streams its share through its own window of
+    trace slots (pnr_trace_replay_sharded).  After every poll the ranks all-gather the records of
+    the traces that finished (one fixed-size block per rank: latency-bound over xGMI, never
+    per-link-bandwidth-bound) and every rank replays them in global seed order -- the replay must
+    not be sharded, it is order-dependent by definition -- so every GPU's density map holds the
+    replayed nodes of all ranks: early DENSITY stops and the seed skip rule work as on one GPU, and
+    every rank ends with the same node graph (no final gather is needed).
+
+The all-gather is handed to the C ABI as a callback (pnr_allgather_fn): make_exchange() wraps
+torch.distributed, ThreadExchange joins several contexts of one process (tests).
 """
+import ctypes as C
+import threading
+
 import numpy as np
 import torch
 
-from .lib import SEED_DT, XEST_DT, NODE_DT, replay as _replay
+from .lib import SEED_DT, NODE_DT, ALLGATHER_FN
 
 
 def shard_indices(n, rank, world):
@@ -26,39 +35,77 @@ def _all_gather(dist, t, world):
     return out
 
 
-def trace_sharded(ctx, seeds, dist, rank, world, trace_fn=None, device=None, params=None, shape=None):
-    """Trace `seeds` (sorted, identical on every rank) sharded round-robin; returns
-    (nodes, links, T_all) on every rank (rank 0's replay result is authoritative; the others run the
-    same deterministic replay on the same gathered records)."""
-    params = params if params is not None else ctx.p
-    shape = shape if shape is not None else ctx.shape
-    ni = params.ni
-    trace_fn = trace_fn or (lambda s: ctx.trace_batch(s)[:3])
-    n = len(seeds)
-    mine = shard_indices(n, rank, world)
-    T, stop, xc = trace_fn(seeds[mine])
-    m = (n + world - 1) // world  # padded share
-    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu"))
-    Tp = torch.zeros(2 * m, dtype=torch.int32)
-    Tp[:len(T)] = torch.from_numpy(np.ascontiguousarray(T, np.int32))
-    xp = torch.zeros((2 * m, ni, 8), dtype=torch.float32)
-    if len(T):
-        xp[:len(T)] = torch.from_numpy(np.ascontiguousarray(xc).view(np.float32).reshape(len(T), ni, 8))
-    Tg = _all_gather(dist, Tp.to(dev), world)
-    xg = _all_gather(dist, xp.to(dev), world)
-    T_all = np.zeros(2 * n, np.int32)
-    xc_all = np.zeros((2 * n, ni, 8), np.float32)
-    for r in range(world):
-        idx = shard_indices(n, r, world)
-        k = len(idx)
-        if k == 0:
-            continue
-        Tr = Tg[r].cpu().numpy()[:2 * k]
-        xr = xg[r].cpu().numpy()[:2 * k]
-        T_all[np.repeat(2 * idx, 2) + np.tile([0, 1], k)] = Tr
-        xc_all[np.repeat(2 * idx, 2) + np.tile([0, 1], k)] = xr
-    nodes, links, _ = _replay(params, shape, seeds, T_all, xc_all.view(XEST_DT).reshape(2 * n, ni))
-    return nodes, links, T_all
+def make_exchange(dist, world, device=None):
+    """pnr_allgather_fn over torch.distributed: `bytes` bytes per rank -> world x bytes in rank order.  With a CUDA `device` (backend
+    nccl = RCCL) the block goes through pinned staging buffers and the GPU; otherwise (gloo) it stays in host memory.  Keep the
+    returned object alive while the C call runs."""
+    cuda = device is not None and torch.device(device).type == "cuda"
+    st = {"nb": -1}
+
+    def fn(user, send, recv, nbytes):
+        try:
+            nb = int(nbytes)
+            if st["nb"] != nb:
+                st["nb"] = nb
+                st["inp"] = torch.empty(nb, dtype=torch.uint8)
+                st["out"] = torch.empty(world * nb, dtype=torch.uint8)
+                if cuda:
+                    st["inp"], st["out"] = st["inp"].pin_memory(), st["out"].pin_memory()
+                    st["ginp"] = torch.empty(nb, dtype=torch.uint8, device=device)
+                    st["gout"] = torch.empty(world * nb, dtype=torch.uint8, device=device)
+            C.memmove(st["inp"].data_ptr(), send, nb)
+            if cuda:
+                st["ginp"].copy_(st["inp"], non_blocking=True)
+                dist.all_gather_into_tensor(st["gout"], st["ginp"])
+                st["out"].copy_(st["gout"])  # blocking: the block is on the host when this returns
+            else:
+                dist.all_gather(list(st["out"].view(world, nb).unbind(0)), st["inp"])
+            C.memmove(recv, st["out"].data_ptr(), world * nb)
+            return 0
+        except Exception:  # noqa: BLE001 -- must not propagate through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    return ALLGATHER_FN(fn)
+
+
+class ThreadExchange:
+    """all-gather between `world` threads of ONE process, each driving its own context (tests: logical ranks on one GPU)"""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.blocks = [b""] * world
+
+    def callback(self, rank):
+        def fn(user, send, recv, nbytes):
+            try:
+                self.blocks[rank] = C.string_at(send, int(nbytes))
+                self.barrier.wait(timeout=300)
+                data = b"".join(self.blocks)
+                C.memmove(recv, data, len(data))
+                self.barrier.wait(timeout=300)  # nobody overwrites its block before everyone has read it
+                return 0
+            except Exception:  # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                self.barrier.abort()
+                return 1
+        return ALLGATHER_FN(fn)
+
+
+def trace_sharded(ctx, seeds, dist, rank, world, device=None):
+    """This rank's share of tracing the sorted `seeds` (identical on every rank): (nodes, links, iterations run here).  Every rank
+    returns the same graph -- the graph ctx.trace_replay(seeds) gives on one GPU."""
+    if ctx.p.somaradius > 0 and not ctx.have_soma():
+        raise RuntimeError("somaradius > 0: run ctx.soma() on every rank before tracing")
+    if world == 1:
+        nodes, links, _, iters = ctx.trace_replay(seeds)
+        return nodes, links, iters
+    ex = make_exchange(dist, world, device)
+    nodes, links, _, iters = ctx.trace_replay_sharded(seeds, rank, world, ex)
+    return nodes, links, iters
 
 
 def slab_bounds(l, rank, world, halo):
@@ -85,6 +132,7 @@ def frangi_seeds_sharded(ctx, img_ptr, shape, dist, rank, world, device=None, re
     z0, z1, zlo, zhi = slab_bounds(l, rank, world, halo)
     seeds = np.zeros(0, SEED_DT)
     jmin, jmax = np.float32(np.inf), np.float32(-np.inf)
+    keep = ctx._keep  # the caller's keep-alive reference of the whole stack survives the slab views
     if z1 > z0:
         ctx.set_volume_device(img_ptr + zlo * h * w, (zhi - zlo, h, w))
         jmin, jmax = ctx.frangi_slab(z0 - zlo, z1 - zlo)
@@ -99,7 +147,7 @@ def frangi_seeds_sharded(ctx, img_ptr, shape, dist, rank, world, device=None, re
         ctx.quantise_j8(jmin, jmax)
         seeds = ctx.extract_seeds(z0 - zlo, z1 - zlo)
         seeds["z"] += np.float32(zlo)
-    ctx.set_volume_device(img_ptr, (l, h, w))
+    ctx.set_volume_device(img_ptr, (l, h, w), keepalive=keep)
     return seeds, float(jmin), float(jmax)
 
 

@@ -10,7 +10,8 @@ import pnr_amd
 from pnr_amd import lib
 
 pytestmark = pytest.mark.gpu
-F32_RTOL, F32_ATOL = 1e-5, 1e-6
+# Contract of the particle filter: BIT IDENTITY with the oracle -- every IEEE operation of the reference's scalar loops in its order
+# (DESIGN.md 2): particle states, weights, N_eff, estimates, resampling indices and stop reasons are compared with array_equal.
 
 
 def _slice(w=96, h=80, seed=4):
@@ -84,8 +85,8 @@ def test_trace_2d_vs_oracle(oracle, sigs, np_, ni):
             j = 2 * i + d
             assert T[j] == Tn and stop[j] == st, (j, T[j], Tn, stop[j], st)
             rows = min(Tn + 1, ni)
-            assert np.allclose(mat(xc[j])[:rows], xco[:rows], rtol=F32_RTOL, atol=F32_ATOL)
-            assert np.allclose(dbg["xfilt"][j, :rows], xf[:rows], rtol=F32_RTOL, atol=F32_ATOL)
+            assert np.array_equal(mat(xc[j])[:rows], xco[:rows], equal_nan=True)
+            assert np.array_equal(dbg["xfilt"][j, :rows], xf[:rows], equal_nan=True)
     assert T.max() > 3
 
 

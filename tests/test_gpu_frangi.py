@@ -36,12 +36,13 @@ def test_frangi_vs_golden(golden):
     c.set_volume(golden["img"])
     jmin, jmax = c.frangi()
     g = c.get_frangi()
-    assert np.allclose(g["J"], golden["J"], rtol=J_RTOL, atol=0)
-    assert abs(jmax - golden["Jmax"]) <= J_RTOL * golden["Jmax"] and jmin == golden["Jmin"]
+    # the contract is J_RTOL (fp64 exp of the device library vs glibc, < 1 ulp each, before the f32 store); what is MEASURED on
+    # gfx950 with this ROCm is identity on every golden voxel, and that is what is asserted for these fixed inputs
+    assert np.array_equal(g["J"], golden["J"])
+    assert jmax == golden["Jmax"] and jmin == golden["Jmin"]
     for k in ("Vx", "Vy", "Vz"):
         assert np.array_equal(g[k], golden[k]), k
     assert np.array_equal(g["J8"], golden["J8_restated"])
-    print("J exact fraction", (g["J"] == golden["J"]).mean())
 
 
 @pytest.mark.parametrize("shape,sigs,zdist", [((33, 21, 9), [2.0], 2.0), ((20, 50, 14), [2.0, 3.0], 1.0), ((9, 9, 5), [2.0], 2.0),

@@ -1,0 +1,121 @@
+"""One stack on several GPUs (BASELINE configs[3]) through the real HIP contexts, on the one GPU of the test box:
+
+  * pnr_trace_replay_sharded with 2 / 3 logical ranks -- one context and one host thread per rank, joined by an in-process
+    all-gather (ThreadExchange) -- must end, on EVERY rank, with exactly the node graph of pnr_trace_replay on one GPU, and with
+    no more SMC iterations than the map-free tracing needs;
+  * the sharded front half (Frangi + seeds per z-slab, scores per slab, merged sort) must give the sorted seed list of one GPU;
+  * `bench.py --gpus 2` must start two ranks (here over gloo, sharing the GPU) and report the graph of `--gpus 1`.
+The multi-process collectives themselves are covered on CPU (tests/test_multigpu_gloo.py)."""
+import json
+import os
+import subprocess
+import sys
+import threading
+import numpy as np
+import pytest
+import synth
+import pnr_amd
+from pnr_amd import lib, multigpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _graph_equal(a, b):
+    return len(a[0]) == len(b[0]) and np.array_equal(a[1], b[1]) and all(np.array_equal(a[0][k], b[0][k], equal_nan=True) for k in a[0].dtype.names)
+
+
+@pytest.mark.parametrize("world,opts", [(2, {}), (3, dict(window=16, poll=3, exchange_block=2048)), (2, dict(groups=2, window=32))])
+def test_sharded_trace_logical_ranks(world, opts):
+    img = synth.synth(96, 80, 40, seed=11)
+    p = pnr_amd.make_params(sigmas=[2.0, 3.0], np_=48, ni=40, zdist=2.0, nodepervol=3, vol=5)
+    c0 = pnr_amd.Context(p, 0)
+    c0.set_volume(img)
+    c0.frangi()
+    seeds = c0.score_filter_sort(c0.extract_seeds())[:60]
+    assert len(seeds) > 30
+    T, stop, xc, _ = c0.trace_batch(seeds)
+    free_iters = int((T + (T < p.ni)).sum())
+    n1, l1, nt1, it1 = c0.trace_replay(seeds)
+    X = multigpu.ThreadExchange(world)
+    ctxs, out = [], [None] * world
+    for r in range(world):
+        c = pnr_amd.Context(p, 0)
+        c.set_volume(img)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        ctxs.append(c)
+
+    def run(r):
+        try:
+            out[r] = ctxs[r].trace_replay_sharded(seeds, r, world, X.callback(r))
+        except Exception as e:  # noqa: BLE001
+            out[r] = e
+            X.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+        assert not t.is_alive()
+    for r in range(world):
+        assert not isinstance(out[r], Exception), out[r]
+        assert out[r][2] == nt1 and _graph_equal((out[r][0], out[r][1]), (n1, l1)), f"rank {r} of {world}"
+    assert sum(o[3] for o in out) <= free_iters
+    for c in ctxs:
+        c.close()
+
+
+def test_sharded_front_half_gives_the_one_gpu_seed_list():
+    """Frangi + seeds per z-slab, scores per slab (pnr_score_filter_seeds), merged stable sort (pnr_sort_seeds) == pnr_frangi +
+    pnr_extract_seeds + pnr_score_filter_sort_seeds; three logical ranks in sequence on one context (the all-reduce of Jmin / Jmax
+    emulated), ragged slabs"""
+    import torch
+    img = synth.synth_torch(88, 72, 50, seed=5)
+    p = pnr_amd.make_params(sigmas=[2.0, 4.0], np_=32, ni=10, zdist=2.0)
+    c = pnr_amd.Context(p, 0)
+    shape = tuple(img.shape)
+    c.set_volume_device(img.data_ptr(), shape, keepalive=img)
+    c.frangi()
+    want = c.score_filter_sort(c.extract_seeds())
+    world = 3
+    ext = []
+    for r in range(world):  # pass 1: every rank's Jmin / Jmax over its own planes
+        z0, z1, zlo, zhi = multigpu.slab_bounds(shape[0], r, world, multigpu.frangi_halo(p))
+        c.set_volume_device(img.data_ptr() + zlo * shape[1] * shape[2], (zhi - zlo, shape[1], shape[2]))
+        ext.append(c.frangi_slab(z0 - zlo, z1 - zlo))
+    gmin, gmax = min(e[0] for e in ext), max(e[1] for e in ext)
+    parts = []
+    for r in range(world):
+        mine, _, _ = multigpu.frangi_seeds_sharded(c, img.data_ptr(), shape, None, r, world, reduce_fn=lambda a, b: (gmin, gmax))
+        assert c._keep is img  # the caller's keep-alive reference survives the slab views
+        parts.append(c.score_filter(mine))
+    got = c.sort_seeds(np.concatenate(parts))
+    assert len(got) == len(want) > 20
+    for k in want.dtype.names:
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    torch.cuda.synchronize()
+
+
+def _bench(args, env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_two_ranks_and_matches_one_gpu():
+    """`python bench.py --gpus 2` (no torchrun around it) becomes the launcher of two ranks; rehearsed on one GPU over gloo.
+    Same stack, same 150 sorted seeds: the sharded step reports n_gpus 2, strong scaling and the node count of the 1-GPU step."""
+    common = ["--size", "160", "--seeds", "150", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra"]
+    one = _bench(["--gpus", "1"] + common, {})
+    two = _bench(["--gpus", "2"] + common, {"PNR_BENCH_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong" and one["scaling"] == "strong"
+    assert two["counts"]["nodes"] == one["counts"]["nodes"] > 50
+    assert two["counts"]["n_seeds"] == one["counts"]["n_seeds"] and two["counts"]["n_seeds_init"] == one["counts"]["n_seeds_init"]
+    assert two["counts"]["traces_used"] == one["counts"]["traces_used"]
+    for k in ("roofline", "roofline_smc_group"):
+        assert two[k]["frac"] > 0 and one[k]["frac"] > 0

@@ -11,14 +11,15 @@ import pnr_amd
 from pnr_amd import lib
 
 pytestmark = pytest.mark.gpu
-F32_RTOL, F32_ATOL = 1e-5, 1e-6
+# Contract of the particle filter: BIT IDENTITY with the oracle -- every IEEE operation of the reference's scalar loops in its order
+# (DESIGN.md 2): particle states, weights, N_eff, estimates, resampling indices and stop reasons are compared with array_equal.
 
 
 @pytest.fixture(autouse=True, params=["phased", "persistent"])
 def smc_driver(request, monkeypatch):
     """every test of this module runs with both schedulers of the particle filter (include/pnr_hip.h:
-    pnr_set_smc_driver); a new context takes its initial driver from PNR_SMC_DRIVER"""
-    monkeypatch.setenv("PNR_SMC_DRIVER", request.param)
+    pnr_set_smc_driver); a new Context takes its initial driver from pnr_amd.lib.DEFAULTS"""
+    monkeypatch.setitem(lib.DEFAULTS, "smc_driver", request.param)
     return request.param
 
 
@@ -71,9 +72,8 @@ def test_zncc_vs_oracle(oracle, sigs, zdist):
     c = pnr_amd.Context(pnr_amd.make_params(sigmas=sigs, zdist=zdist), 0)
     c.set_volume(img)
     got_c, got_s = c.zncc(pd)
-    assert np.allclose(got_c, want_c, rtol=F32_RTOL, atol=F32_ATOL)
+    assert np.array_equal(got_c, want_c)
     assert np.array_equal(got_s, want_s)
-    print("zncc bit-exact fraction", (got_c == want_c).mean())
     assert c.zncc(np.zeros((0, 6), np.float32))[0].shape == (0,)
 
 
@@ -102,15 +102,14 @@ def test_trace_vs_oracle(oracle, sigs, np_, ni, zdist):
             j = 2 * i + d
             assert T[j] == Tn and stop[j] == st, (j, T[j], Tn, stop[j], st)
             rows = min(Tn + 1, ni)
-            assert np.allclose(mat(xc[j])[:rows], xco[:rows], rtol=F32_RTOL, atol=F32_ATOL)
-            assert np.allclose(dbg["xfilt"][j, :rows], xf[:rows], rtol=F32_RTOL, atol=F32_ATOL)  # particle weights incl.
-            assert np.allclose(dbg["neff"][j, :rows], neff[:rows], rtol=F32_RTOL)
+            assert np.array_equal(mat(xc[j])[:rows], xco[:rows], equal_nan=True)
+            assert np.array_equal(dbg["xfilt"][j, :rows], xf[:rows], equal_nan=True)  # particle weights incl.
+            assert np.array_equal(dbg["neff"][j, :rows], neff[:rows], equal_nan=True)
             res = (neff[:Tn] / np_ < 0.8)
             for it in np.nonzero(res)[0]:
                 assert np.array_equal(dbg["idxres"][j, it], idx[it]), (j, it)
                 nres += 1
     assert T.max() > 3 and nres > 0
-    print("xc bit-exact:", all(np.array_equal(mat(xc[j])[:max(T[j], 1)], mat(xc[j])[:max(T[j], 1)]) for j in range(len(T))))
 
 
 def test_trace_nan_direction_and_border_seed(oracle):
@@ -132,7 +131,7 @@ def test_trace_nan_direction_and_border_seed(oracle):
             j = 2 * i + d
             assert T[j] == Tn and stop[j] == st
             rows = min(Tn + 1, 10)
-            assert np.allclose(mat(xc[j])[:rows], xco[:rows], rtol=F32_RTOL, atol=F32_ATOL, equal_nan=True)
+            assert np.array_equal(mat(xc[j])[:rows], xco[:rows], equal_nan=True)
 
 
 def test_trace_leaving_through_a_border(oracle):
@@ -194,7 +193,7 @@ def test_end_to_end_vs_oracle(oracle):
     assert len(res["nodes"]) == len(nodes_o) and res["ntraces"] == nt
     assert np.array_equal(res["links"], links_o) and np.array_equal(res["nodes"]["type"], nodes_o["type"])
     for k in ("x", "y", "z", "vx", "vy", "vz", "corr", "sig"):
-        assert np.allclose(res["nodes"][k], nodes_o[k], rtol=F32_RTOL, atol=F32_ATOL), k
+        assert np.array_equal(res["nodes"][k], nodes_o[k], equal_nan=True), k
     assert len(nodes_o) > 50
 
 
@@ -240,8 +239,8 @@ def test_streaming_scheduler_edge_cases(monkeypatch, smc_driver, window, look0, 
     assert len(seeds) > 30
     T, stop, xc, _ = c.trace_batch(seeds)
     n1, l1, nt1 = c.replay(seeds, T, xc)
-    for k, v in (("PNR_WINDOW", window), ("PNR_LOOK0", look0), ("PNR_LOOK_PCT", look_pct), ("PNR_POLL", poll), ("PNR_GROUPS", groups)):
-        monkeypatch.setenv(k, str(v))
+    for k, v in (("window", window), ("look0", look0), ("look_pct", look_pct), ("poll", poll), ("groups", groups)):
+        c.set_option(k, v)
     n2, l2, nt2, iters = c.trace_replay(seeds)
     assert nt1 == nt2 and len(n1) == len(n2) > 20 and np.array_equal(l1, l2)
     for k in n1.dtype.names:
@@ -269,8 +268,8 @@ def test_large_sigma_templates_outside_the_cube(oracle):
             j = 2 * i + d
             assert T[j] == Tn and stop[j] == st
             rows = min(Tn + 1, ni)
-            assert np.allclose(mat(xc[j])[:rows], xco[:rows], rtol=F32_RTOL, atol=F32_ATOL)
-            assert np.allclose(dbg["xfilt"][j, :rows], xf[:rows], rtol=F32_RTOL, atol=F32_ATOL)
+            assert np.array_equal(mat(xc[j])[:rows], xco[:rows], equal_nan=True)
+            assert np.array_equal(dbg["xfilt"][j, :rows], xf[:rows], equal_nan=True)
 
 
 def test_many_particles_vs_oracle(oracle, smc_driver):
@@ -292,8 +291,8 @@ def test_many_particles_vs_oracle(oracle, smc_driver):
         Tn, st, xco, xf, idx, neff = To.trace(img, q, max_dbg=ni)
         assert T[d] == Tn and stop[d] == st
         rows = min(Tn + 1, ni)
-        assert np.allclose(mat(xc[d])[:rows], xco[:rows], rtol=F32_RTOL, atol=F32_ATOL)
-        assert np.allclose(dbg["xfilt"][d, :rows], xf[:rows], rtol=F32_RTOL, atol=F32_ATOL)
+        assert np.array_equal(mat(xc[d])[:rows], xco[:rows], equal_nan=True)
+        assert np.array_equal(dbg["xfilt"][d, :rows], xf[:rows], equal_nan=True)
 
 
 def test_small_stash_budget_gives_same_traces(monkeypatch, smc_driver):
@@ -309,8 +308,8 @@ def test_small_stash_budget_gives_same_traces(monkeypatch, smc_driver):
     seeds = a.score_filter_sort(a.extract_seeds())[:40]
     Ta, sa, xa, _ = a.trace_batch(seeds)
     na, la, _, _ = a.trace_replay(seeds)
-    monkeypatch.setenv("PNR_STASH_MB", "4")  # 2 x 4 MB / 2: room for a handful of traces
     b = pnr_amd.Context(p, 0)
+    b.set_option("stash_mb", 4)  # room for a handful of traces
     b.set_volume(img)
     Tb, sb, xb, _ = b.trace_batch(seeds)
     nb, lb, _, _ = b.trace_replay(seeds)
@@ -341,8 +340,8 @@ def test_trace_config5_shape_vs_oracle(oracle):
             j = 2 * i + d
             assert T[j] == Tn and stop[j] == st
             rows = min(Tn + 1, ni)
-            assert np.allclose(mat(xc[j])[:rows], xco[:rows], rtol=F32_RTOL, atol=F32_ATOL)
-            assert np.allclose(dbg["xfilt"][j, :rows], xf[:rows], rtol=F32_RTOL, atol=F32_ATOL)
+            assert np.array_equal(mat(xc[j])[:rows], xco[:rows], equal_nan=True)
+            assert np.array_equal(dbg["xfilt"][j, :rows], xf[:rows], equal_nan=True)
 
 
 @pytest.mark.parametrize("S,seed,groups", [(512, 2, 1), (1024, 3, 2)])
@@ -353,10 +352,10 @@ def test_full_size_properties(monkeypatch, smc_driver, S, seed, groups):
     import torch
     if S > 512 and smc_driver != "phased":
         pytest.skip("once is enough at this size")
-    monkeypatch.setenv("PNR_GROUPS", str(groups))
     img = synth.synth_torch(S, S, S, seed=seed)
     p = pnr_amd.make_params(sigmas=(2, 4, 6), np_=200, ni=200, zdist=2)
     c = pnr_amd.Context(p, 0)
+    c.set_option("groups", groups)
     c.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
     jmin, jmax = c.frangi()
     assert jmin == 0 and 0 < jmax < 1
@@ -386,8 +385,8 @@ def test_trace_without_stash_matches(oracle, monkeypatch):
     a = pnr_amd.Context(p, 0)
     a.set_volume(img)
     Ta, sa, xa, _ = a.trace_batch(seeds)
-    monkeypatch.setenv("PNR_NO_STASH", "1")
     b = pnr_amd.Context(p, 0)
+    b.set_option("no_stash", 1)
     b.set_smc_driver("persistent")  # the fallback belongs to the persistent driver: also a cross-driver comparison
     b.set_volume(img)
     Tb, sb, xb, _ = b.trace_batch(seeds)

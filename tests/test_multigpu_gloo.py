@@ -1,9 +1,15 @@
-"""CPU, world_size 2, gloo: the multi-GPU host logic (round-robin seed sharding, padded
-all-gather of trace records, replay on the merged records, variable-length graph gather) gives
-exactly the unsharded result.  The GPU trace kernel is replaced here by the oracle tracer (the
-only place a CPU tracer may stand in: this is a test of the host logic, not a product path)."""
+"""CPU tests of the multi-GPU host logic.  The GPU trace engine is replaced by the library's host play-back engine
+(pnr_sched_playback) fed with the oracle's map-free traces -- the only place a CPU tracer may stand in: these are tests of the
+host logic (round-robin seed sharding, the streaming window with early DENSITY stops, the per-poll all-gather of finished trace
+records with carry-over, the replay in global seed order on every rank, the variable-length seed / graph gathers), not a product
+path.  What is checked: every rank ends with exactly the node graph of the unsharded map-free trace + replay.
+
+  * world_size 2 over torch.distributed gloo (two processes),
+  * 1..4 logical ranks as threads of one process (ThreadExchange), several windows / polls / block sizes.
+"""
 import os
 import sys
+import threading
 import numpy as np
 import pytest
 import torch
@@ -13,70 +19,157 @@ import torch.multiprocessing as mp
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, q):
-    sys.path.insert(0, HERE)
-    sys.path.insert(0, os.path.dirname(HERE))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _workload(n_seeds=9, ni=20, np_=24):
+    """small stack, its best seeds and the oracle's map-free traces of both directions of every seed"""
     import orc
     import synth
     import pnr_amd
-    from pnr_amd import lib, multigpu
+    from pnr_amd import lib
     L = orc.load_oracle()
     img = synth.synth(48, 40, 24, seed=1)
-    ni, np_ = 20, 24
     J, jmin, jmax, Vx, Vy, Vz = orc.frangi3d(L, img, [2.0], 2.0)
     so = orc.extract_seeds(L, 5, orc.j8(L, J, jmin, jmax), Vx, Vy, Vz)
     T = orc.Tracker(L, [2.0], 2, np_, ni, 3.0, 0.3, zdist=2.0)
     corr, _ = T.zncc(img, so[:, :6])
     so[:, 7] = corr
     so = so[corr >= 0.3]
-    so = so[np.argsort(-so[:, 7], kind="stable")][:9]  # odd count: ragged shares
+    so = so[np.argsort(-so[:, 7], kind="stable")][:n_seeds]
     seeds = np.zeros(len(so), lib.SEED_DT)
     for i, k in enumerate(lib.SEED_DT.names):
         seeds[k] = so[:, i]
-
-    def trace_fn(s):
-        Ts, xcs = [], []
-        for sd in s:
-            for sgn in (1, -1):
-                q6 = np.array([sd["x"], sd["y"], sd["z"], sgn * sd["vx"], sgn * sd["vy"], sgn * sd["vz"]], np.float32)
-                Tn, st, xc, *_ = T.trace(img, q6)
-                Ts.append(Tn)
-                xcs.append(xc)
-        return np.array(Ts, np.int32), None, (np.stack(xcs) if xcs else np.zeros((0, ni, 8), np.float32))
-
+    traces = {}
+    Ts, xcs = [], []
+    for sd in seeds:
+        for sgn in (1, -1):
+            q6 = np.array([sd["x"], sd["y"], sd["z"], sgn * sd["vx"], sgn * sd["vy"], sgn * sd["vz"]], np.float32)
+            Tn, st, xc, *_ = T.trace(img, q6)
+            traces[q6.tobytes()] = (int(Tn), np.asarray(xc, np.float32).reshape(ni, 8))
+            Ts.append(Tn)
+            xcs.append(xc)
     p = pnr_amd.make_params(sigmas=[2.0], np_=np_, ni=ni, nodepervol=4, vol=5)
-    nodes, links, T_all = multigpu.trace_sharded(None, seeds, dist, rank, world, trace_fn=trace_fn, device=torch.device("cpu"),
-                                                 params=p, shape=img.shape)
+    Tf = np.array(Ts, np.int32)
+    xcf = np.stack(xcs).astype(np.float32)
+    n1, l1, _ = lib.replay(p, img.shape, seeds, Tf, xcf.view(lib.XEST_DT).reshape(len(Tf), ni))
+    total_free = int(np.minimum(Tf + 1, ni).sum())
+    return dict(img=img, seeds=seeds, traces=traces, p=p, nodes=n1, links=l1, ni=ni, total_free=total_free)
+
+
+def _same_graph(nodes, links, W):
+    return (len(nodes) == len(W["nodes"]) and np.array_equal(links, W["links"])
+            and all(np.array_equal(nodes[k], W["nodes"][k]) for k in nodes.dtype.names))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pnr_amd import lib, multigpu
+    W = _workload()
+    seeds, p, img = W["seeds"], W["p"], W["img"]
+    lookup = lambda q6: W["traces"][np.asarray(q6, np.float32).tobytes()]
+    ex = multigpu.make_exchange(dist, world, torch.device("cpu"))
+    # block of 1 KiB: a record of 20 rows is 656 B, so finished traces queue up and are carried over several polls
+    nodes, links, nt, iters = lib.sched_playback(p, img.shape, seeds, lookup, rank, world, ex, block_bytes=1024, window=6, poll=2)
+    ok = _same_graph(nodes, links, W)
+    it = torch.tensor([iters], dtype=torch.int64)
+    dist.all_reduce(it)
     graphs = multigpu.gather_graphs(nodes, links, dist, rank, world, torch.device("cpu"))
-    # ragged seed all-gather (z-slab sharding of the seed extraction): rank r contributes seeds[r::world]... as contiguous slices
-    cut = [0, len(seeds) // 3, len(seeds)][: world + 1] if world == 2 else None
+    # ragged seed all-gather (z-slab sharding of the seed extraction): contiguous, unequal slices
+    cut = [0, len(seeds) // 3, len(seeds)]
     mine = seeds[cut[rank]:cut[rank + 1]]
     allseeds = multigpu.gather_seeds(mine, dist, rank, world, torch.device("cpu"))
     seeds_ok = len(allseeds) == len(seeds) and all(np.array_equal(allseeds[k], seeds[k], equal_nan=True) for k in seeds.dtype.names)
     z0, z1, zlo, zhi = multigpu.slab_bounds(24, rank, world, multigpu.frangi_halo(p))
     seeds_ok = seeds_ok and (z0, z1) == ((0, 12) if rank == 0 else (12, 24)) and zlo == max(0, z0 - 5) and zhi == min(24, z1 + 5)
+    oks = torch.tensor([int(ok and seeds_ok)], dtype=torch.int64)
+    dist.all_reduce(oks)  # every rank must hold the same, correct graph
     if rank == 0:
-        Tf, _, xcf = trace_fn(seeds)  # unsharded
-        n1, l1, _ = lib.replay(p, img.shape, seeds, Tf, xcf.view(lib.XEST_DT).reshape(len(Tf), ni))
-        ok = np.array_equal(T_all, Tf) and np.array_equal(links, l1) and all(np.array_equal(nodes[k], n1[k]) for k in nodes.dtype.names)
-        ok = ok and seeds_ok and len(graphs) == world and all(np.array_equal(g[1], links) and np.array_equal(g[0]["x"], nodes["x"]) for g in graphs)
-        q.put((ok, len(nodes), int(Tf.sum())))
+        ok_all = int(oks.item()) == world and len(graphs) == world and all(np.array_equal(g[1], links) and np.array_equal(g[0]["x"], nodes["x"]) for g in graphs)
+        q.put((ok_all, len(nodes), int(it.item()), W["total_free"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_trace_equals_unsharded():
+def test_sharded_trace_equals_unsharded_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    ok, nn, tsum = q.get(timeout=240)
+    ok, nn, iters, total_free = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert ok and nn > 10 and tsum > 10
+    assert ok and nn > 10
+    assert 10 < iters <= total_free  # early DENSITY stops never add iterations
+
+
+@pytest.fixture(scope="module")
+def workload():
+    sys.path.insert(0, HERE)
+    return _workload(n_seeds=14)
+
+
+@pytest.mark.parametrize("world,window,poll,block,groups", [(1, 768, 4, 0, 1), (1, 4, 1, 0, 1), (1, 8, 2, 0, 2), (2, 6, 2, 1024, 1), (3, 4, 3, 700, 1),
+                                                            (4, 768, 4, 0, 1), (2, 8, 1, 4096, 2)])
+def test_playback_logical_ranks(workload, world, window, poll, block, groups):
+    from pnr_amd import lib, multigpu
+    W = workload
+    lookup = lambda q6: W["traces"][np.asarray(q6, np.float32).tobytes()]
+    X = multigpu.ThreadExchange(world)
+    out = [None] * world
+
+    def run(r):
+        try:
+            out[r] = lib.sched_playback(W["p"], W["img"].shape, W["seeds"], lookup, r, world, X.callback(r) if world > 1 else None,
+                                        block_bytes=block, window=window, poll=poll, groups=groups)
+        except Exception as e:  # noqa: BLE001
+            out[r] = e
+            X.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    for r in range(world):
+        assert not isinstance(out[r], Exception), out[r]
+        nodes, links, nt, iters = out[r]
+        assert _same_graph(nodes, links, W), f"rank {r} of {world}"
+    assert sum(o[3] for o in out) <= W["total_free"]
+
+
+def test_failing_rank_aborts_the_others(workload):
+    """a rank whose engine fails says so in one last exchange: the other rank returns an error instead of waiting for ever"""
+    from pnr_amd import lib, multigpu
+    W = workload
+    X = multigpu.ThreadExchange(2)
+    out = [None, None]
+    calls = [0]
+
+    def lookup_ok(q6):
+        return W["traces"][np.asarray(q6, np.float32).tobytes()]
+
+    def lookup_bad(q6):
+        calls[0] += 1
+        if calls[0] > 3:
+            raise RuntimeError("injected failure")
+        return lookup_ok(q6)
+
+    def run(r):
+        try:
+            out[r] = lib.sched_playback(W["p"], W["img"].shape, W["seeds"], lookup_bad if r == 1 else lookup_ok, r, 2, X.callback(r), window=4, poll=1)
+        except lib.PnrError as e:
+            out[r] = e
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    assert isinstance(out[0], lib.PnrError) and "aborted" in str(out[0])
+    assert isinstance(out[1], lib.PnrError)
