@@ -112,7 +112,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     std::vector<int32_t> outbox; // finished on this rank, not yet applied / sent
     size_t out_head = 0;
     const size_t rec_max_words = 4 + (size_t)ni * 8;
-    int64_t block = sh.block_bytes > 0 ? sh.block_bytes : 65536;
+    int64_t block = sh.block_bytes > 0 ? sh.block_bytes : 262144;
     block = std::max<int64_t>(block, (int64_t)(HDR_WORDS + rec_max_words) * 4);
     block = (block + 15) / 16 * 16;
     const size_t block_words = (size_t)block / 4;

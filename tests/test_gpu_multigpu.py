@@ -83,7 +83,7 @@ def test_sharded_front_half_gives_the_one_gpu_seed_list():
     ext = []
     for r in range(world):  # pass 1: every rank's Jmin / Jmax over its own planes
         z0, z1, zlo, zhi = multigpu.slab_bounds(shape[0], r, world, multigpu.frangi_halo(p))
-        c.set_volume_device(img.data_ptr() + zlo * shape[1] * shape[2], (zhi - zlo, shape[1], shape[2]))
+        c.set_volume_device(img.data_ptr() + zlo * shape[1] * shape[2], (zhi - zlo, shape[1], shape[2]), keepalive=img)
         ext.append(c.frangi_slab(z0 - zlo, z1 - zlo))
     gmin, gmax = min(e[0] for e in ext), max(e[1] for e in ext)
     parts = []
