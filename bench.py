@@ -275,7 +275,7 @@ def main():
                 dist.barrier()
                 dist.destroy_process_group()
             return
-        km = {g: ctx.kernel_ms(g) for g in ("gauss", "hessian_eigen", "j8", "seed_maxima", "zncc", "smc", "smc_sums", "smc_predict", "smc_update")}
+        km = {g: ctx.kernel_ms(g) for g in ("gauss", "hessian_tile", "hessian_eigen", "j8", "seed_maxima", "zncc", "smc", "smc_sums", "smc_predict", "smc_update")}
         # dominant kernel: the sampling kernel of the particle filter -- ph_sample (one launch per SMC step over all
         # active traces; the "smc" timer group) with the phased driver, smc_trace (one launch per batch, sampling +
         # sums + update) with the persistent one.  Algorithmic bytes: 8 corner bytes x sum(M_sigma)
@@ -289,7 +289,7 @@ def main():
         # several launches per step: bytes per launch / average launch duration = total bytes of the timed region / total device time
         bytes_launch = 8.0 * Mtot * evals * a.steps / max(smc_n, 1)
         achieved = bytes_launch / (smc_ms / max(smc_n, 1) * 1e-3) / 1e9 if smc_ms > 0 else 0.0
-        fr_ms = (km["gauss"][0] + km["hessian_eigen"][0] + km["j8"][0]) / a.steps
+        fr_ms = (km["gauss"][0] + km["hessian_tile"][0] + km["hessian_eigen"][0] + km["j8"][0]) / a.steps
         fr_vox = nvox if not shard else None  # a rank's slab + halo when sharded: no per-stack Frangi figure then
         # HBM traffic per launch: PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, calibrated on
         # a known byte count in the same access pattern: scripts/prof_traffic.sh), collected for THIS workload and
@@ -332,7 +332,7 @@ def main():
                 "device_ms_per_step": smc_all_ms / a.steps, "Mevals_per_s": evals * a.steps / smc_all_ms / 1e3,
                 "note": "SURVEY 8(d): 8*sum(M) algorithmic bytes x particle evaluations / device time of the whole SMC kernel group (t_smc)"},
             "roofline_frangi": None if not fr_vox or fr_ms <= 0 else {
-                "kernels": "gauss_xy_u8+gauss_z+hessian_eigen+j8", "bound": "hbm", "achieved": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9,
+                "kernels": "gauss_x_u8+gauss_axis(y,z)+hessian_tile+eigen_queue+j8", "bound": "hbm", "achieved": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "device_ms_per_step": fr_ms,
                 "note": "(S+12) B/voxel compulsory bytes over the Frangi kernel group; the fp64 JAMA eigen-solver (parity-mandated) is the limiter"},
             "roofline_sums": None if a.driver != "phased" or km["smc_sums"][0] <= 0 else {

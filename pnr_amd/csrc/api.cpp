@@ -201,6 +201,8 @@ void pnr_destroy(pnr_ctx *c)
     hipFree(c->d_img_owned); hipFree(c->d_stash); hipFree(c->d_slot_busy); hipFree(c->d_den); hipFree(c->d_den_idx); hipFree(c->d_den_val);
     hipFree(c->d_tmpA); hipFree(c->d_tmpB); hipFree(c->d_J);
     hipFree(c->d_Vx); hipFree(c->d_Vy); hipFree(c->d_Vz); hipFree(c->d_J8); hipFree(c->d_minmax);
+    for (int s = 0; s < PNR_MAX_SIGMAS; s++) hipFree(c->d_F[s]);
+    hipFree(c->d_scale); hipFree(c->d_taps); hipFree(c->d_qh); hipFree(c->d_qidx); hipFree(c->d_qcount);
     hipFree(c->d_p); hipFree(c->d_u); hipFree(c->d_w0); hipFree(c->d_w0cws); hipFree(c->d_v); hipFree(c->d_w);
     hipFree(c->d_wcws); hipFree(c->d_tmpl); hipFree(c->d_corrc); hipFree(c->d_sig); hipFree(c->d_M); hipFree(c->d_moff);
     hipFree(c->d_rng); hipFree(c->d_grid); hipFree(c->d_axes); hipFree(c->d_axes_off); hipFree(c->d_wd);
@@ -237,6 +239,7 @@ static int set_dims(pnr_ctx *c, int64_t w, int64_t h, int64_t l)
     c->w = w; c->h = h; c->l = l;
     c->N = w * h * l;
     c->have_j8 = false;
+    c->have_v = c->have_scale = false;
     c->seeds.clear();
     c->have_soma = false;
     if ((l == 1) != c->tab.is2d) { // the tracker tables depend on the dimensionality (Tracker(..., P == 1, ...))
@@ -305,7 +308,9 @@ int pnr_get_frangi(pnr_ctx *c, float *J, uint8_t *J8, uint8_t *Vx, uint8_t *Vy, 
 {
     PNR_REQUIRE(c && c->have_j8 && c->d_J, PNR_E_STATE, "pnr_get_frangi: run pnr_frangi first");
     const size_t n = (size_t)c->N;
-    int rc = download(c, J, c->d_J, n);
+    int rc = PNR_OK;
+    if (Vx || Vy || Vz) rc = pnr_frangi_materialise_v(c); // the pipeline itself only needs the directions at the seeds
+    if (!rc) rc = download(c, J, c->d_J, n);
     if (!rc) rc = download(c, J8, c->d_J8, n);
     if (!rc) rc = download(c, Vx, c->d_Vx, n);
     if (!rc) rc = download(c, Vy, c->d_Vy, n);
@@ -363,6 +368,8 @@ int pnr_set_j8_v(pnr_ctx *c, const uint8_t *J8, const uint8_t *Vx, const uint8_t
     PNR_HIP(hipMemcpyAsync(c->d_Vz, Vz, n, hipMemcpyHostToDevice, c->stream));
     PNR_HIP(hipStreamSynchronize(c->stream));
     c->have_j8 = true;
+    c->have_v = true;
+    c->have_scale = false;
     return PNR_OK;
 }
 

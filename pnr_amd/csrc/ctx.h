@@ -97,6 +97,13 @@ struct pnr_ctx {
     float *d_tmpA = nullptr, *d_tmpB = nullptr, *d_J = nullptr;
     uint8_t *d_Vx = nullptr, *d_Vy = nullptr, *d_Vz = nullptr, *d_J8 = nullptr;
     unsigned int *d_minmax = nullptr; // [0]=min bits, [1]=max bits
+    float *d_F[PNR_MAX_SIGMAS] = {};  // smoothed volume of every scale, kept for the direction bytes (frangi.hip)
+    uint8_t *d_scale = nullptr;       // per voxel: the scale whose response is in J
+    bool have_scale = false, have_v = false; // d_scale + d_F valid / the direction volumes Vx, Vy, Vz are filled
+    float *d_taps = nullptr;          // Gaussian taps of all scales
+    float *d_qh = nullptr;            // survivor queue of the Hessian stage: [region][6][entries]
+    unsigned int *d_qidx = nullptr, *d_qcount = nullptr;
+    size_t q_regions = 0;
     int64_t frangi_cap = 0;           // voxels the buffers above were sized for
     bool have_j8 = false;
     float Jmin = 0, Jmax = 0;
@@ -229,3 +236,5 @@ int pnr_density_reset(pnr_ctx *c);                       // zero the device dens
 int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, hipStream_t on = nullptr); // push the voxels touched since Replayer::touched was cleared
 int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y);
 int pnr_ensure_frangi_buffers(pnr_ctx *c);
+int pnr_frangi_materialise_v(pnr_ctx *c);
+int pnr_seed_dirs(pnr_ctx *c, const long long *d_idx, int n, unsigned char *d_dirs); // 0: done, 1: gather from the volumes, < 0: error

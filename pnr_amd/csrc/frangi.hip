@@ -348,101 +348,238 @@ struct HessOut {
     float *Dzz, *Dyy, *Dyz, *Dxx, *Dxy, *Dxz;
 };
 
-constexpr int HE_BLOCK = 256;  // voxels per block along x: the larger the block, the tighter the survivors pack into waves
+// Frangi vesselness of one voxel from its eigenvalues sorted by |lambda| (frangi.cpp:218-231)
+__device__ __forceinline__ double vesselness(const double (&d)[3], float two_a2, float two_b2, float two_c2)
+{
+    const double L2 = d[1], L3 = d[2];
+    const double a1 = fabs(d[0]), a2 = fabs(L2), a3 = fabs(L3);
+    const double Ra = a2 / a3;
+    const double Rb = a1 / sqrt(a2 * a3);
+    const double S = sqrt(a1 * a1 + a2 * a2 + a3 * a3);
+    const double expRa = (1 - exp(-((Ra * Ra) / (double)two_a2)));
+    const double expRb = exp(-((Rb * Rb) / (double)two_b2));
+    const double expS = (1 - exp(-(S * S) / (double)two_c2));
+    double vox = expRa * expRb * expS;
+    vox = (L2 > 0) ? 0 : vox;
+    vox = (L3 > 0) ? 0 : vox;
+    vox = (vox != vox) ? 0 : vox; // NaN -> 0
+    return vox;
+}
+
+// ---- K4a: the Hessian stencil, LDS-tiled ------------------------------------------------------------------------------
+// A work-group owns a column of HT_X x HT_Y voxels and marches HT_Z planes along z with a ring of six planes (tile + halo 2)
+// in LDS: every plane is fetched from HBM once per work-group (1.6x the tile for the x / y halo, 1.8x with the z halo of a
+// 32-plane march) instead of once per stencil point.  Each voxel's six second derivatives go through the test that proves the
+// response zero (below); the survivors are appended to the work-group's own region of a queue in HBM (no global atomics) for
+// the eigen-solver kernel, so that kernel runs with full wavefronts whatever the survival rate.
+constexpr int HT_X = 64, HT_Y = 8, HT_Z = 32, HT_PX = HT_X + 4, HT_PY = HT_Y + 4, HT_PLANE = HT_PX * HT_PY, HT_THREADS = HT_X * HT_Y;
+constexpr int HT_REGION = HT_X * HT_Y * HT_Z; // queue entries a work-group can produce
+constexpr int HT_RING = 6;
+
+struct Tile {
+    const float *pl[5]; // planes z-2 .. z+2 of the ring
+    int o;              // this thread's voxel inside a plane
+};
+__device__ __forceinline__ float t_at(const Tile &T, int dx, int dy, int dz) { return T.pl[dz + 2][T.o + dy * HT_PX + dx]; }
+// first difference along axis A at the voxel displaced by (dx,dy,dz), whose coordinate along A is c of n: frangi.cpp:305-381
+template <int A>
+__device__ __forceinline__ float td1(const Tile &T, int dx, int dy, int dz, int c, int n)
+{
+    constexpr int ax = A == 0, ay = A == 1, az = A == 2;
+    if (c == 0) return t_at(T, dx + ax, dy + ay, dz + az) - t_at(T, dx, dy, dz);
+    if (c < n - 1) return 0.5f * (t_at(T, dx + ax, dy + ay, dz + az) - t_at(T, dx - ax, dy - ay, dz - az));
+    return t_at(T, dx, dy, dz) - t_at(T, dx - ax, dy - ay, dz - az);
+}
+// difference along AO of the first difference along AI (d2 above, on the tile)
+template <int AI, int AO>
+__device__ __forceinline__ float td2(const Tile &T, int ci, int ni, int co, int no)
+{
+    constexpr int same = AI == AO, ox = AO == 0, oy = AO == 1, oz = AO == 2;
+    if (co == 0) return td1<AI>(T, ox, oy, oz, ci + same, ni) - td1<AI>(T, 0, 0, 0, ci, ni);
+    if (co < no - 1) return 0.5f * (td1<AI>(T, ox, oy, oz, ci + same, ni) - td1<AI>(T, -ox, -oy, -oz, ci - same, ni));
+    return td1<AI>(T, 0, 0, 0, ci, ni) - td1<AI>(T, -ox, -oy, -oz, ci - same, ni);
+}
+
+// work-group id -> tile id such that the work-groups of one XCD (id mod 8) own a contiguous range of tiles (a bijection for any n)
+__device__ __forceinline__ unsigned int xcd_contiguous(unsigned int b, unsigned int n)
+{
+    const unsigned int x = b & 7u, idx = b >> 3, q = n >> 3, r = n & 7u;
+    return x * q + (x < r ? x : r) + idx;
+}
+
+struct HessQueue {
+    float *h;            // [region][6][HT_REGION]
+    unsigned int *idx;   // [region][HT_REGION]: (z - z0) << 9 | ty << 6 | tx
+    unsigned int *count; // [region]
+};
 
 template <bool DUMP>
-__global__ __launch_bounds__(HE_BLOCK, 8) void hessian_eigen(const float *__restrict__ F, float *__restrict__ J,
-                                                      unsigned char *__restrict__ Vx, unsigned char *__restrict__ Vy,
-                                                      unsigned char *__restrict__ Vz, int w, int h, int l, int tiles_x,
-                                                      float s2, float two_a2, float two_b2, float two_c2, int first,
-                                                      unsigned int *__restrict__ minmax, HessOut dump, int zs0 = 0, int zs1 = 1 << 30)
+__global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restrict__ F, int w, int h, int l, int tiles_x, int tiles_y, int zc0, int zc1,
+                                                           float s2, HessQueue Q, unsigned int *__restrict__ minmax, int first, int zs0, int zs1, HessOut dump)
 {
-    const i64 b = blockIdx.x;
-    const i64 row = b / tiles_x;
-    const int x = (int)(b % tiles_x) * HE_BLOCK + threadIdx.x;
-    const int z = (int)(row / h), y = (int)(row - (i64)z * h);
+    __shared__ float ring[HT_RING][HT_PLANE];
+    __shared__ unsigned int s_cnt, s_zero;
+    const int tid = threadIdx.x, tx = tid & (HT_X - 1), ty = tid >> 6;
+    // consecutive work-groups go round-robin to the 8 XCDs, each with its own L2: give every XCD a contiguous range of tiles, so
+    // that the halo a tile shares with its x / y neighbours is found in the L2 of the same XCD
+    const unsigned int region = xcd_contiguous(blockIdx.x, gridDim.x);
+    unsigned int b = region;
+    const int bx = (int)(b % (unsigned)tiles_x); b /= (unsigned)tiles_x;
+    const int by = (int)(b % (unsigned)tiles_y);
+    const int bz = (int)(b / (unsigned)tiles_y);
+    const int x0 = bx * HT_X, y0 = by * HT_Y, z0 = zc0 + bz * HT_Z;
+    const int z1 = z0 + HT_Z < zc1 ? z0 + HT_Z : zc1;
     const i64 wh = (i64)w * h;
-    unsigned int omin = 0xffffffffu, omax = 0u;
-    // Phase 1 (all lanes): Hessian of the own voxel and the decision whether the eigen-solver is needed.
-    // Phase 2: the surviving voxels of the 256-voxel block are compacted through LDS so that whole
-    // wavefronts drop out instead of idling next to a few busy lanes (the fp64 solver is the cost).
-    __shared__ float s_h[HE_BLOCK][6];
-    __shared__ int s_x[HE_BLOCK];
-    __shared__ int s_cnt;
-    if (!DUMP) {
-        if (threadIdx.x == 0) s_cnt = 0;
+    if (tid == 0) { s_cnt = 0; s_zero = 0; }
+    // a plane of the ring: HT_PLANE floats, two per thread; out-of-volume halo cells repeat the border (never read: the
+    // one-sided border rules of the reference do not look past the border)
+    const int e0 = tid, e1 = tid + HT_THREADS;
+    const int r0 = e0 / HT_PX, c0 = e0 - r0 * HT_PX, r1 = e1 / HT_PX, c1 = e1 - r1 * HT_PX;
+    auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    const i64 g0 = (i64)clampi(y0 - 2 + r0, h - 1) * w + clampi(x0 - 2 + c0, w - 1);
+    const i64 g1 = (i64)clampi(y0 - 2 + r1, h - 1) * w + clampi(x0 - 2 + c1, w - 1);
+    const bool has1 = e1 < HT_PLANE;
+    auto fetch = [&](int zp, float &a, float &c) {
+        const i64 zo = (i64)clampi(zp, l - 1) * wh;
+        a = F[zo + g0];
+        c = has1 ? F[zo + g1] : 0.f;
+    };
+    auto put = [&](int slot, float a, float c) {
+        ring[slot][e0] = a;
+        if (has1) ring[slot][e1] = c;
+    };
+    // slots: plane zp lives in slot (zp - (z0 - 2)) mod 6
+    {
+        float a, c;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { fetch(z0 - 2 + k, a, c); put(k, a, c); }
+    }
+    __syncthreads();
+    const int x = x0 + tx, y = y0 + ty;
+    const bool inside = x < w && y < h;
+    const int o = (ty + 2) * HT_PX + tx + 2;
+    float *const qh = DUMP ? nullptr : Q.h + (size_t)region * 6 * HT_REGION;
+    unsigned int *const qi = DUMP ? nullptr : Q.idx + (size_t)region * HT_REGION;
+    int s0 = 0; // slot of plane z - 2
+    bool zero_here = false;
+#pragma unroll 1
+    for (int z = z0; z < z1; z++) {
+        float na = 0.f, nc = 0.f;
+        const bool more = z + 1 < z1;
+        if (more) fetch(z + 3, na, nc); // lands while this plane is computed; stored into the slot nobody reads now
+        Tile T;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { const int sl = s0 + k; T.pl[k] = ring[sl >= HT_RING ? sl - HT_RING : sl]; }
+        T.o = o;
+        bool surv = false;
+        float Dzz = 0, Dyy = 0, Dyz = 0, Dxx = 0, Dxy = 0, Dxz = 0;
+        if (inside) {
+            // six second derivatives, each x sigma^2 (frangi.cpp:319,339,345,368,374,380)
+            Dzz = td2<2, 2>(T, z, l, z, l) * s2;
+            Dyy = td2<1, 1>(T, y, h, y, h) * s2;
+            Dyz = td2<1, 2>(T, y, h, z, l) * s2;
+            Dxx = td2<0, 0>(T, x, w, x, w) * s2;
+            Dxy = td2<0, 1>(T, x, w, y, h) * s2;
+            Dxz = td2<0, 2>(T, x, w, z, l) * s2;
+            if (DUMP) {
+                const i64 i = (i64)z * wh + (i64)y * w + x;
+                dump.Dzz[i] = Dzz; dump.Dyy[i] = Dyy; dump.Dyz[i] = Dyz;
+                dump.Dxx[i] = Dxx; dump.Dxy[i] = Dxy; dump.Dxz[i] = Dxz;
+            } else {
+                // A response > 0 needs lambda2 <= 0 and lambda3 <= 0 (the two largest-magnitude eigenvalues).  Then
+                // trace = l1+l2+l3 <= |l2| + l2 + l3 = l3 <= 0.  So a trace that is positive by a margin far above the
+                // solver's rounding error (1e-9 of the matrix 1-norm vs ~1e-15) proves the response is exactly 0: at the first
+                // scale J stays the 0 it was cleared to, at later scales the voxel cannot beat J >= 0 -- no eigen-solver either
+                // way.  (NaN compares false: no skip.)
+                const double tr = (double)Dxx + (double)Dyy + (double)Dzz;
+                const double nrm = fabs((double)Dxx) + fabs((double)Dyy) + fabs((double)Dzz) + 2.0 * (fabs((double)Dxy) + fabs((double)Dxz) + fabs((double)Dyz));
+                surv = !(tr > 1e-9 * nrm);
+                if (!surv && z >= zs0 && z < zs1) zero_here = true;
+            }
+        }
+        if (!DUMP) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(surv);
+            if (m) {
+                unsigned int base = 0;
+                if ((tid & 63) == 0) base = atomicAdd(&s_cnt, (unsigned int)__builtin_popcountll(m));
+                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                if (surv) {
+                    const unsigned int p = base + (unsigned int)__builtin_popcountll(m & ((1ull << (tid & 63)) - 1ull));
+                    qh[0 * HT_REGION + p] = Dxx; qh[1 * HT_REGION + p] = Dxy; qh[2 * HT_REGION + p] = Dxz;
+                    qh[3 * HT_REGION + p] = Dyy; qh[4 * HT_REGION + p] = Dyz; qh[5 * HT_REGION + p] = Dzz;
+                    qi[p] = ((unsigned int)(z - z0) << 9) | (unsigned int)tid;
+                }
+            }
+        }
+        if (more) {
+            const int sl = s0 + 5; // plane z + 3 replaces plane z - 3
+            put(sl >= HT_RING ? sl - HT_RING : sl, na, nc);
+        }
+        s0 = s0 + 1 >= HT_RING ? 0 : s0 + 1;
         __syncthreads();
     }
-    if (x < w) {
-        const i64 i = row * w + x;
-        // six second derivatives, each x sigma^2 (frangi.cpp:319,339,345,368,374,380)
-        const float Dzz = d2(F, i, wh, z, l, wh, z, l, 1) * s2;
-        const float Dyy = d2(F, i, w, y, h, w, y, h, 1) * s2;
-        const float Dyz = d2(F, i, w, y, h, wh, z, l, 0) * s2;
-        const float Dxx = d2(F, i, 1, x, w, 1, x, w, 1) * s2;
-        const float Dxy = d2(F, i, 1, x, w, w, y, h, 0) * s2;
-        const float Dxz = d2(F, i, 1, x, w, wh, z, l, 0) * s2;
-        // Scales after the first only ever write when the response beats J >= 0, i.e. when it is > 0, which
-        // needs lambda2 <= 0 and lambda3 <= 0 (the two largest-magnitude eigenvalues).  Then
-        // trace = l1+l2+l3 <= |l2| + l2 + l3 = l3 <= 0.  So a trace that is positive by a margin far above
-        // the solver's rounding error (1e-9 of the matrix 1-norm vs ~1e-15) proves the response is exactly 0
-        // and the voxel is left untouched -- without running the eigen-solver.  (NaN compares false: no skip.)
-        bool skip = false;
-        if (!DUMP && !first) {
-            const double tr = (double)Dxx + (double)Dyy + (double)Dzz;
-            const double nrm = fabs((double)Dxx) + fabs((double)Dyy) + fabs((double)Dzz) + 2.0 * (fabs((double)Dxy) + fabs((double)Dxz) + fabs((double)Dyz));
-            skip = tr > 1e-9 * nrm;
-        }
-        if (DUMP) {
-            dump.Dzz[i] = Dzz; dump.Dyy[i] = Dyy; dump.Dyz[i] = Dyz;
-            dump.Dxx[i] = Dxx; dump.Dxy[i] = Dxy; dump.Dxz[i] = Dxz;
-        } else if (!skip) {
-            const int slot = atomicAdd(&s_cnt, 1); // order inside the block is irrelevant: voxels are independent
-            s_h[slot][0] = Dxx; s_h[slot][1] = Dxy; s_h[slot][2] = Dxz;
-            s_h[slot][3] = Dyy; s_h[slot][4] = Dyz; s_h[slot][5] = Dzz;
-            s_x[slot] = x;
+    if (DUMP) return;
+    if (zero_here) s_zero = 1;
+    __syncthreads();
+    if (tid == 0) {
+        Q.count[region] = s_cnt;
+        // the first scale writes every voxel (frangi.cpp:237-250): a voxel whose response is proven 0 takes part in Jmin / Jmax
+        // with that 0 (conditional atomics: min only falls, max only rises, a stale read costs one redundant atomic at most)
+        if (first && s_zero) {
+            const unsigned int z0o = f2ord(0.f);
+            if (z0o < __hip_atomic_load(&minmax[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&minmax[0], z0o);
+            if (z0o > __hip_atomic_load(&minmax[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&minmax[1], z0o);
         }
     }
-    if (DUMP) return;
-    __syncthreads();
-    if ((int)threadIdx.x < s_cnt) {
-        const float Dxx = s_h[threadIdx.x][0], Dxy = s_h[threadIdx.x][1], Dxz = s_h[threadIdx.x][2];
-        const float Dyy = s_h[threadIdx.x][3], Dyz = s_h[threadIdx.x][4], Dzz = s_h[threadIdx.x][5];
-        const i64 i = row * w + s_x[threadIdx.x];
-        {
-            double V[3][3], d[3];
-            V[0][0] = Dxx; V[0][1] = Dxy; V[0][2] = Dxz;
-            V[1][0] = Dxy; V[1][1] = Dyy; V[1][2] = Dyz;
-            V[2][0] = Dxz; V[2][1] = Dyz; V[2][2] = Dzz;
-            eigen3(V, d);
-            const double L2 = d[1], L3 = d[2];
-            const double a1 = fabs(d[0]), a2 = fabs(L2), a3 = fabs(L3);
-            const double Ra = a2 / a3;
-            const double Rb = a1 / sqrt(a2 * a3);
-            const double S = sqrt(a1 * a1 + a2 * a2 + a3 * a3);
-            const double expRa = (1 - exp(-((Ra * Ra) / (double)two_a2)));
-            const double expRb = exp(-((Rb * Rb) / (double)two_b2));
-            const double expS = (1 - exp(-(S * S) / (double)two_c2));
-            double vox = expRa * expRb * expS;
-            vox = (L2 > 0) ? 0 : vox;
-            vox = (L3 > 0) ? 0 : vox;
-            vox = (vox != vox) ? 0 : vox; // NaN -> 0
-            bool wr = first != 0;
-            if (!wr) wr = vox > (double)J[i];
-            if (wr) {
-                const float jf = (float)vox;
-                J[i] = jf;
-                Vx[i] = quant_dir(V[0][0]);
-                Vy[i] = quant_dir(V[1][0]);
-                Vz[i] = quant_dir(V[2][0]);
-                if (z >= zs0 && z < zs1) omin = omax = f2ord(jf); // Jmin / Jmax over the planes this context owns (z-slab sharding)
+}
+
+// ---- K4b: eigenvalues + vesselness of the queued voxels ------------------------------------------------------------------
+// SUB work-groups share a region and take its entries in turns of 256, so every wavefront but a region's last is full.  Only the
+// eigenVALUES are needed here (JAMA's d / e recurrences do not depend on the accumulated eigenvectors, so leaving V unused lets
+// the compiler drop that half of the arithmetic; the values are bit-identical): the direction bytes are produced where they are
+// consumed -- at the seeds (seed_dirs) or, on request, for the whole volume (v_fill) -- from the winning scale kept per voxel.
+constexpr int EQ_SUB = 8, EQ_BLOCK = 256;
+
+__global__ __launch_bounds__(EQ_BLOCK, 8) void eigen_queue(HessQueue Q, float *__restrict__ J, unsigned char *__restrict__ Sc, int w, int h, int tiles_x,
+                                                           int tiles_y, int zc0, float two_a2, float two_b2, float two_c2, int first, int scale,
+                                                           unsigned int *__restrict__ minmax, int zs0, int zs1)
+{
+    const unsigned int region = blockIdx.x / EQ_SUB, sub = blockIdx.x % EQ_SUB;
+    const unsigned int cnt = Q.count[region];
+    if (sub * EQ_BLOCK >= cnt) return;
+    unsigned int b = region;
+    const int bx = (int)(b % (unsigned)tiles_x); b /= (unsigned)tiles_x;
+    const int by = (int)(b % (unsigned)tiles_y);
+    const int bz = (int)(b / (unsigned)tiles_y);
+    const i64 wh = (i64)w * h;
+    const float *qh = Q.h + (size_t)region * 6 * HT_REGION;
+    const unsigned int *qi = Q.idx + (size_t)region * HT_REGION;
+    unsigned int omin = 0xffffffffu, omax = 0u;
+    for (unsigned int e = sub * EQ_BLOCK + threadIdx.x; e < cnt; e += EQ_SUB * EQ_BLOCK) {
+        const unsigned int code = qi[e];
+        const int z = zc0 + bz * HT_Z + (int)(code >> 9), y = by * HT_Y + (int)((code >> 6) & 7u), x = bx * HT_X + (int)(code & 63u);
+        const i64 i = (i64)z * wh + (i64)y * w + x;
+        double V[3][3], d[3];
+        const float Dxx = qh[0 * HT_REGION + e], Dxy = qh[1 * HT_REGION + e], Dxz = qh[2 * HT_REGION + e];
+        const float Dyy = qh[3 * HT_REGION + e], Dyz = qh[4 * HT_REGION + e], Dzz = qh[5 * HT_REGION + e];
+        V[0][0] = Dxx; V[0][1] = Dxy; V[0][2] = Dxz;
+        V[1][0] = Dxy; V[1][1] = Dyy; V[1][2] = Dyz;
+        V[2][0] = Dxz; V[2][1] = Dyz; V[2][2] = Dzz;
+        eigen3(V, d);
+        const double vox = vesselness(d, two_a2, two_b2, two_c2);
+        bool wr = first != 0;
+        if (!wr) wr = vox > (double)J[i];
+        if (wr) {
+            const float jf = (float)vox;
+            J[i] = jf;
+            Sc[i] = (unsigned char)scale;
+            if (z >= zs0 && z < zs1) { // Jmin / Jmax over the planes this context owns (z-slab sharding), on writes only (frangi.cpp:237,257)
+                const unsigned int oo = f2ord(jf);
+                omin = oo < omin ? oo : omin;
+                omax = oo > omax ? oo : omax;
             }
         }
     }
-    // Jmin/Jmax are updated only on writes (frangi.cpp:237-238,257-258).  Reduced per wavefront (two atomics
-    // per solving wave, no block barrier): waves with nothing to solve retire immediately and free their
-    // slots -- the fp64 solver is latency-bound, so resident idle waves would cost as much as busy ones.
-    if ((int)(threadIdx.x & ~63u) >= s_cnt) return; // wave-uniform
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned int m1 = __shfl_xor(omin, o), m2 = __shfl_xor(omax, o);
@@ -450,13 +587,48 @@ __global__ __launch_bounds__(HE_BLOCK, 8) void hessian_eigen(const float *__rest
         omax = m2 > omax ? m2 : omax;
     }
     if ((threadIdx.x & 63) == 0) {
-        // millions of same-address atomics serialise (~30 ns each): first look at the current extremes (a
-        // relaxed device-scope load; a stale value can only cause a redundant atomic, never a missed one --
-        // min only falls, max only rises) and touch them only when this wave improves on them
+        // millions of same-address atomics serialise (~30 ns each): look at the current extremes first (relaxed device-scope
+        // load; a stale value can only cause a redundant atomic, never a missed one) and touch them only to improve them
         const unsigned int cur_min = __hip_atomic_load(&minmax[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int cur_max = __hip_atomic_load(&minmax[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (omin < cur_min) atomicMin(&minmax[0], omin);
         if (omax > cur_max) atomicMax(&minmax[1], omax);
+    }
+}
+
+// ---- K4c: the direction bytes Vx, Vy, Vz (frangi.cpp:240-250) of single voxels: the axis eigenvector of the Hessian at the scale
+// that wrote J there (the first scale where no later one did), solved with the full JAMA routine -- the sign of the vector is
+// solver-defined.  `list` == nullptr: every voxel of the volume (pnr_get_frangi asking for V).
+struct ScaleVols {
+    const float *F[PNR_MAX_SIGMAS];
+    float s2[PNR_MAX_SIGMAS];
+};
+__global__ __launch_bounds__(256) void vdir_points(ScaleVols SV, const unsigned char *__restrict__ Sc, const i64 *__restrict__ list, i64 n, int w, int h, int l,
+                                                   unsigned char *__restrict__ ox, unsigned char *__restrict__ oy, unsigned char *__restrict__ oz, int packed)
+{
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const i64 i = list ? list[t] : t;
+    const i64 wh = (i64)w * h;
+    const int z = (int)(i / wh), y = (int)((i - (i64)z * wh) / w), x = (int)(i % w);
+    const int sc = Sc[i];
+    const float *F = SV.F[sc];
+    const float s2 = SV.s2[sc];
+    const float Dzz = d2(F, i, wh, z, l, wh, z, l, 1) * s2;
+    const float Dyy = d2(F, i, w, y, h, w, y, h, 1) * s2;
+    const float Dyz = d2(F, i, w, y, h, wh, z, l, 0) * s2;
+    const float Dxx = d2(F, i, 1, x, w, 1, x, w, 1) * s2;
+    const float Dxy = d2(F, i, 1, x, w, w, y, h, 0) * s2;
+    const float Dxz = d2(F, i, 1, x, w, wh, z, l, 0) * s2;
+    double V[3][3], d[3];
+    V[0][0] = Dxx; V[0][1] = Dxy; V[0][2] = Dxz;
+    V[1][0] = Dxy; V[1][1] = Dyy; V[1][2] = Dyz;
+    V[2][0] = Dxz; V[2][1] = Dyz; V[2][2] = Dzz;
+    eigen3(V, d);
+    if (packed) { // 3 bytes per list entry
+        ox[3 * t] = quant_dir(V[0][0]); ox[3 * t + 1] = quant_dir(V[1][0]); ox[3 * t + 2] = quant_dir(V[2][0]);
+    } else {
+        ox[i] = quant_dir(V[0][0]); oy[i] = quant_dir(V[1][0]); oz[i] = quant_dir(V[2][0]);
     }
 }
 
@@ -560,10 +732,12 @@ int pnr_ensure_frangi_buffers(pnr_ctx *c)
 {
     if (c->frangi_cap >= c->N && c->d_J) return PNR_OK;
     hipFree(c->d_tmpA); hipFree(c->d_tmpB); hipFree(c->d_J);
-    hipFree(c->d_Vx); hipFree(c->d_Vy); hipFree(c->d_Vz); hipFree(c->d_J8);
+    hipFree(c->d_Vx); hipFree(c->d_Vy); hipFree(c->d_Vz); hipFree(c->d_J8); hipFree(c->d_scale);
     c->d_tmpA = c->d_tmpB = c->d_J = nullptr;
-    c->d_Vx = c->d_Vy = c->d_Vz = c->d_J8 = nullptr;
+    c->d_Vx = c->d_Vy = c->d_Vz = c->d_J8 = c->d_scale = nullptr;
+    for (int s = 0; s < PNR_MAX_SIGMAS; s++) { hipFree(c->d_F[s]); c->d_F[s] = nullptr; }
     c->frangi_cap = 0;
+    c->have_v = c->have_scale = false;
     const size_t n = (size_t)c->N;
     PNR_HIP(hipMalloc(&c->d_tmpA, n * 4));
     PNR_HIP(hipMalloc(&c->d_tmpB, n * 4));
@@ -572,7 +746,45 @@ int pnr_ensure_frangi_buffers(pnr_ctx *c)
     PNR_HIP(hipMalloc(&c->d_Vy, n));
     PNR_HIP(hipMalloc(&c->d_Vz, n));
     PNR_HIP(hipMalloc(&c->d_J8, n));
+    PNR_HIP(hipMalloc(&c->d_scale, n));
     c->frangi_cap = c->N;
+    return PNR_OK;
+}
+
+// grow-only scratch: the per-scale Gaussian taps
+static int ensure_taps(pnr_ctx *c)
+{
+    if (!c->d_taps) PNR_HIP(hipMalloc(&c->d_taps, (size_t)PNR_MAX_SIGMAS * (2 * (2 * MAX_L + 1)) * 4));
+    return PNR_OK;
+}
+
+// the smoothed volume F of every scale stays resident (4 B/voxel and scale of the 288 GB): the direction bytes of a voxel are
+// computed from the F of the scale that won there, when and where they are needed
+static int ensure_scale_volume(pnr_ctx *c, int s)
+{
+    if (c->d_F[s]) return PNR_OK;
+    PNR_HIP(hipMalloc(&c->d_F[s], (size_t)c->frangi_cap * 4));
+    return PNR_OK;
+}
+
+// z-chunks of the Hessian stage and their survivor queue: a chunk holds at most 2^27 voxels (3.5 GB of queue at worst)
+static int hess_chunk_planes(const pnr_ctx *c)
+{
+    const i64 wh = c->w * c->h;
+    i64 cz = ((i64)1 << 27) / wh / HT_Z * HT_Z;
+    if (cz < HT_Z) cz = HT_Z;
+    return (int)std::min<i64>(cz, (c->l + HT_Z - 1) / HT_Z * HT_Z);
+}
+static int ensure_queue(pnr_ctx *c, size_t regions)
+{
+    if (c->q_regions >= regions) return PNR_OK;
+    PNR_HIP(hipDeviceSynchronize());
+    hipFree(c->d_qh); hipFree(c->d_qidx); hipFree(c->d_qcount);
+    c->d_qh = nullptr; c->d_qidx = nullptr; c->d_qcount = nullptr; c->q_regions = 0;
+    PNR_HIP(hipMalloc(&c->d_qh, regions * 6 * HT_REGION * 4));
+    PNR_HIP(hipMalloc(&c->d_qidx, regions * HT_REGION * 4));
+    PNR_HIP(hipMalloc(&c->d_qcount, regions * 4));
+    c->q_regions = regions;
     return PNR_OK;
 }
 
@@ -648,15 +860,22 @@ int pnr_gaussian_run(pnr_ctx *c, float sig, float *d_out)
 {
     int rc = check_grid(c);
     if (rc) return rc;
+    rc = ensure_taps(c);
+    if (rc) return rc;
     std::vector<float> gxy, gz;
     pnr::gaussian_taps(sig, gxy);
     pnr::gaussian_taps(sig / c->prm.zdist, gz);
-    float *d_taps = nullptr;
-    PNR_HIP(hipMalloc(&d_taps, (2 * (2 * MAX_L + 1)) * 4));
-    rc = gaussian3d(c, gxy, gz, d_taps, d_out);
+    rc = gaussian3d(c, gxy, gz, c->d_taps, d_out);
     hipStreamSynchronize(c->stream);
-    hipFree(d_taps);
     return rc;
+}
+
+// launches of the Hessian stencil over the z-chunk [zc0, zc1)
+static void tile_grid(const pnr_ctx *c, int zc0, int zc1, int &tiles_x, int &tiles_y, unsigned &blocks)
+{
+    tiles_x = (int)((c->w + HT_X - 1) / HT_X);
+    tiles_y = (int)((c->h + HT_Y - 1) / HT_Y);
+    blocks = (unsigned)((i64)tiles_x * tiles_y * ((zc1 - zc0 + HT_Z - 1) / HT_Z));
 }
 
 int pnr_hessian_run(pnr_ctx *c, float sig, float *const d_out[6])
@@ -664,14 +883,48 @@ int pnr_hessian_run(pnr_ctx *c, float sig, float *const d_out[6])
     int rc = pnr_gaussian_run(c, sig, c->d_tmpA);
     if (rc) return rc;
     const int w = (int)c->w, h = (int)c->h, l = (int)c->l;
-    const int tiles_x = (w + HE_BLOCK - 1) / HE_BLOCK;
     HessOut dump{d_out[0], d_out[1], d_out[2], d_out[3], d_out[4], d_out[5]};
-    hipLaunchKernelGGL(hessian_eigen<true>, dim3((unsigned)((i64)h * l * tiles_x)), dim3(HE_BLOCK), 0, c->stream, c->d_tmpA,
-                       (float *)nullptr, (unsigned char *)nullptr, (unsigned char *)nullptr, (unsigned char *)nullptr, w, h,
-                       l, tiles_x, sig * sig, 0.f, 0.f, 0.f, 1, (unsigned int *)nullptr, dump);
+    int tiles_x, tiles_y;
+    unsigned blocks;
+    tile_grid(c, 0, l, tiles_x, tiles_y, blocks);
+    hipLaunchKernelGGL(hessian_tile<true>, dim3(blocks), dim3(HT_THREADS), 0, c->stream, (const float *)c->d_tmpA, w, h, l, tiles_x, tiles_y, 0, l,
+                       sig * sig, HessQueue{}, (unsigned int *)nullptr, 1, 0, l, dump);
     PNR_HIP(hipGetLastError());
     PNR_HIP(hipStreamSynchronize(c->stream));
     return PNR_OK;
+}
+
+// Vx / Vy / Vz of the whole volume (pnr_get_frangi asking for them): not needed by the pipeline, which takes the directions at
+// the seeds only (pnr_seed_dirs)
+int pnr_frangi_materialise_v(pnr_ctx *c)
+{
+    if (c->have_v) return PNR_OK;
+    PNR_REQUIRE(c->have_scale, PNR_E_STATE, "no Frangi response: the direction volumes cannot be produced");
+    ScaleVols SV{};
+    for (int s = 0; s < c->prm.nsig; s++) { SV.F[s] = c->d_F[s]; SV.s2[s] = c->prm.sig[s] * c->prm.sig[s]; }
+    hipLaunchKernelGGL(vdir_points, dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, SV, (const unsigned char *)c->d_scale, (const i64 *)nullptr,
+                       (i64)c->N, (int)c->w, (int)c->h, (int)c->l, c->d_Vx, c->d_Vy, c->d_Vz, 0);
+    PNR_HIP(hipGetLastError());
+    PNR_HIP(hipStreamSynchronize(c->stream));
+    c->have_v = true;
+    return PNR_OK;
+}
+
+// direction bytes at `n` voxels (device list) -> d_dirs[3n]: from the direction volumes when they exist (pnr_set_j8_v, 2-D
+// stacks, after pnr_get_frangi), otherwise solved on the spot from the winning scale's smoothed volume
+int pnr_seed_dirs(pnr_ctx *c, const long long *d_idx, int n, unsigned char *d_dirs)
+{
+    if (n == 0) return PNR_OK;
+    if (!c->have_v) {
+        PNR_REQUIRE(c->have_scale, PNR_E_STATE, "no direction field: run pnr_frangi (or pnr_set_j8_v) first");
+        ScaleVols SV{};
+        for (int s = 0; s < c->prm.nsig; s++) { SV.F[s] = c->d_F[s]; SV.s2[s] = c->prm.sig[s] * c->prm.sig[s]; }
+        hipLaunchKernelGGL(vdir_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, SV, (const unsigned char *)c->d_scale, (const i64 *)d_idx,
+                           (i64)n, (int)c->w, (int)c->h, (int)c->l, d_dirs, (unsigned char *)nullptr, (unsigned char *)nullptr, 1);
+        PNR_HIP(hipGetLastError());
+        return PNR_OK;
+    }
+    return 1; // the caller gathers from the volumes
 }
 
 // J -> J8 with the given extremes (Advantra_plugin.cpp:2499-2512)
@@ -705,36 +958,68 @@ int pnr_frangi_run_range(pnr_ctx *c, int64_t zs0, int64_t zs1, bool finish, floa
     if (rc) return rc;
     rc = pnr_ensure_frangi_buffers(c);
     if (rc) return rc;
+    rc = ensure_taps(c);
+    if (rc) return rc;
     const int w = (int)c->w, h = (int)c->h, l = (int)c->l;
     const pnr_params &P = c->prm;
-    float *d_taps = nullptr;
-    PNR_HIP(hipMalloc(&d_taps, (size_t)P.nsig * (2 * (2 * MAX_L + 1)) * 4));
     const unsigned int init[2] = {0xffffffffu, 0u};
     PNR_HIP(hipMemcpyAsync(c->d_minmax, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    c->have_v = c->have_scale = false;
     // f32 products, as "2*alpha*alpha" etc. in frangi.cpp:214-216
     const float two_a2 = 2 * P.alpha * P.alpha, two_b2 = 2 * P.beta * P.beta, two_c2 = 2 * P.C * P.C;
+    const int cz = hess_chunk_planes(c);
+    if (l > 1) {
+        int tx, ty;
+        unsigned blocks;
+        tile_grid(c, 0, std::min(cz, l), tx, ty, blocks);
+        rc = ensure_queue(c, blocks);
+        if (rc) return rc;
+        // the first scale writes every voxel; those whose response is proven 0 without the solver keep this 0 (and scale 0)
+        PNR_HIP(hipMemsetAsync(c->d_J, 0, (size_t)c->N * 4, c->stream));
+        PNR_HIP(hipMemsetAsync(c->d_scale, 0, (size_t)c->N, c->stream));
+    }
     for (int s = 0; s < P.nsig; s++) {
-        rc = gaussian3d(c, c->tab.gxy[s], c->tab.gz[s], d_taps + (size_t)s * (2 * (2 * MAX_L + 1)), c->d_tmpA);
-        if (rc) { hipFree(d_taps); return rc; }
-        const int tiles_x = (w + HE_BLOCK - 1) / HE_BLOCK;
-        c->tic();
+        float *Fs = c->d_tmpA;
+        if (l > 1) {
+            rc = ensure_scale_volume(c, s);
+            if (rc) return rc;
+            Fs = c->d_F[s];
+        }
+        rc = gaussian3d(c, c->tab.gxy[s], c->tab.gz[s], c->d_taps + (size_t)s * (2 * (2 * MAX_L + 1)), Fs);
+        if (rc) return rc;
         if (l == 1) { // P == 1: frangi2d (Advantra_plugin.cpp:2496-2497) with frangi_betaone = .5, frangi_betatwo = 15 (:69-70)
+            c->tic();
             const float beta2d = (float)(2 * std::pow((double).5f, 2)), c2d = (float)(2 * std::pow((double)15.f, 2));
-            hipLaunchKernelGGL(frangi2d_pixel, dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, (const float *)c->d_tmpA, c->d_J,
+            hipLaunchKernelGGL(frangi2d_pixel, dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, (const float *)Fs, c->d_J,
                                c->d_Vx, c->d_Vy, c->d_Vz, w, h, P.sig[s] * P.sig[s], beta2d, c2d, s == 0 ? 1 : 0, c->d_minmax);
-        } else
-        hipLaunchKernelGGL(hessian_eigen<false>, dim3((unsigned)((i64)h * l * tiles_x)), dim3(HE_BLOCK), 0, c->stream, c->d_tmpA,
-                           c->d_J, c->d_Vx, c->d_Vy, c->d_Vz, w, h, l, tiles_x, P.sig[s] * P.sig[s], two_a2, two_b2, two_c2,
-                           s == 0 ? 1 : 0, c->d_minmax, HessOut{}, (int)zs0, (int)zs1);
-        c->toc("hessian_eigen");
+            c->toc("hessian_eigen");
+            continue;
+        }
+        for (int zc0 = 0; zc0 < l; zc0 += cz) {
+            const int zc1 = std::min(l, zc0 + cz);
+            int tiles_x, tiles_y;
+            unsigned blocks;
+            tile_grid(c, zc0, zc1, tiles_x, tiles_y, blocks);
+            const HessQueue Q{c->d_qh, c->d_qidx, c->d_qcount};
+            c->tic();
+            hipLaunchKernelGGL(hessian_tile<false>, dim3(blocks), dim3(HT_THREADS), 0, c->stream, (const float *)Fs, w, h, l, tiles_x, tiles_y, zc0, zc1,
+                               P.sig[s] * P.sig[s], Q, c->d_minmax, s == 0 ? 1 : 0, (int)zs0, (int)zs1, HessOut{});
+            c->toc("hessian_tile");
+            c->tic();
+            hipLaunchKernelGGL(eigen_queue, dim3(blocks * EQ_SUB), dim3(EQ_BLOCK), 0, c->stream, Q, c->d_J, c->d_scale, w, h, tiles_x, tiles_y, zc0,
+                               two_a2, two_b2, two_c2, s == 0 ? 1 : 0, s, c->d_minmax, (int)zs0, (int)zs1);
+            c->toc("hessian_eigen");
+        }
     }
     unsigned int mm[2];
     PNR_HIP(hipMemcpyAsync(mm, c->d_minmax, sizeof(mm), hipMemcpyDeviceToHost, c->stream));
     PNR_HIP(hipStreamSynchronize(c->stream));
-    hipFree(d_taps);
+    PNR_HIP(hipGetLastError());
     c->Jmin = ord2f(mm[0]);
     c->Jmax = ord2f(mm[1]);
     c->have_j8 = false;
+    c->have_scale = l > 1;
+    c->have_v = l == 1; // the 2-D kernel writes the direction bytes itself
     if (finish) {
         rc = pnr_j8_run(c, c->Jmin, c->Jmax);
         if (rc) return rc;

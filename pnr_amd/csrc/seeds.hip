@@ -334,8 +334,11 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
         PNR_HIP(hipMalloc(&d_idx, (size_t)ns * 8));
         PNR_HIP(hipMalloc(&d_dirs, (size_t)ns * 3));
         PNR_HIP(hipMemcpyAsync(d_idx, vox.data(), (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(gather_dirs, dim3((ns + 255) / 256), dim3(256), 0, c->stream, c->d_Vx, c->d_Vy, c->d_Vz, d_idx, ns,
-                           d_dirs);
+        const int how = pnr_seed_dirs(c, d_idx, ns, d_dirs); // solved at the seeds from the winning scale's smoothed volume ...
+        if (how < 0) { hipFree(d_idx); hipFree(d_dirs); return how; }
+        if (how == 1) // ... or gathered from the direction volumes when those exist
+            hipLaunchKernelGGL(gather_dirs, dim3((ns + 255) / 256), dim3(256), 0, c->stream, c->d_Vx, c->d_Vy, c->d_Vz, d_idx, ns,
+                               d_dirs);
         PNR_HIP(hipMemcpyAsync(dirs.data(), d_dirs, (size_t)ns * 3, hipMemcpyDeviceToHost, c->stream));
         PNR_HIP(hipStreamSynchronize(c->stream));
         hipFree(d_idx);

@@ -259,6 +259,7 @@ int pnr_soma_run(pnr_ctx *c, uint8_t *E8_out, int32_t *threshold)
     PNR_HIP(hipMemcpyAsync(d_G, G.data(), G.size() * 4, hipMemcpyHostToDevice, st));
     PNR_HIP(hipMemsetAsync(d_hist, 0, 256 * 8, st));
     unsigned char *d_K = c->d_Vx, *d_E = c->d_Vy;
+    c->have_v = false; // the direction volumes serve as scratch here
     const unsigned nb = (unsigned)((n + SOMA_BLOCK - 1) / SOMA_BLOCK);
     c->tic();
     hipLaunchKernelGGL(erode_x, dim3(nb), dim3(SOMA_BLOCK), 0, st, c->d_img, d_K, w, n, Le);
