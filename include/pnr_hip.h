@@ -189,6 +189,12 @@ int pnr_trace_replay(pnr_ctx *ctx, const pnr_seed *seeds, int64_t n, int64_t fir
 int pnr_get_graph(pnr_ctx *ctx, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links,
                   int64_t *n_links);
 
+/* How every replayed trace of the last pnr_trace_replay[_sharded] ended -- what the reference prints per trace at
+ * tracker.cpp:866,879,908,916 -- when the option "trace_log" is set: 5 ints per trace, in replay order:
+ * {seed rank, direction (0 = trackPos, 1 = trackNeg), ti_limit, reason, value}; reason 0 = TRACK LIMIT (value: bits of the last
+ * corr), 1 = success=0 (value: bits of the failing iteration's corr), 2 = DENSITY (value: nodepervol), 3 = SOMA (value: node). */
+int pnr_get_trace_log(pnr_ctx *ctx, int32_t *rec, int64_t cap, int64_t *n);
+
 /* ---- one stack, several GPUs: the sorted seeds sharded over `world` processes (one pnr_ctx per GPU; BASELINE configs[3]) ----
  * The reference has no distributed code; what is kept is the result of its sequential trace loop
  * (Advantra_plugin.cpp:2658-2710).  Rank r traces the seeds r, r + world, ... of the SAME sorted list in its own window of trace
@@ -239,7 +245,7 @@ int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
  *   poll (4) SMC steps between polls | groups (1..4) trace groups on separate streams | split_x10 (40), max_split (24) sampling
  *   work-groups per CU x 10 / per trace | stash_mb (65536) sample-stash budget | host_threads (0 = CPUs of this process /
  *   local_ranks) workers of the seed flood fill and of pnr_reconstruct_ctx | local_ranks (1) processes sharing this host |
- *   trace_timing, seed_timing (0/1) statistics on stderr | replay_batches (0/1), batch_growth, batch_max: rank batches instead
+ *   trace_timing, seed_timing (0/1) statistics on stderr | trace_log (0/1) keep every trace's end for pnr_get_trace_log | replay_batches (0/1), batch_growth, batch_max: rank batches instead
  *   of the streaming window | no_stash (0/1) persistent driver without the sample stash | exchange_block (262144) bytes per rank
  *   and exchange of pnr_trace_replay_sharded.   pnr_get_option also knows "host_threads_effective". */
 int pnr_set_option(pnr_ctx *ctx, const char *key, int64_t value);

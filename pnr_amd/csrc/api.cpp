@@ -206,6 +206,7 @@ void pnr_destroy(pnr_ctx *c)
     hipFree(c->d_p); hipFree(c->d_u); hipFree(c->d_w0); hipFree(c->d_w0cws); hipFree(c->d_v); hipFree(c->d_w);
     hipFree(c->d_wcws); hipFree(c->d_tmpl); hipFree(c->d_corrc); hipFree(c->d_sig); hipFree(c->d_M); hipFree(c->d_moff);
     hipFree(c->d_rng); hipFree(c->d_grid); hipFree(c->d_axes); hipFree(c->d_axes_off); hipFree(c->d_wd);
+    for (auto &kv : c->scratch) hipFree(kv.second.p);
     c->resolve_timers();
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -537,6 +538,15 @@ int pnr_get_graph(pnr_ctx *c, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nod
     return PNR_OK;
 }
 
+int pnr_get_trace_log(pnr_ctx *c, int32_t *rec, int64_t cap, int64_t *n)
+{
+    PNR_REQUIRE(c && n, PNR_E_ARG, "null argument");
+    PNR_REQUIRE(c->have_graph, PNR_E_STATE, "no node graph: pnr_trace_replay has not run");
+    *n = (int64_t)c->graph_log.size() / 5;
+    if (rec) std::memcpy(rec, c->graph_log.data(), 20 * (size_t)std::min<int64_t>(cap, *n));
+    return PNR_OK;
+}
+
 static int trace_replay_impl(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64_t first_batch, const pnr::ShardSpec &sh, pnr_node *nodes,
                              int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used,
                              int64_t *n_iterations)
@@ -549,6 +559,9 @@ static int trace_replay_impl(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64
     c->have_graph = false;
     pnr::Replayer r(c->prm, c->w, c->h, c->l);
     r.set_soma(&c->soma_map, c->soma_nodes);
+    std::vector<pnr::Replayer::TraceEnd> ends;
+    if (c->opt.trace_log) r.log = &ends;
+    c->graph_log.clear();
     int rc = pnr_density_reset(c);
     if (rc) return rc;
     int64_t iters = 0;
@@ -593,10 +606,12 @@ static int trace_replay_impl(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64
             fprintf(stderr, "[pnr trace] batch of %lld seeds launched: %lld iterations, longest trace %lld, nodes so far %zu\n", (long long)m,
                     (long long)bi, (long long)bmax, r.nodes.size());
         r.touched.clear();
+        r.log_base = (int64_t)ends.size() / 2; // (batch mode: rank among the launched seeds)
         r.add(bs.data(), m, T.data(), xc.data());
         rc = pnr_density_update(c, r);
         if (rc) return rc;
     }
+    for (const auto &e : ends) c->graph_log.insert(c->graph_log.end(), {e.seed, e.dir, e.ti_limit, e.reason, e.value});
     if (n_iterations) *n_iterations = iters;
     return store_graph(c, r, nodes, cap_nodes, n_nodes, links, cap_links, n_links, n_traces_used);
 }
@@ -733,6 +748,7 @@ const OptEntry OPTS[] = {
     {"max_split", &pnr::Options::max_split, nullptr, 1, 4096},   {"stash_mb", nullptr, &pnr::Options::stash_mb, 1, 1 << 20},
     {"host_threads", &pnr::Options::host_threads, nullptr, 0, 1024}, {"local_ranks", &pnr::Options::local_ranks, nullptr, 1, 1024},
     {"trace_timing", &pnr::Options::trace_timing, nullptr, 0, 1}, {"seed_timing", &pnr::Options::seed_timing, nullptr, 0, 1},
+    {"trace_log", &pnr::Options::trace_log, nullptr, 0, 1},
     {"replay_batches", &pnr::Options::replay_batches, nullptr, 0, 1}, {"batch_growth", &pnr::Options::batch_growth, nullptr, 100, 100000},
     {"batch_max", &pnr::Options::batch_max, nullptr, 1, 1 << 24}, {"no_stash", &pnr::Options::no_stash, nullptr, 0, 1},
     {"exchange_block", nullptr, &pnr::Options::exchange_block, 1024, 1 << 28},

@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/pnr_hip.h"
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <map>
@@ -66,6 +67,7 @@ struct Options {
     int host_threads = 0;     // host worker threads of the seed flood fill / reconstruct(); 0 = hardware threads / local_ranks
     int local_ranks = 1;      // processes that share this host (one per GPU)
     int trace_timing = 0, seed_timing = 0; // statistics on stderr
+    int trace_log = 0;        // keep how every replayed trace ended (pnr_get_trace_log)
     int replay_batches = 0;   // 1: seed-rank batches instead of the streaming window (always so with the persistent driver)
     int batch_growth = 200, batch_max = 1024;
     int no_stash = 0;         // persistent driver: in-lane two-pass sums
@@ -152,6 +154,7 @@ struct pnr_ctx {
     std::vector<int32_t> graph_links;
     int graph_traces = 0;
     bool have_graph = false;
+    std::vector<int32_t> graph_log; // 5 ints per replayed trace (option "trace_log")
 
     // profiling: HIP event pairs recorded on the ctx stream around each kernel group, resolved
     // lazily (no host sync inside the timed region)
@@ -166,6 +169,30 @@ struct pnr_ctx {
     std::vector<hipEvent_t> free_events;
     hipEvent_t cur_a = nullptr;
     std::map<std::string, pnr::KernelTimer> timers;
+
+    // grow-only named device scratch (per-layer tables, candidate keys, ...): nothing is allocated or freed inside a timed stage
+    // once the first pass has sized it
+    struct DevScratch { void *p = nullptr; size_t cap = 0; };
+    std::map<std::string, DevScratch> scratch;
+    template <typename T>
+    int scratch_get(const char *name, size_t count, T **out)
+    {
+        DevScratch &b = scratch[name];
+        const size_t need = std::max<size_t>(count, 1) * sizeof(T);
+        if (b.cap < need) {
+            if (b.p) (void)hipFree(b.p); // (synchronises the device)
+            b.p = nullptr;
+            b.cap = 0;
+            const size_t cap = need + need / 2;
+            if (hipMalloc(&b.p, cap) != hipSuccess) {
+                pnr::set_error("hipMalloc of %zu B for scratch '%s' failed", cap, name);
+                return PNR_E_NOMEM;
+            }
+            b.cap = cap;
+        }
+        *out = (T *)b.p;
+        return PNR_OK;
+    }
 
     hipEvent_t get_event()
     {

@@ -56,6 +56,11 @@ struct Replayer {
     int trace_count = 0;
     bool stopped = false;          // MAX_TRACE_COUNT reached (:2702)
     const std::unordered_map<int64_t, int32_t> *soma = nullptr; // smap: voxel -> index of its SOMA node (> 0)
+    // optional per-trace record of how the trace ended, what the reference prints at tracker.cpp:866,879,908,916:
+    // {seed rank, direction, ti_limit, reason (0 TRACK LIMIT, 1 success=0, 2 DENSITY, 3 SOMA), value (corr bits / nodespervol / soma index)}
+    struct TraceEnd { int32_t seed, dir, ti_limit, reason, value; };
+    std::vector<TraceEnd> *log = nullptr;
+    int64_t log_base = 0; // rank of seeds[0] of the next add()
 
     Replayer(const pnr_params &p, int64_t w, int64_t h, int64_t l) : prm(p), W((int)w), H((int)h), L((int)l)
     {
@@ -107,18 +112,20 @@ struct Replayer {
                 const int64_t j = 2 * s + dir;
                 const pnr_xest *X = xc + j * ni;
                 int ti_limit = ni;
+                int why = 0, val = 0; // TRACK LIMIT unless something ends the trace before
+                if (ni > 0) std::memcpy(&val, &X[ni - 1].corr, 4);
                 for (int i = 0; i < ni; i++) {
-                    if (i >= T[j]) { ti_limit = i; break; } // iter*New returned false
+                    if (i >= T[j]) { ti_limit = i; why = 1; std::memcpy(&val, &X[i].corr, 4); break; } // iter*New returned false
                     const pnr_xest &e = X[i];
                     const int64_t crd = voxel(e.x, e.y, e.z);
                     if (const int sn = soma_at(crd)) { // soma reached: link with its node, stop the trace (tracker.cpp:858-869)
                         if (i > 0) { links.push_back(sn); links.push_back((int32_t)(nodes.size() - 1)); }
-                        ti_limit = i;
+                        ti_limit = i; why = 3; val = sn;
                         break;
                     }
                     if (den_at(crd) >= prm.nodepervol) { // density limit: link to the node that owns the voxel
                         if (i > 0) { links.push_back(cells[crd].nidx); links.push_back((int32_t)(nodes.size() - 1)); }
-                        ti_limit = i;
+                        ti_limit = i; why = 2; val = prm.nodepervol;
                         break;
                     }
                     nodes.push_back(pnr_node{e.x, e.y, e.z, e.vx, e.vy, e.vz, e.corr, e.sig, (i == 0) ? 7 : 2});
@@ -132,6 +139,7 @@ struct Replayer {
                     if (i > 0) { links.push_back(me); links.push_back(me - 1); }
                 }
                 if (ti_limit > 1) nodes.back().type = 6; // END (tracker.cpp:930-931)
+                if (log) log->push_back(TraceEnd{(int32_t)(log_base + s), dir, ti_limit, why, val});
             }
             if (trace_count > maxtr) stopped = true; // :2702
         }

@@ -225,11 +225,12 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     unsigned int *d_cnt = nullptr;
     float *d_vf = nullptr;
     i64 *d_off = nullptr, *d_keys = nullptr;
-    PNR_HIP(hipMalloc(&d_min, nl * 4));
-    PNR_HIP(hipMalloc(&d_max, nl * 4));
-    PNR_HIP(hipMalloc(&d_cnt, nl * 4));
-    PNR_HIP(hipMalloc(&d_vf, nl * 4));
-    PNR_HIP(hipMalloc(&d_off, (nl + 1) * 8));
+    int rc = c->scratch_get("seed_min", (size_t)nl, &d_min); // context-owned scratch, sized by the first pass
+    if (!rc) rc = c->scratch_get("seed_max", (size_t)nl, &d_max);
+    if (!rc) rc = c->scratch_get("seed_cnt", (size_t)nl, &d_cnt);
+    if (!rc) rc = c->scratch_get("seed_vf", (size_t)nl, &d_vf);
+    if (!rc) rc = c->scratch_get("seed_off", (size_t)nl + 1, &d_off);
+    if (rc) return rc;
     std::vector<int> vmin(nl), vmax(nl);
     std::vector<unsigned int> cnt(nl);
     std::vector<float> vf(nl);
@@ -281,7 +282,8 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     const i64 total = off[nl];
     std::vector<i64> keys((size_t)total);
     if (total > 0) {
-        PNR_HIP(hipMalloc(&d_keys, (size_t)total * 8));
+        rc = c->scratch_get("seed_keys", (size_t)total, &d_keys);
+        if (rc) return rc;
         PNR_HIP(hipMemcpyAsync(d_off, off.data(), (nl + 1) * 8, hipMemcpyHostToDevice, c->stream));
         PNR_HIP(hipMemcpyAsync(d_vf, vf.data(), nl * 4, hipMemcpyHostToDevice, c->stream));
         PNR_HIP(hipMemsetAsync(d_cnt, 0, nl * 4, c->stream));
@@ -331,18 +333,17 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     if (ns > 0) {
         i64 *d_idx = nullptr;
         unsigned char *d_dirs = nullptr;
-        PNR_HIP(hipMalloc(&d_idx, (size_t)ns * 8));
-        PNR_HIP(hipMalloc(&d_dirs, (size_t)ns * 3));
+        rc = c->scratch_get("seed_idx", (size_t)ns, &d_idx);
+        if (!rc) rc = c->scratch_get("seed_dirs", (size_t)ns * 3, &d_dirs);
+        if (rc) return rc;
         PNR_HIP(hipMemcpyAsync(d_idx, vox.data(), (size_t)ns * 8, hipMemcpyHostToDevice, c->stream));
         const int how = pnr_seed_dirs(c, d_idx, ns, d_dirs); // solved at the seeds from the winning scale's smoothed volume ...
-        if (how < 0) { hipFree(d_idx); hipFree(d_dirs); return how; }
+        if (how < 0) return how;
         if (how == 1) // ... or gathered from the direction volumes when those exist
             hipLaunchKernelGGL(gather_dirs, dim3((ns + 255) / 256), dim3(256), 0, c->stream, c->d_Vx, c->d_Vy, c->d_Vz, d_idx, ns,
                                d_dirs);
         PNR_HIP(hipMemcpyAsync(dirs.data(), d_dirs, (size_t)ns * 3, hipMemcpyDeviceToHost, c->stream));
         PNR_HIP(hipStreamSynchronize(c->stream));
-        hipFree(d_idx);
-        hipFree(d_dirs);
     }
     c->seeds.resize(ns);
     for (int i = 0; i < ns; i++) {
@@ -355,7 +356,6 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
         const float Un = (float)std::sqrt((double)Ux * Ux + (double)Uy * Uy + (double)Uz * Uz); // pow(f,2): f64
         c->seeds[i] = pnr_seed{(float)x, (float)y, (float)z, Ux / Un, Uy / Un, Uz / Un, 0.f, 0.f};
     }
-    hipFree(d_min); hipFree(d_max); hipFree(d_cnt); hipFree(d_vf); hipFree(d_off); hipFree(d_keys);
     if (timing)
         fprintf(stderr, "[pnr seeds] kernels + keys %.1f ms (J8 download overlapped), host fill %.1f ms (%u threads, %lld candidates), dirs+free %.1f ms\n",
                 1e3 * (t_gpu - t_start), 1e3 * (t_fill - t_gpu), (unsigned)pnr::host_threads(c->opt), (long long)total, 1e3 * (now() - t_fill));

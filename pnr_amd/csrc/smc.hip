@@ -703,13 +703,13 @@ int pnr_density_reset(pnr_ctx *c)
         const size_t n = c->soma_vox.size();
         long long *d_idx = nullptr;
         unsigned char *d_val = nullptr;
-        PNR_HIP(hipMalloc(&d_idx, n * 8));
-        PNR_HIP(hipMalloc(&d_val, n));
+        int rc = c->scratch_get("soma_den_idx", n, &d_idx);
+        if (!rc) rc = c->scratch_get("soma_den_val", n, &d_val);
+        if (rc) return rc;
         PNR_HIP(hipMemcpyAsync(d_idx, c->soma_vox.data(), n * 8, hipMemcpyHostToDevice, c->stream));
         PNR_HIP(hipMemsetAsync(d_val, 0xff, n, c->stream));
         hipLaunchKernelGGL(den_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_den, (const i64 *)d_idx, (const unsigned char *)d_val, (int)n);
         PNR_HIP(hipStreamSynchronize(c->stream));
-        hipFree(d_idx); hipFree(d_val);
     }
     return PNR_OK;
 }

@@ -58,7 +58,7 @@ public:
     virtual int launch(int g, int active, int poll) = 0;
     // block until the last launch of group g has landed; *active = traces of the group still running
     virtual int wait(int g, int *active) = 0;
-    // after wait(g): has the trace in `slot` stopped?  *T = its successful iterations; rows() = its min(T, ni) estimates
+    // after wait(g): has the trace in `slot` stopped?  *T = its successful iterations; rows() = its min(T + 1, ni) estimates
     virtual bool finished(int g, int slot, int *T) const = 0;
     virtual const pnr_xest *rows(int slot) const = 0;
     // push the density of the voxels in r.touched (final values r.den_at) to the engine's map
@@ -196,7 +196,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                 const int slot = q.busy[b];
                 int Tn = 0;
                 if (!E.finished(g, slot, &Tn)) { q.busy[keep++] = slot; continue; }
-                const int rows = std::min(std::max(Tn, 0), ni);
+                const int rows = std::min(std::max(Tn, 0) + 1, ni); // + the iteration that failed (its corr is what the reference prints)
                 const size_t at = outbox.size();
                 outbox.resize(at + 4 + (size_t)rows * 8);
                 outbox[at] = (int32_t)slot_seed[(size_t)slot]; outbox[at + 1] = slot_dir[(size_t)slot]; outbox[at + 2] = Tn; outbox[at + 3] = rows;
@@ -226,6 +226,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             SeedRec &sr = rec[(size_t)frontier];
             if (!sr.skipped && sr.have < 2) break;
             if (!sr.skipped) { // (a skipped seed sits on a saturated voxel: the replay would skip it as well)
+                r.log_base = frontier;
                 r.add(&seeds[frontier], 1, sr.T, sr.xc.data());
                 std::vector<pnr_xest>().swap(sr.xc);
             }

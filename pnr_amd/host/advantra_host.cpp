@@ -13,6 +13,12 @@ namespace advantra {
 
 static const int nrInputParams = 11; // Advantra_plugin.cpp:60
 
+Settings &settings()
+{
+    static Settings s;
+    return s;
+}
+
 void print_help()
 {
     // wording of the reference's print_help (Advantra_plugin.cpp:125-148), shortened to the call contract
@@ -49,6 +55,7 @@ struct Reader {
     {
         const size_t sz = (type == 3) ? 2 : (type == 4 ? 4 : 1);
         size_t off = (sz * count <= 4) ? field : u32(field);
+        if (off > buf.size() || (size_t)count > (buf.size() - off) / sz) return {}; // a count the file cannot hold: nothing is allocated for it
         std::vector<uint32_t> v(count);
         for (uint32_t i = 0; i < count; i++) {
             if (off + sz > buf.size()) return {};
@@ -73,8 +80,12 @@ static bool load_tiff(const std::string &path, Stack &out, std::string &err)
     size_t ifd = r.u32(4);
     out.data.clear();
     out.w = out.h = out.l = 0;
+    std::vector<size_t> seen; // IFD offsets visited: a chain that revisits one would never end
     while (ifd != 0) {
         if (ifd + 2 > r.buf.size()) { err = "truncated TIFF"; return false; }
+        if (std::find(seen.begin(), seen.end(), ifd) != seen.end()) { err = "TIFF directory chain loops"; return false; }
+        seen.push_back(ifd);
+        if (seen.size() > (1u << 20)) { err = "TIFF with more than 2^20 pages"; return false; }
         const uint16_t n = r.u16(ifd);
         uint32_t w = 0, h = 0, bps = 1, comp = 1, spp = 1, rps = 0xffffffffu;
         std::vector<uint32_t> soff, scnt;
@@ -98,6 +109,7 @@ static bool load_tiff(const std::string &path, Stack &out, std::string &err)
         }
         if (bps != 8 || spp != 1) { err = "only 8-bit single-channel stacks are supported (the reference assumes uint8, Advantra_plugin.cpp:2255)"; return false; }
         if (comp != 1) { err = "compressed TIFF is not supported"; return false; }
+        if (w == 0 || h == 0 || (uint64_t)w * h > r.buf.size()) { err = "TIFF page larger than the file"; return false; } // uncompressed: w*h bytes must be in the file
         if (out.l == 0) { out.w = w; out.h = h; }
         else if (w != out.w || h != out.h) { err = "pages of different size"; return false; }
         (void)rps;
@@ -287,7 +299,7 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
 {
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    p.rng_seed = getenv("PNR_RNG_SEED") ? (uint32_t)strtoul(getenv("PNR_RNG_SEED"), nullptr, 10) : 42u;
+    p.rng_seed = settings().rng_seed;
     printf("-------------  ADVANTRA  -------------\n");
     pnr_ctx *ctx = nullptr;
     if (pnr_create(&p, device, &ctx) != PNR_OK || pnr_set_volume(ctx, data1d, w, h, l) != PNR_OK) {
@@ -326,13 +338,37 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
     int64_t nn = 0, nl = 0, used = 0, iters = 0;
     if (ok) {
         printf("seed selection & sorting... %gk seeds, %g sec.\ntracing...\n", nseeds / 1000.0, secs(t2, t3));
-        int64_t cap = 1 << 16;
-        for (;;) { // :2658-2710 on the GPU in seed-rank batches + host replay
-            R.nodes.resize((size_t)cap);
-            R.links.resize((size_t)(2 * (2 * cap + 2)));
-            ok = pnr_trace_replay(ctx, seeds.data(), nseeds, 0, R.nodes.data(), cap, &nn, R.links.data(), 2 * cap + 2, &nl, &used, &iters) == PNR_OK;
-            if (!ok || (nn <= cap && nl <= 2 * cap + 2)) break;
-            cap = std::max(nn, nl / 2) + 2;
+        // :2658-2710: the particle filters on the GPU (a window of traces refilled as they stop), the bookkeeping replayed on the
+        // host in seed order; the graph stays in the context and is fetched once its size is known
+        if (settings().verbose) pnr_set_option(ctx, "trace_log", 1);
+        ok = pnr_trace_replay(ctx, seeds.data(), nseeds, 0, nullptr, 0, &nn, nullptr, 0, &nl, &used, &iters) == PNR_OK;
+        if (ok) {
+            R.nodes.resize((size_t)nn);
+            R.links.resize((size_t)(2 * nl));
+            ok = pnr_get_graph(ctx, R.nodes.data(), nn, &nn, R.links.data(), nl, &nl) == PNR_OK;
+        }
+        if (ok && settings().verbose) { // what the reference prints while it traces (TRACING_VERBOSE :2677; tracker.cpp:866,879,908,916)
+            int64_t nlog = 0;
+            pnr_get_trace_log(ctx, nullptr, 0, &nlog);
+            std::vector<int32_t> lg((size_t)nlog * 5);
+            pnr_get_trace_log(ctx, lg.data(), nlog, &nlog);
+            int trace_count = 0;
+            for (int64_t k = 0; k < nlog; k++) {
+                const int32_t *e = &lg[(size_t)k * 5];
+                const pnr_seed &sd = seeds[(size_t)e[0]];
+                if (e[1] == 0)
+                    printf("\nTrace: %6d\t [%4.1f, %4.1f, %4.1f]\t sc=%6.2f\t corr=%3.2f\t progress %3.2f%%\t", ++trace_count, sd.x, sd.y, sd.z, sd.score, sd.corr,
+                           (100.0 * e[0]) / (double)nseeds);
+                float cv;
+                std::memcpy(&cv, &e[4], 4);
+                switch (e[3]) {
+                case 3: printf("\n--%d[%d], SOMA, idx=%d", e[2], p.ni, e[4]); break;
+                case 2: printf("\n--%d[%d], DENSITY, nodespervol=%d", e[2], p.ni, e[4]); break;
+                case 1: printf("\n--%d[%d], success=0, corr=%1.2f", e[2], p.ni, cv); break;
+                default: printf("\n--%d[%d], TRACK LIMIT, niter=%d", e[2], p.ni, p.ni); break;
+                }
+            }
+            printf("\n");
         }
     }
     auto t4 = clk::now();
@@ -341,8 +377,6 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
         pnr_destroy(ctx);
         return false;
     }
-    R.nodes.resize((size_t)nn);
-    R.links.resize((size_t)(2 * nl));
     R.n_seeds_init = nfound; R.n_seeds = nseeds; R.n_traces = used; R.n_iterations = iters;
     R.t_frangi = secs(t0, t1); R.t_seeds = secs(t1, t2); R.t_select = secs(t2, t3); R.t_trace = secs(t3, t4);
     printf("\n-----\n%g%% seeds used \n", nseeds ? 100.0 * used / nseeds : 0.0);
@@ -366,7 +400,7 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
     R.t_recon = secs(t4, t5);
     R.swc_path = inimg_file + "_Advantra.swc"; // :2164
     save_treelist(R.tree, R.parent, R.swc_path, -1, 1.f, "Advantra", swc_comment(paras, p));
-    if (getenv("PNR_SAVE_MIDRES")) save_nodelist(R.nodes, R.links, inimg_file + "_n0_.swc"); // saveMidres tap (:2099)
+    if (settings().save_midres) save_nodelist(R.nodes, R.links, inimg_file + "_n0_.swc"); // saveMidres tap (:2099)
     printf("%s\n%lld trace nodes, %lld traces, %lld SMC iterations, %zu tree nodes | frangi %.3f s, seeds %.3f s, selection %.3f s, "
            "tracing %.3f s, reconstruct %.3f s\n",
            R.swc_path.c_str(), (long long)nn - 1, (long long)used, (long long)iters, R.tree.size() - 1, R.t_frangi, R.t_seeds, R.t_select,

@@ -29,6 +29,14 @@ struct Result {
     double t_frangi = 0, t_seeds = 0, t_select = 0, t_trace = 0, t_recon = 0;
 };
 
+// switches of the head-less driver (advantra_cli flags; the plugin's compile-time TRACING_VERBOSE / saveMidres taps)
+struct Settings {
+    bool verbose = false;     // -v: per-trace progress and stop reasons in the reference's words (tracker.cpp:866,879,908,916; Advantra_plugin.cpp:2677)
+    bool save_midres = false; // --save-midres: also write <inimg>_n0_.swc, the node graph before reconstruct() (:2099)
+    uint32_t rng_seed = 42;   // --rng-seed: replaces srand(time(NULL)) of tracker.cpp:1003,1098
+};
+Settings &settings();
+
 void print_help();
 // simple_loadimage_wrapper's role (Advantra_plugin.cpp:2241): 8-bit multi-page uncompressed TIFF, or
 // ".raw" (u8, dims from `raw_dims` = "w,h,l").  Returns false with a message in `err`.

@@ -104,6 +104,7 @@ def load():
                                            C.POINTER(i64), C.POINTER(i64)]
     L.pnr_sched_playback.argtypes = [C.POINTER(Params), i64, i64, i64, vp, i64, i32, i32, ALLGATHER_FN, vp, i64, TRACE_FN, vp, i32, i32, i32,
                                      vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    L.pnr_get_trace_log.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.pnr_set_option.argtypes = [vp, C.c_char_p, i64]
     L.pnr_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     for name in EXPORTS:
@@ -118,7 +119,7 @@ EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", 
            "pnr_set_j8_v", "pnr_extract_seeds", "pnr_extract_seeds_range", "pnr_zncc_batch",
            "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_replay_traces_ctx", "pnr_frangi_slab", "pnr_quantise_j8", "pnr_soma", "pnr_get_soma", "pnr_trace_replay", "pnr_reconstruct", "pnr_get_table", "pnr_set_profiling", "pnr_set_smc_driver",
            "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch", "pnr_get_graph", "pnr_trace_replay_sharded", "pnr_sched_playback",
-           "pnr_set_option", "pnr_get_option", "pnr_score_filter_seeds", "pnr_sort_seeds"]
+           "pnr_set_option", "pnr_get_option", "pnr_score_filter_seeds", "pnr_sort_seeds", "pnr_get_trace_log"]
 
 
 def check(rc):
@@ -331,6 +332,14 @@ class Context:
         links = np.zeros((nl.value, 2), np.int32)
         check(self.L.pnr_get_graph(self.h, nodes.ctypes.data, len(nodes), C.byref(nn), links.ctypes.data, len(links), C.byref(nl)))
         return nodes, links
+
+    def trace_log(self):
+        """[(seed rank, direction, ti_limit, reason, value)] of the last trace_replay with option trace_log = 1 (pnr_get_trace_log)"""
+        n = C.c_int64()
+        check(self.L.pnr_get_trace_log(self.h, None, 0, C.byref(n)))
+        rec = np.zeros((n.value, 5), np.int32)
+        check(self.L.pnr_get_trace_log(self.h, rec.ctypes.data, n.value, C.byref(n)))
+        return rec
 
     def trace_replay(self, seeds, first_batch=0):
         """streamed trace + replay (pnr_trace_replay): nodes, links, traces used, SMC iterations run"""

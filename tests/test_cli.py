@@ -83,3 +83,50 @@ def test_cli_soma_and_single_slice(tmp_path, case):
     assert np.array_equal(rows[:, [0, 1, 6]], want[:, [0, 1, 6]]) and np.allclose(rows[:, 2:6], want[:, 2:6], atol=2e-3)
     if case == "soma":
         assert (rows[:, 1] == 1).sum() >= 1  # a SOMA-typed node in the SWC
+
+
+def test_cli_rejects_malformed_tiff(tmp_path):
+    """a TIFF whose directory chain loops, whose value count exceeds the file or whose page is larger than the file ends with a
+    message, not with an endless loop or a multi-gigabyte allocation (CPU only: the loader runs before any device call)"""
+    import struct
+    paras = "2 0 5 0.3 3 2 10 20 2 4 1".split()
+
+    def tiff(entries, next_ifd, extra=b""):
+        body = struct.pack("<H", len(entries)) + b"".join(struct.pack("<HHII", *e) for e in entries) + struct.pack("<I", next_ifd)
+        return b"II" + struct.pack("<HI", 42, 8) + body + extra
+
+    base = [(256, 4, 1, 4), (257, 4, 1, 4), (258, 3, 1, 8), (259, 3, 1, 1), (277, 3, 1, 1)]
+    strip = [(273, 4, 1, 8 + 2 + 12 * 7 + 4), (279, 4, 1, 16)]
+    cases = {
+        "loop.tif": (tiff(base + strip, 8, b"\x07" * 16), "loops"),                                     # IFD points at itself
+        "count.tif": (tiff(base + [(273, 4, 0x40000000, 200), (279, 4, 1, 16)], 0, b"\x07" * 16), ""),   # 2^30 strip offsets in a 130-byte file
+        "huge.tif": (tiff([(256, 4, 1, 60000), (257, 4, 1, 60000)] + base[2:] + strip, 0, b"\x07" * 16), "larger than the file"),
+    }
+    for name, (blob, msg) in cases.items():
+        f = tmp_path / name
+        f.write_bytes(blob)
+        r = run("-f", "advantra_func", "-i", str(f), "-p", *paras)
+        assert r.returncode == 0 and r.stderr.strip() and msg in r.stderr, (name, r.stderr)  # dofunc prints and returns, no crash
+        assert not os.path.exists(str(f) + "_Advantra.swc")
+
+
+@pytest.mark.gpu
+def test_cli_verbose_prints_the_reference_trace_lines(tmp_path):
+    """-v: per-trace progress and stop reasons in the reference's words (Advantra_plugin.cpp:2677; tracker.cpp:866,879,908,916);
+    --save-midres: the node graph before reconstruct() (:2099); same SWC as without the flags"""
+    from PIL import Image
+    img = synth.synth(64, 56, 32, seed=2)
+    tif = str(tmp_path / "stack.tif")
+    pages = [Image.fromarray(z) for z in img]
+    pages[0].save(tif, save_all=True, append_images=pages[1:], compression=None)
+    paras = "2,3 0 5 0.3 3 2 40 50 2 4 5".split()
+    quiet = run("-f", "advantra_func", "-i", tif, "-p", *paras)
+    swc_quiet = open(tif + "_Advantra.swc").read()
+    r = run("-v", "--save-midres", "-f", "advantra_func", "-i", tif, "-p", *paras)
+    assert r.returncode == 0 and quiet.returncode == 0, r.stderr
+    assert open(tif + "_Advantra.swc").read() == swc_quiet and os.path.exists(tif + "_n0_.swc")
+    out = r.stdout
+    ntr = out.count("\nTrace: ")
+    ends = sum(out.count(k) for k in ("], DENSITY, nodespervol=4", "], success=0, corr=", "], TRACK LIMIT, niter=40", "], SOMA, idx="))
+    assert ntr > 5 and ends == 2 * ntr  # trackPos + trackNeg of every trace that was used
+    assert "% seeds used" in out and "seed extraction..." in out and "Trace: " not in quiet.stdout
