@@ -100,6 +100,80 @@ __global__ __launch_bounds__(256) void gauss_axis(const float *__restrict__ in, 
     }
 }
 
+// The same pass with the radius L a compile-time constant: every thread computes GR CONSECUTIVE outputs along the axis, so an
+// input row read from LDS feeds up to GR accumulators (2L + GR LDS reads for GR outputs instead of GR (2L + 1)), the taps are
+// scalar registers, and the loop over the input rows is fully unrolled so that all indices are static.  For every output the
+// products are still added in ascending tap order with separate multiply and add -- the reference's sum, bit for bit.
+constexpr int GR = 8, TAT = 64, GT = TAT / GR; // outputs per thread, outputs per tile along the axis, row groups (waves) per block
+
+template <int L>
+__global__ __launch_bounds__(64 * GT) void gauss_axis_t(const float *__restrict__ in, float *__restrict__ out, int w, int n_axis, i64 axis_stride, int n_other,
+                                                     i64 other_stride, int tiles_x, int tiles_a, const float *__restrict__ taps)
+{
+    __shared__ float s_in[(TAT + 2 * L) * 64];
+    i64 b = blockIdx.x;
+    const int tx_tile = (int)(b % tiles_x);
+    b /= tiles_x;
+    const int ta_tile = (int)(b % tiles_a);
+    const int o = (int)(b / tiles_a);
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6; // GT groups of GR consecutive rows
+    const int x = tx_tile * 64 + lane;
+    const int a0 = ta_tile * TAT;
+    const float *base = in + (i64)o * other_stride;
+    constexpr int rows = TAT + 2 * L;
+    if (x < w) {
+#pragma unroll 4
+        for (int r = grp; r < rows; r += GT) {
+            int a = a0 - L + r;
+            a = a < 0 ? 0 : (a > n_axis - 1 ? n_axis - 1 : a);
+            s_in[r * 64 + lane] = base[(i64)a * axis_stride + x];
+        }
+    }
+    float tp[2 * L + 1];
+#pragma unroll
+    for (int k = 0; k <= 2 * L; k++) tp[k] = taps[k]; // uniform address, static index: scalar loads
+    __syncthreads();
+    if (x >= w) return;
+    float acc[GR];
+#pragma unroll
+    for (int j = 0; j < GR; j++) acc[j] = 0.f;
+    const float *col = s_in + grp * GR * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 2 * L + GR; t++) { // input row t of this thread's window feeds output j with tap k = t - j
+        const float v = col[t * 64];
+#pragma unroll
+        for (int j = 0; j < GR; j++) {
+            const int k = t - j;
+            if (k >= 0 && k <= 2 * L) acc[j] = acc[j] + v * tp[k];
+        }
+    }
+    float *dst = out + (i64)o * other_stride;
+#pragma unroll
+    for (int j = 0; j < GR; j++) {
+        const int a = a0 + grp * GR + j;
+        if (a < n_axis) dst[(i64)a * axis_stride + x] = acc[j];
+    }
+}
+
+// launch the strided-axis pass: the templated kernel for the radii the default parameters produce, the generic one otherwise
+static void launch_gauss_axis(hipStream_t st, const float *in, float *out, int w, int n_axis, i64 axis_stride, int n_other, i64 other_stride,
+                              const float *d_taps, int L)
+{
+    const int tiles_x = (w + 63) / 64;
+    int tiles_a = (n_axis + TAT - 1) / TAT;
+    dim3 grid((unsigned)((i64)tiles_x * tiles_a * n_other));
+#define PNR_GA(LL) case LL: hipLaunchKernelGGL(gauss_axis_t<LL>, grid, dim3(64 * GT), 0, st, in, out, w, n_axis, axis_stride, n_other, other_stride, tiles_x, tiles_a, d_taps); return;
+    switch (L) {
+        PNR_GA(2) PNR_GA(3) PNR_GA(5) PNR_GA(6) PNR_GA(9) PNR_GA(12) PNR_GA(18) PNR_GA(24)
+    default: break;
+    }
+#undef PNR_GA
+    tiles_a = (n_axis + TA - 1) / TA;
+    grid = dim3((unsigned)((i64)tiles_x * tiles_a * n_other));
+    const size_t sm = ((size_t)(TA + 2 * L) * 64 + 2 * L + 1) * 4;
+    hipLaunchKernelGGL(gauss_axis, grid, dim3(256), sm, st, in, out, w, n_axis, axis_stride, n_other, other_stride, tiles_x, tiles_a, d_taps, L);
+}
+
 // ----------------------------------------------------------------------------------------
 // K4: Hessian (frangi.cpp:305-381) + eigen (:1269-1493) + vesselness (:190-273)
 // ----------------------------------------------------------------------------------------
@@ -457,6 +531,7 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
     __syncthreads();
     const int x = x0 + tx, y = y0 + ty;
     const bool inside = x < w && y < h;
+    const bool interior_xy = x0 >= 2 && x0 + HT_X + 2 <= w && y0 >= 2 && y0 + HT_Y + 2 <= h; // block-uniform
     const int o = (ty + 2) * HT_PX + tx + 2;
     float *const qh = DUMP ? nullptr : Q.h + (size_t)region * 6 * HT_REGION;
     unsigned int *const qi = DUMP ? nullptr : Q.idx + (size_t)region * HT_REGION;
@@ -475,12 +550,24 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
         float Dzz = 0, Dyy = 0, Dyz = 0, Dxx = 0, Dxy = 0, Dxz = 0;
         if (inside) {
             // six second derivatives, each x sigma^2 (frangi.cpp:319,339,345,368,374,380)
-            Dzz = td2<2, 2>(T, z, l, z, l) * s2;
-            Dyy = td2<1, 1>(T, y, h, y, h) * s2;
-            Dyz = td2<1, 2>(T, y, h, z, l) * s2;
-            Dxx = td2<0, 0>(T, x, w, x, w) * s2;
-            Dxy = td2<0, 1>(T, x, w, y, h) * s2;
-            Dxz = td2<0, 2>(T, x, w, z, l) * s2;
+            if (interior_xy && z >= 2 && z + 2 < l) {
+                // no voxel of this plane of the tile is within 2 of a border: the centred differences everywhere.  The same
+                // operations as the general path below takes for such a voxel (coordinate 2 of 5 stands for "interior"), but
+                // with the border rules resolved at compile time: 19 LDS reads instead of every variant's
+                Dzz = td2<2, 2>(T, 2, 5, 2, 5) * s2;
+                Dyy = td2<1, 1>(T, 2, 5, 2, 5) * s2;
+                Dyz = td2<1, 2>(T, 2, 5, 2, 5) * s2;
+                Dxx = td2<0, 0>(T, 2, 5, 2, 5) * s2;
+                Dxy = td2<0, 1>(T, 2, 5, 2, 5) * s2;
+                Dxz = td2<0, 2>(T, 2, 5, 2, 5) * s2;
+            } else {
+                Dzz = td2<2, 2>(T, z, l, z, l) * s2;
+                Dyy = td2<1, 1>(T, y, h, y, h) * s2;
+                Dyz = td2<1, 2>(T, y, h, z, l) * s2;
+                Dxx = td2<0, 0>(T, x, w, x, w) * s2;
+                Dxy = td2<0, 1>(T, x, w, y, h) * s2;
+                Dxz = td2<0, 2>(T, x, w, z, l) * s2;
+            }
             if (DUMP) {
                 const i64 i = (i64)z * wh + (i64)y * w + x;
                 dump.Dzz[i] = Dzz; dump.Dyy[i] = Dyy; dump.Dyz[i] = Dyz;
@@ -494,6 +581,23 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
                 const double tr = (double)Dxx + (double)Dyy + (double)Dzz;
                 const double nrm = fabs((double)Dxx) + fabs((double)Dyy) + fabs((double)Dzz) + 2.0 * (fabs((double)Dxy) + fabs((double)Dxz) + fabs((double)Dyz));
                 surv = !(tr > 1e-9 * nrm);
+                if (surv) {
+                    // Second proof of a zero response: TWO positive eigenvalues.  With all roots real, Descartes' rule on the
+                    // characteristic polynomial l^3 - c2 l^2 + c1 l - c0 (c2 = trace <= 0 here) gives exactly two positive roots iff
+                    // c1 < 0 and c0 < 0; then (p1 + p2) |n| > -c1 puts the larger positive root above 5e-10 of the norm -- far above
+                    // the solver's rounding -- and at least one of the two largest-magnitude eigenvalues is that positive one.
+                    const double xx = Dxx, yy = Dyy, zz = Dzz, xy = Dxy, xz = Dxz, yz = Dyz;
+                    const double c1 = (xx * yy - xy * xy) + (xx * zz - xz * xz) + (yy * zz - yz * yz);
+                    const double c0 = xx * (yy * zz - yz * yz) - xy * (xy * zz - yz * xz) + xz * (xy * yz - yy * xz);
+                    const double n2 = nrm * nrm, n3 = n2 * nrm;
+                    // Third: ONE positive eigenvalue p (c0 > 0: n1 <= n2 < 0 < p) that is not the smallest in magnitude.  The
+                    // product of the pairwise sums (n1 + n2)(n1 + p)(n2 + p) = c2 c1 - c0 is positive only if n2 + p > 0 (and
+                    // n1 + p < 0); above the margin that puts p at least 2.5e-10 of the norm beyond |n2|, so p is one of the two
+                    // largest-magnitude eigenvalues and the response is 0.
+                    const bool two_pos = c1 < -1e-9 * n2 && c0 < -1e-9 * n3;
+                    const bool one_pos_big = c0 > 1e-9 * n3 && (tr * c1 - c0) > 1e-9 * n3;
+                    surv = !(two_pos || one_pos_big);
+                }
                 if (!surv && z >= zs0 && z < zs1) zero_here = true;
             }
         }
@@ -820,18 +924,8 @@ static int gaussian3d(pnr_ctx *c, const std::vector<float> &gxy, const std::vect
         hipLaunchKernelGGL(gauss_x_u8, dim3((unsigned)(rows * tiles_x)), dim3(GX_BLOCK), 0, c->stream, c->d_img, bufX, w,
                            rows, tiles_x, d_txy, Lxy);
     }
-    {
-        const int tiles_x = (w + 63) / 64, tiles_a = (h + TA - 1) / TA;
-        const size_t sm = ((size_t)(TA + 2 * Lxy) * 64 + 2 * Lxy + 1) * 4;
-        hipLaunchKernelGGL(gauss_axis, dim3((unsigned)((i64)tiles_x * tiles_a * l)), dim3(256), sm, c->stream, bufX, bufY,
-                           w, h, (i64)w, l, (i64)w * h, tiles_x, tiles_a, d_txy, Lxy);
-    }
-    if (!two_d) {
-        const int tiles_x = (w + 63) / 64, tiles_a = (l + TA - 1) / TA;
-        const size_t sm = ((size_t)(TA + 2 * Lz) * 64 + 2 * Lz + 1) * 4;
-        hipLaunchKernelGGL(gauss_axis, dim3((unsigned)((i64)tiles_x * tiles_a * h)), dim3(256), sm, c->stream, bufY, bufZ,
-                           w, l, (i64)w * h, h, (i64)w, tiles_x, tiles_a, d_tz, Lz);
-    }
+    launch_gauss_axis(c->stream, bufX, bufY, w, h, (i64)w, l, (i64)w * h, d_txy, Lxy);
+    if (!two_d) launch_gauss_axis(c->stream, bufY, bufZ, w, l, (i64)w * h, h, (i64)w, d_tz, Lz);
     c->toc("gauss", two_d ? 2 : 3);
     PNR_HIP(hipGetLastError());
     return PNR_OK;

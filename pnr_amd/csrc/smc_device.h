@@ -530,7 +530,15 @@ __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash
 #pragma unroll
         for (int j = 0; j < CH; j++) cur[j] = nxt[j];
     }
-    for (int k = nfull * CH; k < M; k++) ag += stash_lane[(i64)k * STRIDE];
+    // the tail (M is not a multiple of CH): all its loads in flight together, then the ordered adds -- one memory latency, not `tail`
+    {
+        const float *tp = stash_lane + (i64)nfull * CH * STRIDE;
+#pragma unroll
+        for (int j = 0; j < CH; j++) cur[j] = (j < tail) ? tp[j * STRIDE] : 0.f;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            if (j < tail) ag += cur[j];
+    }
     ag /= (float)M;
     float corra = 0.f, corrb = 0.f;
     if (nfull > 0) {
@@ -555,12 +563,19 @@ __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash
 #pragma unroll
         for (int j = 0; j < CH; j++) cur[j] = nxt[j];
     }
-    for (int k = nfull * CH; k < M; k++) {
-        const float di = stash_lane[(i64)k * STRIDE] - ag;
-        corra += di * wd[k];
-        corrb = (float)__builtin_fma((double)di, (double)di, (double)corrb);
+    {
+        const float *tp = stash_lane + (i64)nfull * CH * STRIDE;
+        const float *wk = wd + nfull * CH;
+#pragma unroll
+        for (int j = 0; j < CH; j++) cur[j] = (j < tail) ? tp[j * STRIDE] : 0.f;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            if (j < tail) {
+                const float di = cur[j] - ag;
+                corra += di * wk[j];
+                corrb = (float)__builtin_fma((double)di, (double)di, (double)corrb);
+            }
     }
-    (void)tail;
     const float prod = corrb * corrc;
     return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f; // tracker.cpp:1955
 }
