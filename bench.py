@@ -346,10 +346,40 @@ def main():
             "smc_launches_per_step": smc_n / a.steps,
             "Mvox_per_s_frangi": (nvox / (fr_ms * 1e-3) / 1e6) if (fr_vox and fr_ms > 0) else None,
         }
+        groups = ctx.get_option("groups")
+        out["config"]["trace_groups"] = groups
+        if groups > 1 and a.driver == "phased":
+            # launches of different trace groups overlap: a kernel's duration includes the time it shares the CUs, and the sum of the
+            # durations counts that time twice -- the group figure is taken over the wall time of the tracing stage instead
+            tr_ms = st.get("trace_replay_gather_ms", st.get("trace_replay_exchange_ms"))
+            g2 = 8.0 * Mtot * evals / (tr_ms * 1e-3) / 1e9
+            out["roofline_smc_group"].update(achieved=g2, frac=g2 / HBM_PEAK_GBS, device_ms_per_step=None, wall_ms_per_step=tr_ms, Mevals_per_s=evals / tr_ms / 1e3,
+                                             note=f"SURVEY 8(d): 8*sum(M) algorithmic bytes x particle evaluations / WALL time of the tracing stage (kernels of the {groups} trace "
+                                                  "groups overlap on their streams, host replay and polls included)")
+            out["roofline"]["note"] += (f"; {groups} trace groups: this kernel's launches overlap the other group's ph_sums / ph_predict / ph_update launches, so its average "
+                                        "duration includes shared time -- roofline_isolated is the same kernel with one trace group (untimed extra step)")
         if world == 1 and not a.one_shot and not a.no_extra:
+            s_all = ctx.score_filter_sort(ctx.extract_seeds())[:a.seeds]
+            if groups > 1 and a.driver == "phased":
+                # the same step with ONE trace group (launches never overlap): what each kernel needs alone
+                ctx.set_option("groups", 1)
+                ctx.reset_kernel_ms()
+                t0i = time.perf_counter()
+                _, _, _, it_iso = ctx.trace_replay(s_all)
+                t_iso = 1e3 * (time.perf_counter() - t0i)
+                ctx.set_option("groups", groups)
+                ki = {g: ctx.kernel_ms(g) for g in ("smc", "smc_sums", "smc_predict", "smc_update")}
+                ev_i = it_iso * (a.np + 1)
+                all_i = sum(v[0] for v in ki.values())
+                out["roofline_isolated"] = {
+                    "kernel": kname, "bound": "lds-gather/valu", "launches": ki["smc"][1], "avg_launch_ms": ki["smc"][0] / max(ki["smc"][1], 1),
+                    "achieved": 8.0 * Mtot * ev_i / (ki["smc"][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * Mtot * ev_i / (ki["smc"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "smc_group_frac": 8.0 * Mtot * ev_i / (all_i * 1e-3) / 1e9 / HBM_PEAK_GBS, "smc_group_device_ms": all_i, "trace_wall_ms": t_iso,
+                    "sums_avg_launch_ms": ki["smc_sums"][0] / max(ki["smc_sums"][1], 1),
+                    "sums_GBs": 2.0 * 4 * Mtot * stash_row_floats(a.np) * it_iso / (ki["smc_sums"][0] * 1e-3) / 1e9,
+                    "note": "one trace group, same seeds, after the timed region: per-kernel durations without overlap (what rocprofv3 shows with option groups=1)"}
             # the same kernel with every CU busy: ONE launch over all traces (outside the timed region)
             ctx.reset_kernel_ms()
-            s_all = ctx.score_filter_sort(ctx.extract_seeds())[:a.seeds]
             T1, _, _, _ = ctx.trace_batch(s_all)
             ms1, n1 = ctx.kernel_ms("smc")
             ev1 = int((T1 + (T1 < a.ni)).sum()) * (a.np + 1)

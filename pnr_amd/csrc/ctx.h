@@ -60,8 +60,8 @@ struct Options {
     int window = 768;         // trace slots the streaming tracer keeps busy
     int look0 = 0, look_pct = -1; // admission lookahead max(look0, frontier * look_pct / 100); 0 / -1 = automatic (stream_sched.h)
     int poll = 4;             // SMC steps between two polls
-    int groups = 1;           // trace groups on separate streams
-    int split_x10 = 40;       // sampling work-groups per CU x 10
+    int groups = 2;           // trace groups on separate streams (2: one group's ordered sums overlap the other's sampling)
+    int split_x10 = 0;        // sampling work-groups per CU x 10 and launch; 0 = automatic (40 with one trace group, 22 with several)
     int max_split = 24;       // ... and at most this many per trace
     int64_t stash_mb = 65536; // sample-stash budget
     int host_threads = 0;     // host worker threads of the seed flood fill / reconstruct(); 0 = hardware threads / local_ranks

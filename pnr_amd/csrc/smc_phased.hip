@@ -582,6 +582,7 @@ void pnr_phased_destroy(pnr_phased *h)
 // than CUs (the dispatcher keeps every CU busy until the items run out) without paying the cube staging too often.
 static int pick_nsplit(int active, int ncu, int max_split, int x10 /* work-groups per CU x 10 */)
 {
+    if (x10 <= 0) x10 = 40;
     int ns = (int)(((long long)x10 * ncu / 10 + active - 1) / active);
     return ns < 1 ? 1 : (ns > max_split ? max_split : ns);
 }
@@ -781,9 +782,10 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
 // The window can be shared by G groups of traces (option "groups", 1..4) that step independently, each on its own stream with
 // its own active list: while the host collects, replays and refills one group, the other groups' steps keep the GPU busy, and
 // launches with few traces (a chain's ordered sums take 0.25 ms however few there are) overlap.  Results do not depend on the
-// grouping: a trace is a function of its seed and of the replayed map.  Two groups take 4 % off the bench step; the default
-// stays one group, whose launches do not overlap, so that a kernel's duration -- HIP events or rocprofv3 -- is the time that
-// kernel needs and the roofline figures built on it mean what they say.
+// grouping: a trace is a function of its seed and of the replayed map.  Two groups (the default) take 7 % off the tracing of the
+// bench step -- with 22 instead of 40 sampling work-groups per CU and launch, because a launch now shares the CUs; a third group
+// gains nothing (the streams share two hardware queues).  With several groups the launches of different groups overlap, so a
+// kernel's duration (HIP events, rocprofv3) includes the time it shares the CUs; option "groups" = 1 gives the isolated figure.
 // ---------------------------------------------------------------------------------------------------------
 namespace {
 
@@ -799,6 +801,7 @@ struct PhasedEngine final : pnr::StreamEngine {
     };
     Grp grp[pnr_phased::MAXG];
     std::string msg;
+    int split_x10 = 40; // with several trace groups a launch shares the CUs with the other groups' launches: fewer, fatter work-groups
 
     explicit PhasedEngine(pnr_ctx *ctx) : c(ctx) {}
     const char *error() const override { return msg.c_str(); }
@@ -875,7 +878,7 @@ struct PhasedEngine final : pnr::StreamEngine {
         const int np = E.np, ni = E.ni, S = E.S, np_pad = E.np_pad, ng = E.ng;
         for (int k = 0; k < poll; k++) { // `poll` SMC steps over the group's active list (every trace at its own iteration)
             const int lp = q.lp;
-            const int nsplit = pick_nsplit(active, E.ncu, E.max_split, c->opt.split_x10);
+            const int nsplit = pick_nsplit(active, E.ncu, E.max_split, split_x10);
             c->tic(st);
             hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
             c->toc("smc_predict", 1, st);
@@ -942,6 +945,7 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
     int64_t window = std::min<int64_t>(std::max(2, o.window), std::max<int64_t>(2, 2 * own));
     window += window & 1;
     PhasedEngine eng(c);
+    eng.split_x10 = c->opt.split_x10 > 0 ? c->opt.split_x10 : (std::min(std::max(1, o.groups), (int)pnr_phased::MAXG) > 1 ? 22 : 40);
     int rc = eng.init(window);
     if (rc) { pnr::set_error("%s", eng.error()); return rc; }
     pnr::SchedStats st;

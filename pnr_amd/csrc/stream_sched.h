@@ -32,7 +32,7 @@ struct SchedOptions {
     int look0 = 0;     // seeds admitted at most max(look0, frontier * look_pct / 100) ranks beyond the replay frontier;
     int look_pct = -1; // look0 = 0 / look_pct < 0: automatic, max(128, 64 * world) / min(400, 50 * world) (scripts/sim_sharded.py)
     int poll = 4;      // SMC steps between two polls
-    int groups = 1;    // trace groups stepping independently (engine permitting)
+    int groups = 2;    // trace groups stepping independently (engine permitting)
     int timing = 0;    // one line of statistics on stderr
 };
 

@@ -1,8 +1,8 @@
-"""per-launch times of the phased SMC kernels with a handful of traces (the latency floors).  usage: sums_floor.py [nseeds]"""
+"""per-launch times of the phased SMC kernels with a handful of traces (the latency floors).  usage: sums_floor.py [nseeds] [stack edge]"""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import numpy as np, torch, synth, pnr_amd
-S = 256
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 img = synth.synth_torch(S, S, S, seed=3); torch.cuda.synchronize()
 c = pnr_amd.Context(pnr_amd.make_params(sigmas=(2, 4, 6), np_=200, ni=200, zdist=2), 0)
 c.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
