@@ -117,7 +117,7 @@ struct LayerFinder {
     }
 
     // keys ascending; emits accepted maxima (pixel offsets) in processing order (highest first)
-    void run(const unsigned char *L8, const i64 *keys, i64 nkeys, float tol, std::vector<int> &accepted)
+    void run(const unsigned char *L8, const i64 *keys, i64 nkeys, float tol, int layer_min, std::vector<int> &accepted)
     {
         const int step[8] = {-w, -w + 1, 1, w + 1, w, w - 1, -1, -w - 1};
         std::memset(flags.data(), 0, flags.size());
@@ -129,6 +129,12 @@ struct LayerFinder {
             if (flags[start] & F_PROCESSED) continue;
             int sx = start % w, sy = start / w;
             float v0 = (float)L8[start];
+            // A maximum whose flood threshold v0 - tolerance does not exceed the layer's minimum can never be accepted: every
+            // neighbour the fill looks at is either listed, or ends the candidate (PROCESSED, higher than v0, an edge pixel), or
+            // qualifies -- so the fill only stops at one of those three, at the latest at the image edge.  The candidates come in
+            // descending value, so none of the remaining ones can be accepted either, and the marks their fills would leave are
+            // never looked at: the layer is finished (this is where the reference floods the whole background of every layer).
+            if ((float)layer_min >= v0 - tol) break;
             bool retry;
             do {
                 retry = false;
@@ -313,7 +319,7 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
                 (void)hipEventSynchronize(c->j8_ev[k / per_chunk]); // this layer's bytes have arrived
                 i64 *kb = keys.data() + off[k];
                 std::sort(kb, kb + cnt[k]); // unique keys: order fully defined (seed.cpp:632)
-                lf.run(h_j8 + (size_t)k * wh, kb, cnt[k], tol, acc[k]);
+                lf.run(h_j8 + (size_t)k * wh, kb, cnt[k], tol, vmin[k], acc[k]);
             }
         };
         std::vector<std::thread> th;
