@@ -246,7 +246,7 @@ int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
  *   work-groups per CU x 10 / per trace | stash_mb (65536) sample-stash budget | host_threads (0 = CPUs of this process /
  *   local_ranks) workers of the seed flood fill and of pnr_reconstruct_ctx | local_ranks (1) processes sharing this host |
  *   trace_timing, seed_timing (0/1) statistics on stderr | trace_log (0/1) keep every trace's end for pnr_get_trace_log | replay_batches (0/1), batch_growth, batch_max: rank batches instead
- *   of the streaming window | no_stash (0/1) persistent driver without the sample stash | exchange_block (262144) bytes per rank
+ *   of the streaming window | no_stash (0/1) persistent driver without the sample stash | exchange_block (0 = 256 KB / world) bytes per rank
  *   and exchange of pnr_trace_replay_sharded.   pnr_get_option also knows "host_threads_effective". */
 int pnr_set_option(pnr_ctx *ctx, const char *key, int64_t value);
 int pnr_get_option(pnr_ctx *ctx, const char *key, int64_t *value);

@@ -751,7 +751,7 @@ const OptEntry OPTS[] = {
     {"trace_log", &pnr::Options::trace_log, nullptr, 0, 1},
     {"replay_batches", &pnr::Options::replay_batches, nullptr, 0, 1}, {"batch_growth", &pnr::Options::batch_growth, nullptr, 100, 100000},
     {"batch_max", &pnr::Options::batch_max, nullptr, 1, 1 << 24}, {"no_stash", &pnr::Options::no_stash, nullptr, 0, 1},
-    {"exchange_block", nullptr, &pnr::Options::exchange_block, 1024, 1 << 28},
+    {"exchange_block", nullptr, &pnr::Options::exchange_block, 0, 1 << 28},
 };
 } // namespace
 

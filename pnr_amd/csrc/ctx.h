@@ -71,7 +71,7 @@ struct Options {
     int replay_batches = 0;   // 1: seed-rank batches instead of the streaming window (always so with the persistent driver)
     int batch_growth = 200, batch_max = 1024;
     int no_stash = 0;         // persistent driver: in-lane two-pass sums
-    int64_t exchange_block = 262144; // bytes per rank and exchange of the sharded tracer
+    int64_t exchange_block = 0; // bytes per rank and exchange of the sharded tracer; 0 = automatic (256 KB / world, at least 32 KB)
 };
 int host_threads(const Options &o); // worker threads to use on this host
 

@@ -112,7 +112,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     std::vector<int32_t> outbox; // finished on this rank, not yet applied / sent
     size_t out_head = 0;
     const size_t rec_max_words = 4 + (size_t)ni * 8;
-    int64_t block = sh.block_bytes > 0 ? sh.block_bytes : 262144;
+    int64_t block = sh.block_bytes > 0 ? sh.block_bytes : std::max<int64_t>(32768, 262144 / world); // a rank's share of the finished traces shrinks with the world
     block = std::max<int64_t>(block, (int64_t)(HDR_WORDS + rec_max_words) * 4);
     block = (block + 15) / 16 * 16;
     const size_t block_words = (size_t)block / 4;
@@ -207,37 +207,41 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             }
             q.busy.resize(keep);
         }
-        // ---- the finished records reach the replay: directly, or through the all-gather of every rank's block
+        // ---- the finished records reach the replay: directly, or through the all-gather of every rank's block -- once per rotation
+        // of the trace groups (every rank runs the same number of groups, so all of them exchange in the same turns)
         int busy_all = 0;
-        if (world == 1) {
-            if (!apply(outbox.data(), outbox.size())) { err = "malformed trace record"; return fail(PNR_E_STATE); }
-            outbox.clear();
-        } else {
-            int busy = 0, abort_rank = -1;
-            for (int k = 0; k < G; k++) busy |= (grp[(size_t)k].inflight || grp[(size_t)k].active > 0) ? 1 : 0;
-            rc = exchange(busy, 0, &busy_all, &abort_rank);
-            if (rc) { aborted = true; return fail(rc); }
-            if (abort_rank >= 0) { aborted = true; err = "rank " + std::to_string(abort_rank) + " aborted the sharded trace"; return fail(PNR_E_STATE); }
-        }
-        // ---- replay in seed order as far as the finished traces reach, push the new density to the engine
+        const bool sync_turn = world == 1 || g == G - 1;
         const int64_t frontier_was = frontier;
-        r.touched.clear();
-        while (frontier < n && !r.stopped) {
-            SeedRec &sr = rec[(size_t)frontier];
-            if (!sr.skipped && sr.have < 2) break;
-            if (!sr.skipped) { // (a skipped seed sits on a saturated voxel: the replay would skip it as well)
-                r.log_base = frontier;
-                r.add(&seeds[frontier], 1, sr.T, sr.xc.data());
-                std::vector<pnr_xest>().swap(sr.xc);
+        if (sync_turn) {
+            if (world == 1) {
+                if (!apply(outbox.data(), outbox.size())) { err = "malformed trace record"; return fail(PNR_E_STATE); }
+                outbox.clear();
+            } else {
+                int busy = 0, abort_rank = -1;
+                for (int k = 0; k < G; k++) busy |= (grp[(size_t)k].inflight || grp[(size_t)k].active > 0) ? 1 : 0;
+                rc = exchange(busy, 0, &busy_all, &abort_rank);
+                if (rc) { aborted = true; return fail(rc); }
+                if (abort_rank >= 0) { aborted = true; err = "rank " + std::to_string(abort_rank) + " aborted the sharded trace"; return fail(PNR_E_STATE); }
             }
-            frontier++;
+            // ---- replay in seed order as far as the finished traces reach, push the new density to the engine
+            r.touched.clear();
+            while (frontier < n && !r.stopped) {
+                SeedRec &sr = rec[(size_t)frontier];
+                if (!sr.skipped && sr.have < 2) break;
+                if (!sr.skipped) { // (a skipped seed sits on a saturated voxel: the replay would skip it as well)
+                    r.log_base = frontier;
+                    r.add(&seeds[frontier], 1, sr.T, sr.xc.data());
+                    std::vector<pnr_xest>().swap(sr.xc);
+                }
+                frontier++;
+            }
+            if (!r.touched.empty()) {
+                rc = E.density_update(r, G > 1);
+                if (rc) { err = E.error(); return fail(rc); }
+            }
+            if (r.stopped) break; // MAX_TRACE_COUNT (:2702): whatever is still running is never looked at
+            if (frontier >= n) break;
         }
-        if (!r.touched.empty()) {
-            rc = E.density_update(r, G > 1);
-            if (rc) { err = E.error(); return fail(rc); }
-        }
-        if (r.stopped) break; // MAX_TRACE_COUNT (:2702): whatever is still running is never looked at
-        if (frontier >= n) break;
         // ---- admission into this group: this rank's seeds inside the lookahead
         const int64_t lim = frontier + std::max<int64_t>(look0, frontier * look_pct / 100);
         int m = 0, m_max = 2 * NT;
@@ -285,6 +289,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             q.inflight = true;
         }
         // ---- nothing running anywhere and nothing admitted: the frontier cannot move any more
+        if (world > 1 && !sync_turn) continue; // the idle count only moves in the turns every rank synchronises in
         bool any = frontier > frontier_was;
         if (world > 1) {
             any = any || busy_all > 0; // only what every rank knows: all ranks count the same idle turns

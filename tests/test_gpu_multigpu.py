@@ -119,3 +119,28 @@ def test_bench_gpus_2_starts_two_ranks_and_matches_one_gpu():
     assert two["counts"]["traces_used"] == one["counts"]["traces_used"]
     for k in ("roofline", "roofline_smc_group"):
         assert two[k]["frac"] > 0 and one[k]["frac"] > 0
+
+
+def test_exchange_callback_over_rccl_one_rank():
+    """the RCCL form of the exchange callback (pinned staging -> device -> all_gather_into_tensor -> host) with a world of one, the
+    only RCCL world a one-GPU box can form: the block comes back unchanged, twice, also after the block size changes"""
+    code = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, os.environ["PNR_ROOT"])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["PNR_PORT"], RANK="0", WORLD_SIZE="1")
+import torch, torch.distributed as dist
+from pnr_amd import multigpu
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+ex = multigpu.make_exchange(dist, 1, torch.device("cuda", 0))
+for nb in (4096, 4096, 65536):
+    send = (C.c_ubyte * nb)(*[(7 * i + nb) % 251 for i in range(nb)])
+    recv = (C.c_ubyte * nb)()
+    rc = ex(None, C.cast(send, C.c_void_p), C.cast(recv, C.c_void_p), nb)
+    assert rc == 0 and bytes(recv) == bytes(send), nb
+dist.destroy_process_group()
+print("exchange ok")
+'''
+    env = dict(os.environ, PNR_ROOT=ROOT, PNR_PORT=str(29600 + os.getpid() % 300), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "exchange ok" in r.stdout, r.stderr[-2000:]
