@@ -22,30 +22,47 @@
 namespace {
 typedef long long i64;
 
+// per-layer extremes of J8: LM_PARTS work-groups per layer, 16 bytes per lane and load, combined with atomics (vmin starts at
+// 0x7f7f7f7f, vmax at 0: memsets)
+constexpr int LM_PARTS = 8;
 __global__ __launch_bounds__(256) void layer_minmax(const unsigned char *__restrict__ J8, i64 wh, int z0,
                                                      int *__restrict__ vmin, int *__restrict__ vmax)
 {
-    const int zl = blockIdx.x;
+    const int zl = blockIdx.x / LM_PARTS, part = blockIdx.x % LM_PARTS;
     const unsigned char *L = J8 + (i64)(z0 + zl) * wh;
+    const i64 per = (wh + LM_PARTS - 1) / LM_PARTS;
+    const i64 i0 = part * per, i1 = (i0 + per < wh) ? i0 + per : wh;
     int mn = 255, mx = 0;
-    for (i64 i = threadIdx.x; i < wh; i += 256) {
-        const int v = L[i];
-        mn = v < mn ? v : mn;
-        mx = v > mx ? v : mx;
+    // bytes up to the first 16-byte boundary, then uint4 loads, then the rest
+    i64 a = i0;
+    const i64 mis = (16 - (i64)((uintptr_t)(L + i0) & 15)) & 15;
+    const i64 head = (a + mis < i1) ? a + mis : i1;
+    for (i64 i = a + threadIdx.x; i < head; i += 256) { const int v = L[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    a = head;
+    const i64 nvec = (i1 - a) / 16;
+    const uint4 *V = (const uint4 *)(L + a);
+    for (i64 k = threadIdx.x; k < nvec; k += 256) {
+        const uint4 q = V[k];
+        const unsigned int wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int b8 = 0; b8 < 4; b8++) {
+                const int v = (int)((wds[c] >> (8 * b8)) & 0xffu);
+                mn = v < mn ? v : mn;
+                mx = v > mx ? v : mx;
+            }
     }
+    for (i64 i = a + nvec * 16 + threadIdx.x; i < i1; i += 256) { const int v = L[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const int a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
-        mn = a < mn ? a : mn;
-        mx = b > mx ? b : mx;
+        const int x = __shfl_xor(mn, o), y = __shfl_xor(mx, o);
+        mn = x < mn ? x : mn;
+        mx = y > mx ? y : mx;
     }
-    __shared__ int s_mn[4], s_mx[4];
-    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; k++) { mn = s_mn[k] < mn ? s_mn[k] : mn; mx = s_mx[k] > mx ? s_mx[k] : mx; }
-        vmin[zl] = mn;
-        vmax[zl] = mx;
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&vmin[zl], mn);
+        atomicMax(&vmax[zl], mx);
     }
 }
 
@@ -270,7 +287,9 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     }
 
     c->tic();
-    hipLaunchKernelGGL(layer_minmax, dim3(nl), dim3(256), 0, c->stream, c->d_J8, wh, (int)z0, d_min, d_max);
+    PNR_HIP(hipMemsetAsync(d_min, 0x7f, nl * 4, c->stream));
+    PNR_HIP(hipMemsetAsync(d_max, 0, nl * 4, c->stream));
+    hipLaunchKernelGGL(layer_minmax, dim3(nl * LM_PARTS), dim3(256), 0, c->stream, c->d_J8, wh, (int)z0, d_min, d_max);
     PNR_HIP(hipMemsetAsync(d_cnt, 0, nl * 4, c->stream));
     const int tiles_x = (w + 255) / 256;
     const unsigned nblk = (unsigned)((i64)tiles_x * h * nl);

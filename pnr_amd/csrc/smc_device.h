@@ -130,15 +130,41 @@ __device__ __forceinline__ float sample(const Vol &V, const Frame &f, const floa
 // one (pose, sigma) chain: two sequential passes, sums in sample order
 __device__ __forceinline__ float zncc_chain(const Vol &V, const Frame &f, const float4 *__restrict__ tm, int M, float corrc)
 {
+    // the samples are read straight from HBM / L2 (seed scoring: one evaluation per seed, no cube to share): ZB samples -- 8 ZB
+    // corner bytes per lane -- are in flight before the first is used; the sums stay in sample order
+    constexpr int ZB = 8;
     float ag = 0.f;
-    for (int k = 0; k < M; ++k) ag += sample(V, f, tm[k]);
+    int k = 0;
+    for (; k + ZB <= M; k += ZB) {
+        float v[ZB];
+#pragma unroll
+        for (int j = 0; j < ZB; j++) v[j] = sample(V, f, tm[k + j]);
+#pragma unroll
+        for (int j = 0; j < ZB; j++) ag += v[j];
+    }
+    for (; k < M; ++k) ag += sample(V, f, tm[k]);
     ag /= (float)M;
     float corra = 0.f, corrb = 0.f;
-    for (int k = 0; k < M; ++k) {
+    for (k = 0; k + ZB <= M; k += ZB) {
+        float v[ZB], w[ZB];
+#pragma unroll
+        for (int j = 0; j < ZB; j++) {
+            const float4 t = tm[k + j];
+            v[j] = sample(V, f, t);
+            w[j] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < ZB; j++) {
+            const float di = v[j] - ag;
+            corra += di * w[j];
+            corrb = (float)((double)corrb + (double)di * (double)di); // corrb += pow(f32,2)
+        }
+    }
+    for (; k < M; ++k) {
         const float4 t = tm[k];
         const float di = sample(V, f, t) - ag;
         corra += di * t.w;
-        corrb = (float)((double)corrb + (double)di * (double)di); // corrb += pow(f32,2)
+        corrb = (float)((double)corrb + (double)di * (double)di);
     }
     const float prod = corrb * corrc;
     return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f; // tracker.cpp:1955

@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic of smc_trace / hessian_eigen from PMC counters (separate passes: FETCH_SIZE takes 3 TCC slots,
+# HBM traffic of the SMC and Frangi kernels from PMC counters (separate passes: FETCH_SIZE takes 3 TCC slots,
 # WRITE_SIZE 2), calibrated on a known byte count in the same access pattern (MI355X_MICROARCH.md, HBM).
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/traffic
 rm -rf $OUT && mkdir -p $OUT
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --output-format csv -d $OUT/calib_$ctr -- $ROOT/scripts/probes/fetch_calib > $OUT/calib_$ctr.log 2>&1
-  rocprofv3 --pmc $ctr --kernel-include-regex "smc_trace|ph_sample|ph_sums|hessian_eigen|gauss" --output-format csv -d $OUT/bench_$ctr -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra "$@" > $OUT/bench_$ctr.json 2> $OUT/bench_$ctr.err
+  rocprofv3 --pmc $ctr --kernel-include-regex "smc_trace|ph_sample|ph_sums|hessian_tile|eigen_queue|gauss" --output-format csv -d $OUT/bench_$ctr -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra "$@" > $OUT/bench_$ctr.json 2> $OUT/bench_$ctr.err
 done
 python - <<PY
 import csv, glob, collections, json
@@ -17,7 +17,7 @@ def load(pat):
     for f in glob.glob(pat, recursive=True):
         for r in csv.DictReader(open(f)):
             import re
-            m = re.search(r'(smc_trace|ph_sample|ph_sums|hessian_eigen|gauss_x_u8|gauss_axis|j8_kernel|rd|wr|fillBuffer)', r['Kernel_Name'])
+            m = re.search(r'(smc_trace|ph_sample|ph_sums|hessian_tile|eigen_queue|gauss_x_u8|gauss_axis_t|gauss_axis|j8_kernel|rd|wr|fillBuffer)', r['Kernel_Name'])
             k = m.group(1) if m else r['Kernel_Name'][:30]
             agg[(k, r['Counter_Name'])][0] += float(r['Counter_Value']); agg[(k, r['Counter_Name'])][1] += 1
     return agg
