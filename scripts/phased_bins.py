@@ -1,5 +1,5 @@
 """per-launch durations of the phased SMC kernels binned by the number of active traces.
-usage: phased_bins.py <kernel_trace.csv> [skip_fraction]   (run the profile with PNR_PHASED_GROUPS=1)"""
+usage: phased_bins.py <kernel_trace.csv> [skip_fraction]   (run the profile with PNR_BENCH_OPTS=groups=1)"""
 import csv, sys
 import numpy as np
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]

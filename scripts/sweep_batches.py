@@ -16,7 +16,7 @@ c.set_profiling(True)
 ref = None
 for rep in range(2):
     for fb, gr, mx in cfgs:
-        os.environ["PNR_BATCH_GROWTH"] = str(gr); os.environ["PNR_BATCH_MAX"] = str(mx)
+        c.set_option("replay_batches", 1); c.set_option("batch_growth", gr); c.set_option("batch_max", mx)
         c.reset_kernel_ms()
         t0 = time.time(); n2, l2, nt2, it2 = c.trace_replay(s, first_batch=fb); t1 = time.time()
         if ref is None: ref = (len(n2), l2.copy())
