@@ -494,7 +494,7 @@ __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const F
 template <int CS, bool IS2D = false, bool FAST = false>
 __device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
                                                     const float *__restrict__ ax, int iv, int parts, int p, bool active,
-                                                    float *__restrict__ stash_col, int stride)
+                                                    float *__restrict__ stash_col, int stride, int r0 = 0, int r1 = 1 << 30)
 {
     constexpr int G = CHAIN_G;
     const int lane = threadIdx.x & 63;
@@ -502,8 +502,9 @@ __device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, 
     const float r_aw = ax[nv + nu + (lane < nw ? lane : 0)];
     const float vv = ax[iv]; // wave-uniform
     const float x0 = f.px + vv * f.nvx, y0 = f.py + vv * f.nvy, z0 = f.pz + vv * f.nvz;
-    const int rows = (nu + parts - 1) / parts;
-    for (int r = 0; r < rows; ++r) {
+    int rows = (nu + parts - 1) / parts;
+    if (r1 < rows) rows = r1; // rounds [r0, r1) of the v-slice (default: all)
+    for (int r = r0; r < rows; ++r) {
         const int iu = r * parts + p;
         const bool ok = active && iu < nu;
         const int iuc = iu < nu ? iu : nu - 1;

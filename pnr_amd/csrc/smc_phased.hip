@@ -22,7 +22,7 @@
 
 namespace {
 
-enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_IT = 3, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_FAST = 12, FL_N = 16 };
+enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_IT = 3, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_FAST = 12, FL_NCH = 13, FL_N = 16 };
 constexpr int PH_THREADS = 1024; // sampling work-group: 16 waves (<= 128 VGPRs each)
 constexpr int PH_CS = 54; // the sampling kernel holds nothing but the cube in LDS: 54^3 = 157 464 B of the 160 KB
 
@@ -38,9 +38,18 @@ struct PhState {
     int *list;     // [2][cap]: traces still running in iteration it: list[it & 1][0 .. cnt[it & 1])
     int *cnt;      // [2]
     int *ctr;      // [NT] sampling work-item counter of the current iteration
+    int *uidx;     // [NT][np_pad] chain -> particle (exact duplicates among the particles are evaluated once); the last chain is the centroid
+    int *cmap;     // [NT][np_pad] particle -> chain
     int cap;
-    int ngf, rem, R, W; // full groups of 64 chains, chains in the last group, its row stride, floats per sample row
+    int np_pad;
+    int W;         // floats per sample row of a trace's stash region at most (64 per full group + the last group's stride)
+    int dedup;     // 0: every particle is its own chain
 };
+
+// chains of a trace in this iteration: FL_NCH = unique particles + the centroid (1 in the tail pass); they are laid out as
+// ngf = nch / 64 full groups of 64 lanes and a last group of rem = nch % 64 chains whose stash rows are R floats wide
+__device__ __forceinline__ int last_group_stride(int rem) { return rem > 32 ? 64 : (rem > 16 ? 32 : 16); }
+
 
 __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, const float *__restrict__ seeds6, Vol V, int np, int ni, int it_arg,
                                                    int lp, int CS)
@@ -181,6 +190,62 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     }
     __syncthreads();
     if (tid == 0) fl[FL_FAST] = sbox[7];
+    // ---- exact duplicates among the particles (after a resampling several children of one parent draw the same prediction
+    // offset: identical pose, identical likelihood -- 17 % of the evaluations of the bench workload): a particle whose six pose
+    // words equal those of an earlier particle shares that particle's chain.  Bit-identical results by construction.
+    int *uidx = P.uidx + (i64)tr * P.np_pad, *cmap = P.cmap + (i64)tr * P.np_pad;
+    if (tail) { // only the pending centroid is evaluated
+        if (tid == 0) { uidx[0] = np; fl[FL_NCH] = 1; }
+        return;
+    }
+    extern __shared__ unsigned int dsm[]; // [np] pose hash, [np] representative, then the chain number of a representative
+    unsigned int *hs = dsm;
+    int *rep = (int *)(dsm + np);
+    const unsigned int *curw = (const unsigned int *)cur;
+    auto rotl = [](unsigned int v, int r) { return (v << r) | (v >> (32 - r)); };
+    for (int k = tid; k < np; k += B) {
+        const unsigned int *q = curw + k * PSTRIDE;
+        hs[k] = q[PX] ^ rotl(q[PY], 5) ^ rotl(q[PZ], 11) ^ rotl(q[PVX], 17) ^ rotl(q[PVY], 23) ^ rotl(q[PVZ], 29);
+    }
+    __syncthreads();
+    for (int k = tid; k < np; k += B) {
+        int r = k;
+        if (P.dedup) {
+            const unsigned int hk = hs[k];
+            const unsigned int *qk = curw + k * PSTRIDE;
+            for (int j0 = 0; j0 < k && r == k; j0 += 8) { // eight hashes per round: independent LDS reads
+                unsigned int hv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) hv[u] = hs[j0 + u < np ? j0 + u : 0];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int j = j0 + u;
+                    if (r != k || j >= k || hv[u] != hk) continue; // (the pose itself is compared only when the hashes match)
+                    const unsigned int *qj = curw + j * PSTRIDE;
+                    if (qj[PX] == qk[PX] && qj[PY] == qk[PY] && qj[PZ] == qk[PZ] && qj[PVX] == qk[PVX] && qj[PVY] == qk[PVY] && qj[PVZ] == qk[PVZ]) r = j;
+                }
+            }
+        }
+        rep[k] = r;
+    }
+    __syncthreads();
+    if (tid < 64) { // chain numbers in particle order: ballots over 64 particles at a time
+        int cbase = 0;
+        for (int base = 0; base < np; base += 64) {
+            const int k = base + tid;
+            const bool is = k < np && rep[k] == k;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(is);
+            if (is) {
+                const int c = cbase + (int)__builtin_popcountll(m & ((1ull << tid) - 1ull));
+                uidx[c] = k;
+                hs[k] = (unsigned int)c;
+            }
+            cbase += (int)__builtin_popcountll(m);
+        }
+        if (tid == 0) { uidx[cbase] = np; fl[FL_NCH] = cbase + 1; } // the centroid closes the list
+    }
+    __syncthreads();
+    for (int k = tid; k < np; k += B) cmap[k] = (int)hs[rep[k]];
 }
 
 template <int CS, bool IS2D>
@@ -193,8 +258,6 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
     const int tr = P.list[lp * P.cap + slot];
     const int *fl = P.flags + (i64)tr * FL_N;
     const int it = it_arg >= 0 ? it_arg : fl[FL_IT];
-    const bool tail = (it == ni) || (fl[FL_STOP] != 0);
-    const int pending = it - 1;
     const float *cur = P.part + (i64)tr * 2 * np * PSTRIDE + (it & 1) * np * PSTRIDE;
     const float *xc_pen = P.xcs + (i64)tr * 16 + ((it & 1) ^ 1) * 8;
     Box Bx;
@@ -235,33 +298,37 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
         }
     }
     __syncthreads();
-    const int ngf = P.ngf, rem = P.rem;
+    const int nch = __builtin_amdgcn_readfirstlane(fl[FL_NCH]);
+    const int ngf = nch >> 6, rem = nch & 63, Rt = last_group_stride(rem);
+    const int *uidx = P.uidx + (i64)tr * P.np_pad;
     const int fastmask = __builtin_amdgcn_readfirstlane(fl[FL_FAST]); // sigmas whose templates all lie inside the cube and the volume
-    // work items: a full group's item is ROWS template rows (iu) of one v-slice, the packed last group's a whole v-slice
+    // work items: a full group's item is ROWS template rows (iu) of one v-slice; the last group's chains are spread over the wave
+    // `parts` times (sample_slice_packed) and its item is ROWS rounds of `parts` rows each
     constexpr int ROWS = 5;
-    int nvsum = 0, nchsum = 0;
+    const int parts = rem > 0 ? 64 / rem : 1;
+    int nchsum = 0, npksum = 0;
     for (int s = 0; s < S; s++) {
         const int nv_s = __builtin_amdgcn_readfirstlane(X.grid[s].nv), nu_s = __builtin_amdgcn_readfirstlane(X.grid[s].nu);
-        nvsum += nv_s;
         nchsum += nv_s * ((nu_s + ROWS - 1) / ROWS);
+        npksum += nv_s * (((nu_s + parts - 1) / parts + ROWS - 1) / ROWS);
     }
-    const int nfull = nchsum * ngf, nitems = nfull + (rem > 0 ? nvsum : 0);
+    const int nfull = nchsum * ngf, nitems = nfull + (rem > 0 ? npksum : 0);
     float *const tbase = P.stash + (i64)tr * P.trace_floats;
     const int lane = tid & 63;
-    // Items in descending cost: (sigma descending, v-slice, row chunk, full group), then the packed last group per
-    // (sigma, v-slice); every wave of the work-groups that share this trace pulls the next one from the trace's counter,
-    // so the waves finish within one item of each other.  A tail pass only has the centroid.
-    const int first = (tail && rem > 0) ? nfull : 0;
+    (void)ni;
+    // Items in descending cost: (sigma descending, v-slice, row chunk, full group), then the last group's per (sigma, v-slice,
+    // round chunk); every wave of the work-groups that share this trace pulls the next one from the trace's counter, so the waves
+    // finish within one item of each other.  A tail pass has one chain, the centroid: only last-group items.
     for (;;) {
         int item = 0;
         if (lane == 0) item = atomicAdd(&P.ctr[tr], 1);
-        item = first + __builtin_amdgcn_readfirstlane(item);
+        item = __builtin_amdgcn_readfirstlane(item);
         if (item >= nitems) break;
         const bool packed = item >= nfull;
         int sI = S - 1, r = packed ? item - nfull : item;
         while (sI > 0) {
             const int nv_s = __builtin_amdgcn_readfirstlane(X.grid[sI].nv), nu_s = __builtin_amdgcn_readfirstlane(X.grid[sI].nu);
-            const int c = packed ? nv_s : nv_s * ((nu_s + ROWS - 1) / ROWS) * ngf;
+            const int c = packed ? nv_s * (((nu_s + parts - 1) / parts + ROWS - 1) / ROWS) : nv_s * ((nu_s + ROWS - 1) / ROWS) * ngf;
             if (r < c) break;
             r -= c;
             sI--;
@@ -272,70 +339,63 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
         const int Ms = nv * nu * nw;
         const float *ax = X.axes + __builtin_amdgcn_readfirstlane(X.axes_off[sI]);
         float *const sbase = tbase + (i64)goff * P.W;
-        const int nch = (nu + ROWS - 1) / ROWS;
-        const int per = packed ? 1 : nch * ngf;
+        const int nch_rows = packed ? ((nu + parts - 1) / parts + ROWS - 1) / ROWS : (nu + ROWS - 1) / ROWS;
+        const int per = packed ? nch_rows : nch_rows * ngf;
         const int iv = r / per, r2 = r - iv * per;
-        const int ch = packed ? 0 : r2 / ngf, g = packed ? 0 : r2 - ch * ngf;
         if (!packed) {
-            const int k = g * 64 + lane;
-            const bool is_cen = (k == np) && (pending >= 0);
-            const bool valid = (k < np && !tail) || is_cen;
-            if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
-            const float *q = is_cen ? xc_pen : (valid ? cur + k * PSTRIDE : (tail ? xc_pen : cur));
+            const int ch = r2 / ngf, g = r2 - ch * ngf;
+            const int c = g * 64 + lane; // < nch: the group is full
+            const int k = uidx[c];
+            const float *q = (k >= np) ? xc_pen : cur + k * PSTRIDE; // (the centroid before the first one exists: zeros, discarded)
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
             if (fastmask >> sI & 1)
                 sample_slice<CS, IS2D, true>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
             else
                 sample_slice<CS, IS2D, false>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
         } else {
-            const int cnt = tail ? 1 : rem, jbase = tail ? rem - 1 : 0; // tail: the centroid's chains only
-            const int parts = 64 / cnt;
-            const bool act = lane < parts * cnt;
-            const int pp = act ? lane / cnt : 0, j = jbase + (act ? lane - pp * cnt : 0);
-            const int k = ngf * 64 + j;
-            const float *q = (k == np) ? xc_pen : cur + k * PSTRIDE; // k == np before the first centroid: zeros, discarded
+            const bool act = lane < parts * rem;
+            const int pp = act ? lane / rem : 0, j = act ? lane - pp * rem : 0;
+            const int k = uidx[ngf * 64 + j];
+            const float *q = (k >= np) ? xc_pen : cur + k * PSTRIDE;
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
-            sample_slice_packed<CS, IS2D>(V, Bx, f, nv, nu, nw, ax, iv, parts, pp, act, sbase + (i64)ngf * Ms * 64 + j, P.R);
+            sample_slice_packed<CS, IS2D>(V, Bx, f, nv, nu, nw, ax, iv, parts, pp, act, sbase + (i64)ngf * Ms * 64 + j, Rt, r2 * ROWS, r2 * ROWS + ROWS);
         }
     }
 }
 
 // one wave per (trace, sigma, chain group): the ordered sums of the chains from the stash
 constexpr int PH_CH = 32; // stash values in flight per lane (64: 256 VGPRs, slower with many traces, no faster with few)
-__global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, int np_pad, int ni, int it_arg, int lp)
+__global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, int np_pad, int ni, int it_arg, int lp, int ng_max)
 {
-    const int S = T.nsig, ng = P.ngf + (P.rem > 0 ? 1 : 0), lane = threadIdx.x;
-    const int slot = blockIdx.x / (S * ng);
+    const int S = T.nsig, lane = threadIdx.x;
+    const int slot = blockIdx.x / (S * ng_max);
     if (slot >= P.cnt[lp]) return;
     const int tr = P.list[lp * P.cap + slot];
     const int *fl = P.flags + (i64)tr * FL_N;
-    const int it = it_arg >= 0 ? it_arg : fl[FL_IT];
-    const int r = blockIdx.x - slot * (S * ng);
-    const int sI = r / ng, g = r - sI * ng;
-    const bool tail = (it == ni) || (fl[FL_STOP] != 0);
-    const int pending = it - 1;
-    const int k = g * 64 + lane;
-    const bool is_cen = (k == np) && (pending >= 0);
-    const bool valid = (k < np && !tail) || is_cen;
-    if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
+    const int r = blockIdx.x - slot * (S * ng_max);
+    const int sI = r / ng_max, g = r - sI * ng_max;
+    const int nch = fl[FL_NCH], ngf = nch >> 6, rem = nch & 63;
+    if (g > ngf || (g == ngf && rem == 0)) return; // this trace has fewer chain groups in this iteration
+    (void)np; (void)ni; (void)it_arg;
     const Grid gr = X.grid[sI];
     const int M = gr.nv * gr.nu * gr.nw;
     const float *sbase = P.stash + (i64)tr * P.trace_floats + (i64)gr.off * P.W;
     const float *wd = X.wd + gr.off;
     float cv;
-    if (g < P.ngf) {
+    bool valid = true;
+    if (g < ngf) {
         cv = zncc_from_stash<64, PH_CH>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI]);
     } else { // last group: narrow rows; lanes without a chain re-read a valid column (same 64 B granules)
-        const int j = tail ? P.rem - 1 : (lane < P.rem ? lane : P.rem - 1);
-        const float *col = sbase + (i64)P.ngf * M * 64 + j;
-        switch (P.R) {
+        valid = lane < rem;
+        const int j = valid ? lane : rem - 1;
+        const float *col = sbase + (i64)ngf * M * 64 + j;
+        switch (last_group_stride(rem)) {
         case 16: cv = zncc_from_stash<16, PH_CH>(col, M, wd, T.corrc[sI]); break;
         case 32: cv = zncc_from_stash<32, PH_CH>(col, M, wd, T.corrc[sI]); break;
-        case 48: cv = zncc_from_stash<48, PH_CH>(col, M, wd, T.corrc[sI]); break;
         default: cv = zncc_from_stash<64, PH_CH>(col, M, wd, T.corrc[sI]); break;
         }
     }
-    if (valid) P.corr[((i64)tr * S + sI) * np_pad + k] = cv;
+    if (valid) P.corr[((i64)tr * S + sI) * np_pad + g * 64 + lane] = cv; // indexed by chain
 }
 
 __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np, int np_pad, int ni, int it_arg, int lp, float Kc, float znccth,
@@ -365,7 +425,9 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
     float *xc_cur = P.xcs + (i64)tr * 16 + (it & 1) * 8;
     const float *xc_pen = P.xcs + (i64)tr * 16 + ((it & 1) ^ 1) * 8;
     int *gidx = P.idxres + (i64)tr * np;
-    for (int e = tid; e < S * np_pad; e += B) corr_ks[e] = P.corr[(i64)tr * S * np_pad + e];
+    for (int e = tid; e < S * np_pad; e += B) corr_ks[e] = P.corr[(i64)tr * S * np_pad + e]; // by chain (ph_predict's uidx / cmap)
+    const int cen = fl[FL_NCH] - 1; // the centroid is this iteration's last chain
+    const int *cmap = P.cmap + (i64)tr * P.np_pad;
     if (!tail) {
         for (int e = tid; e < np * PSTRIDE; e += B) cur[e] = gcur[e];
         for (int k = tid; k < np; k += B) { prvw[k] = gprv[k * PSTRIDE + PW]; prior[k] = P.prior[(i64)tr * np + k]; }
@@ -376,7 +438,7 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
     if (pending >= 0 && tid == 0) {
         float best = -FLT_MAX, bs = xc_pen[6];
         for (int s = 0; s < S; s++) {
-            const float cv = corr_ks[s * np_pad + np];
+            const float cv = corr_ks[s * np_pad + cen];
             if (cv > best) { best = cv; bs = T.sig[s]; }
         }
         float *xo = O.xc + ((i64)tr * ni + pending) * 8;
@@ -398,8 +460,9 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
     // ---- max over sigma, likelihood exp(Kc*corr) (:1028-1029) ----
     for (int k = tid; k < np; k += B) {
         float best = -FLT_MAX, bs = 0.f;
+        const int ck = cmap[k];
         for (int s = 0; s < S; s++) {
-            const float cv = corr_ks[s * np_pad + k];
+            const float cv = corr_ks[s * np_pad + ck];
             if (cv > best) { best = cv; bs = T.sig[s]; }
         }
         cur[k * PSTRIDE + PCORR] = best;
@@ -550,7 +613,7 @@ struct pnr_phased {
 static void phased_free(pnr_phased *h)
 {
     hipFree(h->P.part); hipFree(h->P.prior); hipFree(h->P.idxres); hipFree(h->P.corr); hipFree(h->P.xcs); hipFree(h->P.flags);
-    hipFree(h->P.stash); hipFree(h->P.list); hipFree(h->P.cnt); hipFree(h->P.ctr); hipFree(h->d_s6);
+    hipFree(h->P.stash); hipFree(h->P.list); hipFree(h->P.cnt); hipFree(h->P.ctr); hipFree(h->P.uidx); hipFree(h->P.cmap); hipFree(h->d_s6);
     hipFree(h->O.T); hipFree(h->O.stop); hipFree(h->O.xc); hipFree(h->O.xfilt); hipFree(h->O.idxres); hipFree(h->O.neff);
     h->P = PhState{};
     h->O = TraceOut{};
@@ -620,7 +683,8 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
         PNR_HIP(hipStreamCreateWithFlags(&h->st_den, hipStreamNonBlocking));
         PNR_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
     }
-    const int ngf = (np + 1) / 64, rem = (np + 1) - 64 * ngf, R = (rem + 15) / 16 * 16, W = 64 * ngf + R;
+    // stash rows of a trace hold at most np + 1 chains: full groups of 64 + the last group's stride (16 / 32 / 64)
+    const int ngf = (np + 1) / 64, rem = (np + 1) - 64 * ngf, R = rem == 0 ? 0 : (rem > 32 ? 64 : (rem > 16 ? 32 : 16)), W = 64 * ngf + R;
     const long long Mtot = E.T.Mtot, trace_floats = Mtot * W;
     size_t free_b = 0, total_b = 0;
     PNR_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -648,6 +712,8 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
         PNR_HIP(hipMalloc(&h->P.list, (size_t)cap * 2 * 4 * pnr_phased::MAXG)); // one pair of lists per trace group of the streaming tracer
         PNR_HIP(hipMalloc(&h->P.cnt, 2 * 4 * pnr_phased::MAXG));
         PNR_HIP(hipMalloc(&h->P.ctr, (size_t)cap * 4));
+        PNR_HIP(hipMalloc(&h->P.uidx, (size_t)cap * np_pad * 4));
+        PNR_HIP(hipMalloc(&h->P.cmap, (size_t)cap * np_pad * 4));
         PNR_HIP(hipMalloc(&h->d_s6, (size_t)cap * 24));
         PNR_HIP(hipMalloc(&h->O.T, (size_t)cap * 4));
         PNR_HIP(hipMalloc(&h->O.stop, (size_t)cap * 4));
@@ -665,7 +731,9 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     E.P = h->P;
     E.P.trace_floats = trace_floats;
     E.P.cap = (int)h->cap_traces;
-    E.P.ngf = ngf; E.P.rem = rem; E.P.R = R; E.P.W = W;
+    E.P.W = W;
+    E.P.np_pad = np_pad;
+    E.P.dedup = np <= 1024 ? 1 : 0; // the duplicate search is quadratic in np
     E.X.grid = (const Grid *)c->d_grid; E.X.axes = c->d_axes; E.X.axes_off = c->d_axes_off; E.X.wd = c->d_wd;
     E.X.ext_v = c->tab.ext_v; E.X.ext_uw = c->tab.ext_uw;
     for (int s2 = 0; s2 < 8; s2++) { E.X.ext_vs[s2] = s2 < S ? c->tab.ext_vs[s2] : 0.f; E.X.ext_uws[s2] = s2 < S ? c->tab.ext_uws[s2] : 0.f; }
@@ -743,7 +811,7 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
             }
             const int nsplit = pick_nsplit(active, ncu, max_split, c->opt.split_x10);
             c->tic(st);
-            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, T, X, P, (const float *)h->d_s6, V, np, ni, it, it & 1, CS);
+            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, T, X, P, (const float *)h->d_s6, V, np, ni, it, it & 1, CS);
             c->toc("smc_predict", 1, st);
             c->tic(st);
             if (V.l == 1)
@@ -752,7 +820,7 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
                 hipLaunchKernelGGL((ph_sample<CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), cube_bytes, st, V, T, X, P, np, ni, it, it & 1, active);
             c->toc("smc", 1, st);
             c->tic(st);
-            hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it, it & 1);
+            hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it, it & 1, ng);
             c->toc("smc_sums", 1, st);
             c->tic(st);
             hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), upd_lds, st, V, T, P, np, np_pad, ni, it, it & 1, c->prm.Kc, c->prm.znccth,
@@ -880,7 +948,7 @@ struct PhasedEngine final : pnr::StreamEngine {
             const int lp = q.lp;
             const int nsplit = pick_nsplit(active, E.ncu, E.max_split, split_x10);
             c->tic(st);
-            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), 0, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
+            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
             c->toc("smc_predict", 1, st);
             c->tic(st);
             if (E.V.l == 1)
@@ -889,7 +957,7 @@ struct PhasedEngine final : pnr::StreamEngine {
                 hipLaunchKernelGGL((ph_sample<PH_CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
             c->toc("smc", 1, st);
             c->tic(st);
-            hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp);
+            hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp, ng);
             c->toc("smc_sums", 1, st);
             c->tic(st);
             hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), E.upd_lds, st, E.V, E.T, P, np, np_pad, ni, -1, lp, c->prm.Kc, c->prm.znccth,
