@@ -46,6 +46,13 @@ struct PhState {
     int dedup;     // 0: every particle is its own chain
 };
 
+__device__ __forceinline__ unsigned int pose_hash(float x, float y, float z, float vx, float vy, float vz)
+{
+    auto rotl = [](unsigned int v, int r) { return (v << r) | (v >> (32 - r)); };
+    return __float_as_uint(x) ^ rotl(__float_as_uint(y), 5) ^ rotl(__float_as_uint(z), 11) ^ rotl(__float_as_uint(vx), 17) ^ rotl(__float_as_uint(vy), 23) ^
+           rotl(__float_as_uint(vz), 29);
+}
+
 // chains of a trace in this iteration: FL_NCH = unique particles + the centroid (1 in the tail pass); they are laid out as
 // ngf = nch / 64 full groups of 64 lanes and a last group of rem = nch % 64 chains whose stash rows are R floats wide
 __device__ __forceinline__ int last_group_stride(int rem) { return rem > 32 ? 64 : (rem > 16 ? 32 : 16); }
@@ -61,6 +68,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     int *fl = P.flags + (i64)tr * FL_N;
     const int it = it_arg >= 0 ? it_arg : fl[FL_IT]; // streaming mode: every trace has its own iteration count
     __shared__ int sbox[8];
+    extern __shared__ unsigned int dsm[]; // [np] pose hash, [np] representative (the duplicate search at the end)
     const bool tail = (it == ni) || (fl[FL_STOP] != 0);
     const int pending = it - 1; // the previous iteration's centroid is evaluated with this iteration's chains
     float *part = P.part + (i64)tr * 2 * np * PSTRIDE;
@@ -117,6 +125,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
                 prior[k] = T.w[(i64)vi * T.sz + s];
             }
             qx = q[PX]; qy = q[PY]; qz = q[PZ]; qvx = q[PVX]; qvy = q[PVY]; qvz = q[PVZ];
+            dsm[k] = pose_hash(qx, qy, qz, qvx, qvy, qvz);
         }
         const Frame f = make_frame(qx, qy, qz, qvx, qvy, qvz);
         const float ex = X.ext_v * fabsf(qvx) + X.ext_uw * (fabsf(f.ux) + fabsf(f.wx)) + 1.5f;
@@ -198,16 +207,9 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
         if (tid == 0) { uidx[0] = np; fl[FL_NCH] = 1; }
         return;
     }
-    extern __shared__ unsigned int dsm[]; // [np] pose hash, [np] representative, then the chain number of a representative
-    unsigned int *hs = dsm;
+    unsigned int *hs = dsm; // filled where the particles were made; later the chain number of a representative
     int *rep = (int *)(dsm + np);
     const unsigned int *curw = (const unsigned int *)cur;
-    auto rotl = [](unsigned int v, int r) { return (v << r) | (v >> (32 - r)); };
-    for (int k = tid; k < np; k += B) {
-        const unsigned int *q = curw + k * PSTRIDE;
-        hs[k] = q[PX] ^ rotl(q[PY], 5) ^ rotl(q[PZ], 11) ^ rotl(q[PVX], 17) ^ rotl(q[PVY], 23) ^ rotl(q[PVZ], 29);
-    }
-    __syncthreads();
     for (int k = tid; k < np; k += B) {
         int r = k;
         if (P.dedup) {
