@@ -241,7 +241,8 @@ struct Samples {
 
 // FAST: the caller guarantees that every sample of the group lies inside the volume (the clamp is the identity) and that its
 // corner pairs lie inside the cube (ph_predict proved it for all templates of this sigma): no clamp, no range test, no fallback.
-template <int G, int CS, bool IS2D = false, bool FAST = false>
+// PITCH: bytes between two rows of the cube in LDS (CS, or CS rounded up to a multiple of 4 where the cube is filled by LDS-DMA)
+template <int G, int CS, bool IS2D = false, bool FAST = false, int PITCH = CS>
 __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, const float (&x)[G], const float (&y)[G],
                                                    const float (&z)[G])
 {
@@ -262,7 +263,7 @@ __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, c
         const unsigned m = max(max(rx, ry), rz);
         in[j] = FAST || m < (unsigned)(CS - 1);
         all_in = all_in && in[j];
-        const unsigned l = __umul24(rz, CS * CS) + __umul24(ry, CS) + rx;
+        const unsigned l = __umul24(rz, CS * PITCH) + __umul24(ry, PITCH) + rx;
         loff[j] = in[j] ? l : 0u;
     }
 #pragma unroll
@@ -270,10 +271,10 @@ __device__ __forceinline__ Samples<G> interp_group(const Vol &V, const Box &B, c
         lds_cu8 *a = B.lds + loff[j];
         lds_cu8 *a1 = lds_plus1_opaque(a);
         c[j][0] = a[0];            c[j][1] = a1[0];
-        c[j][2] = a[CS];           c[j][3] = a1[CS];
+        c[j][2] = a[PITCH];        c[j][3] = a1[PITCH];
         if (!IS2D) {
-            c[j][4] = a[CS * CS];      c[j][5] = a1[CS * CS];
-            c[j][6] = a[CS * CS + CS]; c[j][7] = a1[CS * CS + CS];
+            c[j][4] = a[CS * PITCH];         c[j][5] = a1[CS * PITCH];
+            c[j][6] = a[CS * PITCH + PITCH]; c[j][7] = a1[CS * PITCH + PITCH];
         }
     }
     if (!FAST && __builtin_amdgcn_ballot_w64(!all_in) != 0ull) { // wave-uniform: some lane has a corner group outside the cube
@@ -451,7 +452,7 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
 // Phase A: sampling is order-free, so it is cut into work items (sigma, group of 64 particles,
 // v-slice) that the 12 waves pull from a shared counter: the long (sigma >= 4) and short chains
 // no longer pin the iteration time to the longest chain.  Values go to the stash at [sample][lane].
-template <int CS, bool IS2D = false, bool FAST = false>
+template <int CS, bool IS2D = false, bool FAST = false, int PITCH = CS>
 __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
                                              const float *__restrict__ ax, int iv, float *__restrict__ stash_lane, int iu0 = 0,
                                              int iu1 = 1 << 30)
@@ -478,7 +479,7 @@ __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const F
                 ys[j] = xy.y;
                 zs[j] = z1 + ww * f.wz;
             }
-            const Samples<G> sm = interp_group<G, CS, IS2D, FAST>(V, B, xs, ys, zs);
+            const Samples<G> sm = interp_group<G, CS, IS2D, FAST, PITCH>(V, B, xs, ys, zs);
 #pragma unroll
             for (int j = 0; j < G; j++)
                 if (iw0 + j < nw) sp[(iw0 + j) * 64] = sm.v[j];
@@ -491,7 +492,7 @@ __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const F
 // wave `parts` = 64 / cnt times, copy p of chain j taking the template rows iu = p, p + parts, ... of the v-slice.
 // Sampling is order-free, so the values are the same as in sample_slice; they go to a narrow [sample][stride] region
 // (stride = cnt rounded up to 16 floats).  The per-lane uu comes from the row register by ds_bpermute.
-template <int CS, bool IS2D = false, bool FAST = false>
+template <int CS, bool IS2D = false, bool FAST = false, int PITCH = CS>
 __device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
                                                     const float *__restrict__ ax, int iv, int parts, int p, bool active,
                                                     float *__restrict__ stash_col, int stride, int r0 = 0, int r1 = 1 << 30)
@@ -522,7 +523,7 @@ __device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, 
                 ys[j] = xy.y;
                 zs[j] = z1 + ww * f.wz;
             }
-            const Samples<G> sm = interp_group<G, CS, IS2D, FAST>(V, B, xs, ys, zs);
+            const Samples<G> sm = interp_group<G, CS, IS2D, FAST, PITCH>(V, B, xs, ys, zs);
 #pragma unroll
             for (int j = 0; j < G; j++)
                 if (ok && iw0 + j < nw) sp[(iw0 + j) * stride] = sm.v[j];

@@ -24,7 +24,8 @@ namespace {
 
 enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_IT = 3, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_FAST = 12, FL_NCH = 13, FL_N = 16 };
 constexpr int PH_THREADS = 1024; // sampling work-group: 16 waves (<= 128 VGPRs each)
-constexpr int PH_CS = 54; // the sampling kernel holds nothing but the cube in LDS: 54^3 = 157 464 B of the 160 KB
+constexpr int PH_CS = 54; // the sampling kernel holds nothing but the cube in LDS: 54 x 54 rows of 56 bytes = 163 296 B of the 160 KB (53 costs 1.5 %)
+constexpr int PH_PITCH = 56; // row pitch: a multiple of 4, so that the dword granules of the LDS-DMA staging never straddle two rows
 
 struct PhState {
     float *part;   // [NT][2][np][9]
@@ -250,6 +251,12 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     for (int k = tid; k < np; k += B) cmap[k] = (int)hs[rep[k]];
 }
 
+#ifdef PNR_SMC_STAMPS
+// diagnostic build only (make stamps): shader-clock sums over the sampling work-groups: [0] cube staging, [1] item loop of wave 0,
+// [2] work-groups, [3] items taken by wave 0 of each work-group
+__device__ unsigned long long g_ph_stamps[8];
+#endif
+
 template <int CS, bool IS2D>
 __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it_arg, int lp, int nslots)
 {
@@ -265,20 +272,39 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
     Box Bx;
     Bx.lds = (lds_cu8 *)cube;
     Bx.ox = fl[FL_OX]; Bx.oy = fl[FL_OY]; Bx.oz = fl[FL_OZ];
-    { // stage the rows of the cube the templates can reach.  The staging is latency-bound: a wave-load fetches four
-      // (z,y) rows, 16 lanes x 4 bytes each (unaligned dwords; lanes past the row end are not stored), NR loads in flight.
-        constexpr int NR = 8;
+#ifdef PNR_SMC_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st_items = 0;
+    if (Bx.ox + Bx.oy + Bx.oz + fl[FL_Y0] + fl[FL_Y1] + fl[FL_Z0] + fl[FL_Z1] == -12345) return; // the flags have landed
+    const unsigned long long st0b = __builtin_amdgcn_s_memtime();
+#endif
+    { // Stage the rows of the cube the templates can reach: a wave-load fetches four (z,y) rows, 16 lanes x one unaligned dword
+      // each, NR of them in flight per wave.  What made the first version slow (45 k cycles per work-group, 18 % of the kernel;
+      // scripts/ph_stamps.py) was neither the memory latency (8, 12 or 23 loads in flight: the same), nor the unaligned addresses
+      // (aligned dwords + DPP shift + v_alignbyte: the same), nor the path into LDS (LDS-DMA: global_load_lds_dword lands one
+      // 256-byte block per ~96 cycles and CU, 57 k cycles for a cube) but the address arithmetic: a division by the run-time row
+      // count per load and four byte writes per dword.  The (plane, row) pair now advances incrementally, and the rows are
+      // PH_PITCH = 56 bytes apart in LDS so that every dword lands with one aligned ds_write_b32 (the last dword of a row carries
+      // two pad bytes).
+        static_assert(PH_PITCH % 4 == 0 && PH_PITCH >= CS && PH_PITCH <= 64, "one dword per lane, 16 lanes per row");
+        constexpr int NR = 16;
         typedef unsigned __attribute__((aligned(1))) u32u;
         const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6, sub = lane >> 4, l4 = (lane & 15) * 4;
         const int y0 = fl[FL_Y0], ny = fl[FL_Y1] - y0, z0 = fl[FL_Z0], nrows = (fl[FL_Z1] - z0) * ny;
         const i64 nvox = V.wh * V.l;
-        for (int r0 = wv * 4 + sub; r0 < nrows + sub; r0 += NR * nwv * 4) { // wave-uniform trip count
+        unsigned *const cube32 = (unsigned *)cube;
+        const int stride = nwv * 4;                       // rows between two loads of a lane
+        const int sq = stride / ny, sr = stride - sq * ny; // wave-uniform: one division per work-group
+        int r = wv * 4 + sub;
+        int zq = r / ny, yr = r - zq * ny;                 // plane / row of r, advanced without dividing again
+        for (; r - sub < nrows; ) { // wave-uniform trip count (r - sub is the wave's first row of this round)
             unsigned v[NR];
             int at[NR];
+            bool ok[NR];
 #pragma unroll
             for (int j = 0; j < NR; j++) {
-                const int r = r0 + j * nwv * 4 < nrows ? r0 + j * nwv * 4 : nrows - 1;
-                const int zz = z0 + r / ny, yy = y0 + (r - (r / ny) * ny);
+                ok[j] = r < nrows;
+                const int zz = z0 + (ok[j] ? zq : 0), yy = y0 + (ok[j] ? yr : 0);
                 const int zg = Bx.oz + zz < V.l ? Bx.oz + zz : V.l - 1, yg = Bx.oy + yy < V.h ? Bx.oy + yy : V.h - 1;
                 const i64 idx = (i64)zg * V.wh + (i64)yg * V.w + Bx.ox + l4;
                 if (idx + 3 < nvox) {
@@ -286,20 +312,21 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
                 } else { // the last bytes of the volume: byte loads, clamped (values past the row end are never addressed)
                     v[j] = 0;
 #pragma unroll
-                    for (int b = 0; b < 4; b++) v[j] |= (unsigned)V.img[idx + b < nvox ? idx + b : nvox - 1] << (8 * b);
+                    for (int q = 0; q < 4; q++) v[j] |= (unsigned)V.img[idx + q < nvox ? idx + q : nvox - 1] << (8 * q);
                 }
-                at[j] = (zz * CS + yy) * CS + l4;
+                at[j] = ((zz * CS + yy) * PH_PITCH + l4) >> 2;
+                r += stride; zq += sq; yr += sr;
+                if (yr >= ny) { yr -= ny; zq++; }
             }
 #pragma unroll
             for (int j = 0; j < NR; j++)
-                if (r0 + j * nwv * 4 < nrows) {
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (l4 + b < CS) cube[at[j] + b] = (unsigned char)(v[j] >> (8 * b));
-                }
+                if (ok[j] && l4 < PH_PITCH) cube32[at[j]] = v[j];
         }
     }
     __syncthreads();
+#ifdef PNR_SMC_STAMPS
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     const int nch = __builtin_amdgcn_readfirstlane(fl[FL_NCH]);
     const int ngf = nch >> 6, rem = nch & 63, Rt = last_group_stride(rem);
     const int *uidx = P.uidx + (i64)tr * P.np_pad;
@@ -326,6 +353,9 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
         if (lane == 0) item = atomicAdd(&P.ctr[tr], 1);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= nitems) break;
+#ifdef PNR_SMC_STAMPS
+        st_items++;
+#endif
         const bool packed = item >= nfull;
         int sI = S - 1, r = packed ? item - nfull : item;
         while (sI > 0) {
@@ -351,18 +381,28 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
             const float *q = (k >= np) ? xc_pen : cur + k * PSTRIDE; // (the centroid before the first one exists: zeros, discarded)
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
             if (fastmask >> sI & 1)
-                sample_slice<CS, IS2D, true>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+                sample_slice<CS, IS2D, true, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
             else
-                sample_slice<CS, IS2D, false>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+                sample_slice<CS, IS2D, false, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
         } else {
             const bool act = lane < parts * rem;
             const int pp = act ? lane / rem : 0, j = act ? lane - pp * rem : 0;
             const int k = uidx[ngf * 64 + j];
             const float *q = (k >= np) ? xc_pen : cur + k * PSTRIDE;
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
-            sample_slice_packed<CS, IS2D>(V, Bx, f, nv, nu, nw, ax, iv, parts, pp, act, sbase + (i64)ngf * Ms * 64 + j, Rt, r2 * ROWS, r2 * ROWS + ROWS);
+            sample_slice_packed<CS, IS2D, false, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, parts, pp, act, sbase + (i64)ngf * Ms * 64 + j, Rt, r2 * ROWS, r2 * ROWS + ROWS);
         }
     }
+#ifdef PNR_SMC_STAMPS
+    if (tid == 0) {
+        const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_ph_stamps[0], st1 - st0);
+        atomicAdd(&g_ph_stamps[4], st0b - st0);
+        atomicAdd(&g_ph_stamps[1], st2 - st1);
+        atomicAdd(&g_ph_stamps[2], 1ull);
+        atomicAdd(&g_ph_stamps[3], st_items);
+    }
+#endif
 }
 
 // one wave per (trace, sigma, chain group): the ordered sums of the chains from the stash
@@ -623,6 +663,15 @@ static void phased_free(pnr_phased *h)
     h->cap_traces = h->cap_dbg = 0;
 }
 
+#ifdef PNR_SMC_STAMPS
+extern "C" int pnr_debug_ph_stamps(unsigned long long *out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ph_stamps), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ph_stamps), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
 void pnr_phased_destroy(pnr_phased *h)
 {
     if (!h) return;
@@ -744,7 +793,7 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     PNR_HIP(hipGetDeviceProperties(&prop, c->device));
     E.ncu = prop.multiProcessorCount;
     E.np = np; E.ni = ni; E.S = S; E.np_pad = np_pad; E.ng = ngf + (rem > 0 ? 1 : 0); E.dbg_iters = dbg_iters;
-    E.cube_bytes = (size_t)PH_CS * PH_CS * PH_CS;
+    E.cube_bytes = (size_t)PH_CS * PH_CS * PH_PITCH;
     E.upd_lds = ((size_t)np * PSTRIDE + 4 * (size_t)np + (size_t)S * np_pad + 2 + 2 + 8) * 4;
     E.trace_floats = trace_floats;
     E.NT = NT;
