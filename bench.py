@@ -199,7 +199,27 @@ def main():
     ctx.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
     ctx.set_profiling(not os.environ.get("PNR_BENCH_NOPROF"))  # NOPROF: how much do the HIP events of the kernel timers cost? (diagnostic; no roofline then)
     nvox = S * S * S
-    exchange = multigpu.make_exchange(dist, world, coll_dev) if shard else None
+    # the per-poll exchange of finished trace records: host data on both ends (pinned records in, host replay out), so on ONE node
+    # it goes through the library's shared-memory all-gather (a few microseconds, no Python in the loop); across nodes, or with
+    # PNR_BENCH_EXCHANGE=rccl, through RCCL (torch.distributed.all_gather_into_tensor with pinned staging)
+    exchange, exchange_kind = None, None
+    if shard:
+        want = os.environ.get("PNR_BENCH_EXCHANGE", "shm" if local_world == world else "rccl")
+        if want == "shm":
+            ok = torch.tensor([1], dtype=torch.int32, device=coll_dev)
+            if rank == 0:
+                try:
+                    probe = pnr_amd.lib.ShmExchange(f"pnr_probe_{os.getpid()}", 0, 1, 64)
+                    probe.close()
+                except Exception:  # noqa: BLE001 -- no usable /dev/shm: every rank falls back together
+                    ok[0] = 0
+            dist.broadcast(ok, 0)
+            if int(ok.item()):
+                exchange = pnr_amd.lib.ShmExchange(f"pnr_bench_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}", rank, world, 1 << 20)
+                exchange_kind = "shared memory (one node)"
+        if exchange is None:
+            exchange = multigpu.make_exchange(dist, world, coll_dev)
+            exchange_kind = "RCCL all_gather_into_tensor" if backend == "nccl" else backend
 
     def step():
         st = {}
@@ -308,7 +328,8 @@ def main():
             par = "1 GPU"
         elif shard:
             par = (f"one stack on {world} GPUs: Frangi + seeds + seed scores in z-slabs, sorted seeds round-robin; RCCL all-reduce(min,max), all-gather of "
-                   "seeds, per-poll all-gather of finished trace records; every rank replays in global seed order")
+                   "seeds; finished trace records all-gathered once per rotation of the trace groups (host data: shared memory on one node, RCCL otherwise); "
+                   "every rank replays in global seed order")
         else:
             par = f"{world} independent stacks, one per GPU; RCCL gather of node graphs"
         out = {
@@ -318,7 +339,7 @@ def main():
             "dtype": "f32 (+f64 3x3 eigen-solver)", "data": "synthetic",
             "config": {"workload": f"{S}^3 synthetic u8 stack (tests/synth.py seed {stack_seed}), scales={{2,4,6}}, zdist=2, np={a.np}, ni={a.ni}, "
                                    f"first {a.seeds} sorted seeds traced in both directions per stack, tolerance=5, znccth=0.3, step=2, kappa=3",
-                       "parallelism": par, "backend": backend if world > 1 else None, "options": opts or None},
+                       "parallelism": par, "backend": backend if world > 1 else None, "record_exchange": exchange_kind, "options": opts or None},
             "roofline": {"kernel": kname, "bound": "lds-gather/valu", "bytes_per_launch": bytes_launch, "avg_launch_ms": smc_ms / max(smc_n, 1), "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "note": "ALGORITHMIC gather bytes, 8*sum(M_sigma)=%d B per particle evaluation, over the launch time of the sampling kernel alone, "

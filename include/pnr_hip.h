@@ -212,6 +212,16 @@ int pnr_trace_replay_sharded(pnr_ctx *ctx, const pnr_seed *seeds, int64_t n, int
                              void *user, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links,
                              int64_t cap_links, int64_t *n_links, int64_t *n_traces_used, int64_t *n_iterations_here);
 
+/* A ready-made exchange for ranks that share ONE host (the 8 GPUs of a node): an all-gather through POSIX shared memory.  The
+ * records being exchanged live in pinned host memory and are consumed by the host replay, so a host-side transport saves the
+ * host -> device -> xGMI -> device -> host round trip of a device collective (a few microseconds per exchange).  `name` must be the
+ * same on all ranks and unique to the job; rank 0 creates the segment, the call returns when all `world` ranks are attached.
+ * Pass pnr_shm_allgather as `exchange` and the handle as `user`.  capacity_bytes >= the largest block ever exchanged. */
+typedef struct pnr_shm_exchange pnr_shm_exchange;
+int pnr_shm_exchange_open(const char *name, int rank, int world, int64_t capacity_bytes, pnr_shm_exchange **out);
+int pnr_shm_allgather(void *user, const void *send, void *recv, int64_t bytes_per_rank);
+void pnr_shm_exchange_close(pnr_shm_exchange *x);
+
 /* The scheduler behind pnr_trace_replay[_sharded] (stream_sched.h) over a HOST engine that plays back map-free traces which
  * `trace(user, pos_dir[6], &T, xc[ni])` supplies (0 = ok; rows 0..min(T, ni)-1 of xc valid) -- pure host code, no GPU: the
  * multi-process tests drive the window / admission / exchange / replay logic with it, and a recorded workload can be

@@ -1,0 +1,178 @@
+// shm_exchange.cpp -- an all-gather between the processes of ONE host through POSIX shared memory: the transport of
+// pnr_trace_replay_sharded's per-poll exchange when all ranks share a node (8 GPUs of one MI355X box).  The records that are
+// exchanged are written by the GPU into pinned HOST memory and consumed by the HOST replay, so a host-side transport saves the
+// host -> device -> xGMI -> device -> host round trip of a device collective: an exchange costs a few microseconds instead of
+// ~100 us.  (Across hosts, or if the processes cannot share memory, the exchange callback is RCCL: pnr_amd/multigpu.py.)
+// The same segment serves the few other collectives of the sharded path in the C++ host (advantra_cli --ranks N).
+//
+// Layout: header | 2 x world x capacity bytes (double-buffered).  One sense-reversing barrier per exchange: a rank writes its block
+// of parity p, waits for everybody, reads all blocks of parity p; it can only reach the exchange after the next one -- which
+// reuses parity p -- after every rank has passed the next barrier, i.e. has finished reading.
+#include "../../include/pnr_hip.h"
+#include <atomic>
+#include <cerrno>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fcntl.h>
+#include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+
+namespace pnr { void set_error(const char *fmt, ...); }
+
+namespace {
+struct ShmHeader {
+    std::atomic<uint32_t> magic;   // set last by the creator
+    uint32_t world;
+    uint64_t capacity;             // bytes per rank and buffer
+    std::atomic<uint32_t> arrived; // barrier: ranks that have arrived in this phase
+    std::atomic<uint32_t> phase;   // barrier: generation
+    std::atomic<uint32_t> attached, failed;
+};
+constexpr uint32_t SHM_MAGIC = 0x504e5258u; // "PNRX"
+constexpr size_t HDR = 256;
+} // namespace
+
+struct pnr_shm_exchange {
+    std::string name;
+    int rank = 0, world = 1, fd = -1;
+    size_t bytes = 0;
+    unsigned char *base = nullptr;
+    ShmHeader *h = nullptr;
+    uint64_t round = 0;
+    double timeout_s = 300.0;
+    bool owner = false;
+};
+
+static bool shm_barrier(pnr_shm_exchange *x)
+{
+    ShmHeader *h = x->h;
+    const uint32_t gen = h->phase.load(std::memory_order_acquire);
+    if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)x->world) {
+        h->arrived.store(0, std::memory_order_relaxed);
+        h->phase.store(gen + 1, std::memory_order_release);
+        return true;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0; h->phase.load(std::memory_order_acquire) == gen; spins++) {
+        if (h->failed.load(std::memory_order_relaxed)) return false;
+        if ((spins & 1023) == 1023) {
+            std::this_thread::yield();
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > x->timeout_s) {
+                h->failed.store(1, std::memory_order_relaxed);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+extern "C" {
+
+int pnr_shm_exchange_open(const char *name, int rank, int world, int64_t capacity_bytes, pnr_shm_exchange **out)
+{
+    if (!name || !out || world < 1 || rank < 0 || rank >= world || capacity_bytes < 16) {
+        pnr::set_error("pnr_shm_exchange_open: bad argument");
+        return PNR_E_ARG;
+    }
+    *out = nullptr;
+    pnr_shm_exchange *x = new pnr_shm_exchange();
+    x->name = name[0] == '/' ? name : std::string("/") + name;
+    x->rank = rank; x->world = world;
+    const size_t cap = ((size_t)capacity_bytes + 63) / 64 * 64;
+    x->bytes = HDR + 2 * (size_t)world * cap;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (rank == 0) {
+        shm_unlink(x->name.c_str()); // a stale segment of a crashed run
+        x->fd = shm_open(x->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (x->fd < 0 || ftruncate(x->fd, (off_t)x->bytes) != 0) {
+            pnr::set_error("shm_open / ftruncate of %s (%zu B) failed: %s", x->name.c_str(), x->bytes, strerror(errno));
+            if (x->fd >= 0) { close(x->fd); shm_unlink(x->name.c_str()); }
+            delete x;
+            return PNR_E_NOMEM;
+        }
+        x->owner = true;
+    } else {
+        for (;;) { // the creator may not be there yet
+            x->fd = shm_open(x->name.c_str(), O_RDWR, 0600);
+            struct stat sb;
+            if (x->fd >= 0 && fstat(x->fd, &sb) == 0 && (size_t)sb.st_size >= x->bytes) break;
+            if (x->fd >= 0) { close(x->fd); x->fd = -1; }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+                pnr::set_error("shared segment %s did not appear", x->name.c_str());
+                delete x;
+                return PNR_E_STATE;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+    }
+    x->base = (unsigned char *)mmap(nullptr, x->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, x->fd, 0);
+    if (x->base == (unsigned char *)MAP_FAILED) {
+        pnr::set_error("mmap of %s failed: %s", x->name.c_str(), strerror(errno));
+        close(x->fd);
+        if (x->owner) shm_unlink(x->name.c_str());
+        delete x;
+        return PNR_E_NOMEM;
+    }
+    x->h = (ShmHeader *)x->base;
+    if (rank == 0) {
+        x->h->world = (uint32_t)world;
+        x->h->capacity = cap;
+        x->h->arrived.store(0); x->h->phase.store(0); x->h->attached.store(0); x->h->failed.store(0);
+        x->h->magic.store(SHM_MAGIC, std::memory_order_release);
+    } else {
+        while (x->h->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+                pnr::set_error("shared segment %s was never initialised", x->name.c_str());
+                munmap(x->base, x->bytes); close(x->fd);
+                delete x;
+                return PNR_E_STATE;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (x->h->world != (uint32_t)world || x->h->capacity != cap) {
+            pnr::set_error("shared segment %s belongs to a different job (world %u, capacity %llu)", x->name.c_str(), x->h->world, (unsigned long long)x->h->capacity);
+            munmap(x->base, x->bytes); close(x->fd);
+            delete x;
+            return PNR_E_STATE;
+        }
+    }
+    x->h->attached.fetch_add(1);
+    if (!shm_barrier(x)) { // everybody is attached: the name can go (the mappings stay)
+        pnr::set_error("ranks did not all attach to %s", x->name.c_str());
+        munmap(x->base, x->bytes); close(x->fd);
+        if (x->owner) shm_unlink(x->name.c_str());
+        delete x;
+        return PNR_E_STATE;
+    }
+    if (x->owner) shm_unlink(x->name.c_str());
+    *out = x;
+    return PNR_OK;
+}
+
+// pnr_allgather_fn: user = the pnr_shm_exchange
+int pnr_shm_allgather(void *user, const void *send, void *recv, int64_t bytes)
+{
+    pnr_shm_exchange *x = (pnr_shm_exchange *)user;
+    if (!x || !send || !recv || bytes < 0 || (uint64_t)bytes > x->h->capacity) return PNR_E_ARG;
+    const size_t cap = (size_t)x->h->capacity;
+    unsigned char *buf = x->base + HDR + (size_t)(x->round & 1) * (size_t)x->world * cap;
+    std::memcpy(buf + (size_t)x->rank * cap, send, (size_t)bytes);
+    if (!shm_barrier(x)) return PNR_E_STATE;
+    for (int r = 0; r < x->world; r++) std::memcpy((unsigned char *)recv + (size_t)r * (size_t)bytes, buf + (size_t)r * cap, (size_t)bytes);
+    x->round++;
+    return PNR_OK;
+}
+
+void pnr_shm_exchange_close(pnr_shm_exchange *x)
+{
+    if (!x) return;
+    if (x->base) munmap(x->base, x->bytes);
+    if (x->fd >= 0) close(x->fd);
+    delete x;
+}
+
+} // extern "C"

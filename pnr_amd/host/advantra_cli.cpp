@@ -3,18 +3,26 @@
 // becomes
 //   advantra_cli [-v] [--save-midres] [--rng-seed N] [-g device] [-d w,h,l for .raw] -f advantra_func -i <inimg_file> -p <11 parameters>
 // (-p takes the rest of the line, as in vaa3d: put the driver's own flags before it)
+//   --ranks N [--share-gpu]: N processes of this host, one GPU each (device = -g + rank; --share-gpu: all on -g, for rehearsals),
+//   reconstruct the ONE stack together; the processes are forked before anything touches a GPU and joined through shared memory.
 // Exit code: 0 = dofunc returned true, 1 = dofunc returned false (usage error).
 #include "advantra_host.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <sys/wait.h>
+#include <unistd.h>
 
 int main(int argc, char **argv)
 {
     std::vector<char *> infiles, paras;
     std::string func = "advantra_func", raw_dims;
-    int device = 0;
+    int device = 0, ranks = 1;
+    bool share_gpu = false;
     for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "--ranks") && i + 1 < argc) { ranks = atoi(argv[++i]); continue; }
+        if (!strcmp(argv[i], "--share-gpu")) { share_gpu = true; continue; }
         if (!strcmp(argv[i], "-x") && i + 1 < argc) { i++; continue; } // plugin name: ignored
         if (!strcmp(argv[i], "-f") && i + 1 < argc) { func = argv[++i]; continue; }
         if (!strcmp(argv[i], "-g") && i + 1 < argc) { device = atoi(argv[++i]); continue; }
@@ -30,5 +38,32 @@ int main(int argc, char **argv)
         return 0;
     }
     if (func != "advantra_func") return 1; // dofunc: unknown function -> false
-    return advantra::advantra_func(infiles, paras, device, raw_dims) ? 0 : 1;
+    if (ranks <= 1) return advantra::advantra_func(infiles, paras, device, raw_dims) ? 0 : 1;
+    if (ranks > 64) { fprintf(stderr, "--ranks: at most 64\n"); return 1; }
+    // one process per GPU, forked here -- nothing has touched a GPU yet -- and joined through a shared-memory segment
+    const std::string name = "pnr_cli_" + std::to_string((long long)getpid());
+    std::vector<pid_t> kids;
+    for (int r = 0; r < ranks; r++) {
+        const pid_t pid = fork();
+        if (pid < 0) { perror("fork"); return 1; }
+        if (pid == 0) {
+            advantra::Settings &S = advantra::settings();
+            S.rank = r; S.world = ranks;
+            if (pnr_shm_exchange_open(name.c_str(), r, ranks, 1 << 18, &S.exchange) != PNR_OK) {
+                fprintf(stderr, "rank %d: %s\n", r, pnr_last_error());
+                _exit(1);
+            }
+            const bool okr = advantra::advantra_func(infiles, paras, share_gpu ? device : device + r, raw_dims);
+            pnr_shm_exchange_close(S.exchange);
+            fflush(stdout); fflush(stderr);
+            _exit(okr ? 0 : 1);
+        }
+        kids.push_back(pid);
+    }
+    int worst = 0;
+    for (pid_t k : kids) {
+        int st = 0;
+        if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) worst = 1;
+    }
+    return worst;
 }

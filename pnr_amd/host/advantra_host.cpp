@@ -2,7 +2,9 @@
 // through the C ABI into libpnr_hip.so.
 #include "advantra_host.h"
 #include <algorithm>
+#include <cfloat>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -294,45 +296,136 @@ bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *>
     return true;
 }
 
+// ---- the few collectives of the sharded path, over the shared-memory all-gather of the ranks of this host -------------------
+namespace {
+constexpr size_t XCHUNK = 1 << 18; // bytes per rank and call (the segment is opened with this capacity)
+bool allgather_bytes(pnr_shm_exchange *x, int world, const void *send, size_t n, std::vector<unsigned char> &out)
+{
+    out.assign(n * (size_t)world, 0);
+    std::vector<unsigned char> sb(XCHUNK), rb(XCHUNK * (size_t)world);
+    for (size_t off = 0; off < n || off == 0; off += XCHUNK) {
+        const size_t m = std::min(XCHUNK, n - off);
+        if (m) std::memcpy(sb.data(), (const unsigned char *)send + off, m);
+        if (pnr_shm_allgather(x, sb.data(), rb.data(), (int64_t)m) != PNR_OK) return false;
+        for (int r = 0; r < world; r++)
+            if (m) std::memcpy(out.data() + (size_t)r * n + off, rb.data() + (size_t)r * m, m);
+        if (n == 0) break;
+    }
+    return true;
+}
+} // namespace
+
 bool reconstruction_func(const unsigned char *data1d, long long w, long long h, long long l, const std::string &inimg_file,
                          const std::vector<std::string> &paras, pnr_params p, int device, Result *result)
 {
+    const int rank = settings().rank, world = settings().world;
+    pnr_shm_exchange *const X = settings().exchange;
+    if (world > 1 && (!X || l < 2)) {
+        fprintf(stderr, "--ranks needs a stack of at least 2 planes and an open exchange\n");
+        return false;
+    }
+    if (rank != 0) { // only rank 0 talks
+        if (!freopen("/dev/null", "w", stdout)) return false;
+    }
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     p.rng_seed = settings().rng_seed;
     printf("-------------  ADVANTRA  -------------\n");
     pnr_ctx *ctx = nullptr;
-    if (pnr_create(&p, device, &ctx) != PNR_OK || pnr_set_volume(ctx, data1d, w, h, l) != PNR_OK) {
+    if (pnr_create(&p, device, &ctx) != PNR_OK) {
         fprintf(stderr, "%s\n", pnr_last_error());
-        pnr_destroy(ctx);
         return false;
     }
+    pnr_set_option(ctx, "local_ranks", world);
     Result R;
     bool ok = true;
-    if (p.somaradius > 0) { // SOMA EXTR. (:2426-2486): erosion, xy blur, max-entropy threshold, regions -> soma nodes
+    auto run_soma = [&]() { // SOMA EXTR. (:2426-2486): erosion, xy blur, max-entropy threshold, regions -> soma nodes
+        if (p.somaradius <= 0) { printf("no soma detection\n"); return; }
         auto ts = clk::now();
         int32_t th = 0;
         int64_t nsoma = 0;
-        ok = pnr_soma(ctx, nullptr, &th, &nsoma) == PNR_OK;
+        ok = ok && pnr_soma(ctx, nullptr, &th, &nsoma) == PNR_OK;
         printf("imerode(%d) imgaussian(%d) maxentropy_th() %d  %lld soma regions  %.3f sec.\n", p.somaradius, p.somaradius, (int)th, (long long)nsoma,
                std::chrono::duration<double>(clk::now() - ts).count());
-    } else {
-        printf("no soma detection\n");
-    }
-    auto t0 = clk::now();
-    ok = ok && pnr_frangi(ctx, &R.Jmin, &R.Jmax) == PNR_OK; // :2496-2512
-    auto t1 = clk::now();
-    const pnr_seed *found = nullptr;
-    int64_t nfound = 0;
-    ok = ok && pnr_extract_seeds(ctx, &found, &nfound) == PNR_OK; // :2549
-    auto t2 = clk::now();
+    };
     std::vector<pnr_seed> seeds;
-    int64_t nseeds = 0;
-    if (ok) {
-        seeds.assign(found, found + nfound);
-        printf("seed extraction... %gk seeds,  %g sec.\n", nfound / 1000.0, secs(t1, t2));
-        ok = pnr_score_filter_sort_seeds(ctx, seeds.data(), nfound, &nseeds) == PNR_OK; // :2561-2586
-        seeds.resize((size_t)nseeds);
+    int64_t nfound = 0, nseeds = 0;
+    auto t0 = clk::now(), t1 = t0, t2 = t0;
+    if (world == 1) {
+        ok = pnr_set_volume(ctx, data1d, w, h, l) == PNR_OK;
+        if (ok) run_soma();
+        t0 = clk::now();
+        ok = ok && pnr_frangi(ctx, &R.Jmin, &R.Jmax) == PNR_OK; // :2496-2512
+        t1 = clk::now();
+        const pnr_seed *found = nullptr;
+        ok = ok && pnr_extract_seeds(ctx, &found, &nfound) == PNR_OK; // :2549
+        t2 = clk::now();
+        if (ok) {
+            seeds.assign(found, found + nfound);
+            printf("seed extraction... %gk seeds,  %g sec.\n", nfound / 1000.0, secs(t1, t2));
+            ok = pnr_score_filter_sort_seeds(ctx, seeds.data(), nfound, &nseeds) == PNR_OK; // :2561-2586
+            seeds.resize((size_t)nseeds);
+        }
+    } else {
+        // this rank's z-slab with its halo (the z pass of the widest Gaussian + the radius-2 Hessian stencil): exact Frangi / seeds
+        // of the planes it owns, no halo exchange -- every rank has the whole stack
+        float smax = 0;
+        for (int i = 0; i < p.nsig; i++) smax = std::max(smax, p.sig[i]);
+        const long long halo = (long long)std::ceil(3 * (smax / p.zdist)) + 2;
+        const long long z0 = l * rank / world, z1 = l * (rank + 1) / world, zlo = std::max(0LL, z0 - halo), zhi = std::min(l, z1 + halo);
+        float mm[2] = {FLT_MAX, -FLT_MAX}; // (min, max) of J over the owned planes
+        const pnr_seed *found = nullptr;
+        int64_t nmine = 0;
+        std::vector<pnr_seed> mine;
+        if (z1 > z0) {
+            ok = pnr_set_volume(ctx, data1d + zlo * w * h, w, h, zhi - zlo) == PNR_OK;
+            ok = ok && pnr_frangi_slab(ctx, z0 - zlo, z1 - zlo, &mm[0], &mm[1]) == PNR_OK;
+        }
+        std::vector<unsigned char> all;
+        if (!allgather_bytes(X, world, mm, sizeof(mm), all)) ok = false; // the 2-float all-reduce
+        R.Jmin = FLT_MAX; R.Jmax = -FLT_MAX;
+        for (int r = 0; r < world && ok; r++) {
+            float q[2];
+            std::memcpy(q, all.data() + (size_t)r * sizeof(q), sizeof(q));
+            R.Jmin = std::min(R.Jmin, q[0]); R.Jmax = std::max(R.Jmax, q[1]);
+        }
+        t1 = clk::now();
+        if (ok && z1 > z0) {
+            ok = pnr_quantise_j8(ctx, R.Jmin, R.Jmax) == PNR_OK && pnr_extract_seeds_range(ctx, z0 - zlo, z1 - zlo, &found, &nmine) == PNR_OK;
+            if (ok) {
+                mine.assign(found, found + nmine);
+                for (auto &sd : mine) sd.z += (float)zlo;
+            }
+        }
+        t2 = clk::now();
+        ok = ok && pnr_set_volume(ctx, data1d, w, h, l) == PNR_OK; // scoring and tracing see the whole stack
+        if (ok) run_soma();
+        int64_t cnt[2] = {nmine, 0};
+        if (ok && nmine) ok = pnr_score_filter_seeds(ctx, mine.data(), nmine, &cnt[1]) == PNR_OK; // this slab's seeds: znccBBB + threshold
+        if (!ok) cnt[0] = -1; // a rank that failed says so: every collective up to here was entered by everybody, none after is
+        std::vector<unsigned char> counts;
+        if (!allgather_bytes(X, world, cnt, sizeof(cnt), counts)) ok = false;
+        int64_t mx = 0;
+        std::vector<int64_t> kept((size_t)world);
+        for (int r = 0; r < world; r++) {
+            int64_t q[2] = {-1, 0};
+            if (counts.size() >= (size_t)(r + 1) * sizeof(q)) std::memcpy(q, counts.data() + (size_t)r * sizeof(q), sizeof(q));
+            if (q[0] < 0) { if (ok) fprintf(stderr, "rank %d failed\n", r); ok = false; continue; }
+            nfound += q[0]; kept[(size_t)r] = q[1]; mx = std::max(mx, q[1]);
+        }
+        mine.resize((size_t)mx); // padded payloads
+        std::vector<unsigned char> pay;
+        if (ok && !allgather_bytes(X, world, mine.data(), (size_t)mx * sizeof(pnr_seed), pay)) ok = false;
+        for (int r = 0; r < world && ok; r++) { // rank order = the z-major order of the unsharded extraction
+            const pnr_seed *q = (const pnr_seed *)(pay.data() + (size_t)r * (size_t)mx * sizeof(pnr_seed));
+            seeds.insert(seeds.end(), q, q + kept[(size_t)r]);
+        }
+        if (ok) {
+            printf("seed extraction... %gk seeds,  %g sec.\n", nfound / 1000.0, secs(t1, t2));
+            nseeds = (int64_t)seeds.size();
+            if (nseeds) ok = pnr_sort_seeds(ctx, seeds.data(), nseeds, &nseeds) == PNR_OK; // the list one GPU would have
+            seeds.resize((size_t)nseeds);
+        }
     }
     auto t3 = clk::now();
     int64_t nn = 0, nl = 0, used = 0, iters = 0;
@@ -341,7 +434,10 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
         // :2658-2710: the particle filters on the GPU (a window of traces refilled as they stop), the bookkeeping replayed on the
         // host in seed order; the graph stays in the context and is fetched once its size is known
         if (settings().verbose) pnr_set_option(ctx, "trace_log", 1);
-        ok = pnr_trace_replay(ctx, seeds.data(), nseeds, 0, nullptr, 0, &nn, nullptr, 0, &nl, &used, &iters) == PNR_OK;
+        if (world == 1)
+            ok = pnr_trace_replay(ctx, seeds.data(), nseeds, 0, nullptr, 0, &nn, nullptr, 0, &nl, &used, &iters) == PNR_OK;
+        else // every rank traces seeds rank, rank + world, ...; finished traces are exchanged and replayed in seed order on every rank
+            ok = pnr_trace_replay_sharded(ctx, seeds.data(), nseeds, rank, world, pnr_shm_allgather, X, nullptr, 0, &nn, nullptr, 0, &nl, &used, &iters) == PNR_OK;
         if (ok) {
             R.nodes.resize((size_t)nn);
             R.links.resize((size_t)(2 * nl));
@@ -378,6 +474,11 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
         return false;
     }
     R.n_seeds_init = nfound; R.n_seeds = nseeds; R.n_traces = used; R.n_iterations = iters;
+    if (rank != 0) { // every rank holds the same graph; rank 0 post-processes and writes it
+        pnr_destroy(ctx);
+        if (result) *result = R;
+        return true;
+    }
     R.t_frangi = secs(t0, t1); R.t_seeds = secs(t1, t2); R.t_select = secs(t2, t3); R.t_trace = secs(t3, t4);
     printf("\n-----\n%g%% seeds used \n", nseeds ? 100.0 * used / nseeds : 0.0);
     { // reconstruct(n0, ...) :2729 -> :2096-2181 (host): refinement, grouping, trees, final resampling

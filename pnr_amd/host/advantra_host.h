@@ -34,6 +34,11 @@ struct Settings {
     bool verbose = false;     // -v: per-trace progress and stop reasons in the reference's words (tracker.cpp:866,879,908,916; Advantra_plugin.cpp:2677)
     bool save_midres = false; // --save-midres: also write <inimg>_n0_.swc, the node graph before reconstruct() (:2099)
     uint32_t rng_seed = 42;   // --rng-seed: replaces srand(time(NULL)) of tracker.cpp:1003,1098
+    // --ranks N: this process is rank `rank` of `world` processes of one host, one GPU each, that reconstruct ONE stack together
+    // (z-slabs of Frangi / seeds, sorted seeds dealt round-robin, finished traces exchanged through shared memory: INTEGRATION.md);
+    // rank 0 writes the SWC.  The reference has no counterpart.
+    int rank = 0, world = 1;
+    pnr_shm_exchange *exchange = nullptr;
 };
 Settings &settings();
 

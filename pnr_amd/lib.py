@@ -105,10 +105,14 @@ def load():
     L.pnr_sched_playback.argtypes = [C.POINTER(Params), i64, i64, i64, vp, i64, i32, i32, ALLGATHER_FN, vp, i64, TRACE_FN, vp, i32, i32, i32,
                                      vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.pnr_get_trace_log.argtypes = [vp, vp, i64, C.POINTER(i64)]
+    L.pnr_shm_exchange_open.argtypes = [C.c_char_p, i32, i32, i64, C.POINTER(vp)]
+    L.pnr_shm_allgather.argtypes = [vp, vp, vp, i64]
+    L.pnr_shm_exchange_close.argtypes = [vp]
+    L.pnr_shm_exchange_close.restype = None
     L.pnr_set_option.argtypes = [vp, C.c_char_p, i64]
     L.pnr_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     for name in EXPORTS:
-        if name not in ("pnr_last_error", "pnr_default_params", "pnr_destroy"):
+        if name not in ("pnr_last_error", "pnr_default_params", "pnr_destroy", "pnr_shm_exchange_close"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -119,7 +123,8 @@ EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", 
            "pnr_set_j8_v", "pnr_extract_seeds", "pnr_extract_seeds_range", "pnr_zncc_batch",
            "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_replay_traces_ctx", "pnr_frangi_slab", "pnr_quantise_j8", "pnr_soma", "pnr_get_soma", "pnr_trace_replay", "pnr_reconstruct", "pnr_get_table", "pnr_set_profiling", "pnr_set_smc_driver",
            "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch", "pnr_get_graph", "pnr_trace_replay_sharded", "pnr_sched_playback",
-           "pnr_set_option", "pnr_get_option", "pnr_score_filter_seeds", "pnr_sort_seeds", "pnr_get_trace_log"]
+           "pnr_set_option", "pnr_get_option", "pnr_score_filter_seeds", "pnr_sort_seeds", "pnr_get_trace_log",
+           "pnr_shm_exchange_open", "pnr_shm_allgather", "pnr_shm_exchange_close"]
 
 
 def check(rc):
@@ -350,11 +355,13 @@ class Context:
         return nodes, links, nt.value, it.value
 
     def trace_replay_sharded(self, seeds, rank, world, exchange):
-        """this rank's part of tracing ONE sorted seed list on `world` GPUs (pnr_trace_replay_sharded); `exchange` is an ALLGATHER_FN.
-        Every rank returns the same graph; the iteration count is this rank's."""
+        """this rank's part of tracing ONE sorted seed list on `world` GPUs (pnr_trace_replay_sharded); `exchange` is an ALLGATHER_FN
+        (a Python callback, e.g. multigpu.make_exchange) or a ShmExchange (the library's own shared-memory all-gather: no Python in
+        the loop).  Every rank returns the same graph; the iteration count is this rank's."""
         s = np.ascontiguousarray(seeds, SEED_DT)
         nn, nl, nt, it = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
-        check(self.L.pnr_trace_replay_sharded(self.h, s.ctypes.data, len(s), rank, world, exchange, None, None, 0, C.byref(nn), None, 0,
+        fn, user = (exchange.fn, exchange.handle) if isinstance(exchange, ShmExchange) else (exchange, None)
+        check(self.L.pnr_trace_replay_sharded(self.h, s.ctypes.data, len(s), rank, world, fn, user, None, 0, C.byref(nn), None, 0,
                                               C.byref(nl), C.byref(nt), C.byref(it)))
         nodes, links = self.get_graph()
         return nodes, links, nt.value, it.value
@@ -427,6 +434,34 @@ def replay(params, shape, seeds, T, xc):
     return nodes[:nn.value].copy(), links[:nl.value].copy(), nt.value
 
 
+class ShmExchange:
+    """pnr_shm_exchange: an all-gather between the ranks of ONE host through POSIX shared memory (include/pnr_hip.h).  `fn` / `handle`
+    are what pnr_trace_replay_sharded takes as exchange / user; allgather() is the same call for other small host-side collectives."""
+
+    def __init__(self, name, rank, world, capacity=1 << 20):
+        self.L = load()
+        h = C.c_void_p()
+        check(self.L.pnr_shm_exchange_open(name.encode(), rank, world, capacity, C.byref(h)))
+        self.handle, self.rank, self.world, self.capacity = h, rank, world, capacity
+        self.fn = C.cast(self.L.pnr_shm_allgather, ALLGATHER_FN)
+
+    def allgather(self, block):
+        """bytes of equal length on every rank -> list of `world` bytes objects"""
+        n = len(block)
+        send = (C.c_char * max(n, 1)).from_buffer_copy(block.ljust(1, b"\0"))
+        recv = (C.c_char * max(n * self.world, 1))()
+        rc = self.L.pnr_shm_allgather(self.handle, send, recv, n)
+        if rc != 0:
+            raise PnrError(f"shared-memory all-gather failed ({rc})")
+        raw = bytes(recv)
+        return [raw[r * n:(r + 1) * n] for r in range(self.world)]
+
+    def close(self):
+        if self.handle:
+            self.L.pnr_shm_exchange_close(self.handle)
+            self.handle = None
+
+
 def sched_playback(params, shape, seeds, trace_fn, rank=0, world=1, exchange=None, block_bytes=0, window=768, groups=1, poll=4):
     """The streaming scheduler over a host engine that plays back map-free traces (pnr_sched_playback; no GPU): `trace_fn(pos_dir6)`
     -> (T, xc[ni][8]).  Returns nodes, links, traces used, iterations on this rank."""
@@ -449,12 +484,15 @@ def sched_playback(params, shape, seeds, trace_fn, rank=0, world=1, exchange=Non
             return 1
 
     tcb = TRACE_FN(_tr)
+    xuser = None
+    if isinstance(exchange, ShmExchange):
+        exchange, xuser = exchange.fn, exchange.handle
     xcb = exchange if exchange is not None else C.cast(None, ALLGATHER_FN)
     nn, nl, nt, it = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
     cap = 2 * len(s) * ni + 2
     nodes = np.zeros(cap, NODE_DT)
     links = np.zeros((2 * cap + 2, 2), np.int32)
-    check(L.pnr_sched_playback(C.byref(params), w, h, l, s.ctypes.data, len(s), rank, world, xcb, None, block_bytes, tcb, None, window, groups, poll,
+    check(L.pnr_sched_playback(C.byref(params), w, h, l, s.ctypes.data, len(s), rank, world, xcb, xuser, block_bytes, tcb, None, window, groups, poll,
                                nodes.ctypes.data, cap, C.byref(nn), links.ctypes.data, len(links), C.byref(nl), C.byref(nt), C.byref(it)))
     return nodes[:nn.value].copy(), links[:nl.value].copy(), nt.value, it.value
 

@@ -130,3 +130,29 @@ def test_cli_verbose_prints_the_reference_trace_lines(tmp_path):
     ends = sum(out.count(k) for k in ("], DENSITY, nodespervol=4", "], success=0, corr=", "], TRACK LIMIT, niter=40", "], SOMA, idx="))
     assert ntr > 5 and ends == 2 * ntr  # trackPos + trackNeg of every trace that was used
     assert "% seeds used" in out and "seed extraction..." in out and "Trace: " not in quiet.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,soma", [(2, False), (3, False), (2, True)])
+def test_cli_ranks_write_the_one_gpu_swc(tmp_path, ranks, soma):
+    """advantra_cli --ranks N: N forked processes (here sharing the one GPU), z-slabs of Frangi / seeds, sorted seeds dealt round-robin,
+    finished traces exchanged through the shared-memory all-gather, replay on every rank -- the SWC rank 0 writes is byte for byte the
+    SWC of the single-process run; with somaradius > 0 as well"""
+    from PIL import Image
+    img = synth.synth(64, 56, 32, seed=2)
+    if soma:
+        img = synth.add_somas(img, ((20, 28, 16, 6), (48, 20, 14, 5)))
+    paras = ("2,3 3 5 0.3 3 2 25 40 2 4 1" if soma else "2,3 0 5 0.3 3 2 40 50 2 4 5").split()
+    outs = []
+    for n in (1, ranks):
+        d = tmp_path / f"r{n}"
+        d.mkdir()
+        tif = str(d / "stack.tif")
+        pages = [Image.fromarray(z) for z in img]
+        pages[0].save(tif, save_all=True, append_images=pages[1:], compression=None)
+        flags = ["--ranks", str(n), "--share-gpu"] if n > 1 else []
+        r = run(*flags, "-f", "advantra_func", "-i", tif, "-p", *paras)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(open(tif + "_Advantra.swc").read())
+        assert "seeds used" in r.stdout
+    assert outs[0] == outs[1] and outs[0].count("\n") > 30

@@ -173,3 +173,31 @@ def test_failing_rank_aborts_the_others(workload):
         assert not t.is_alive()
     assert isinstance(out[0], lib.PnrError) and "aborted" in str(out[0])
     assert isinstance(out[1], lib.PnrError)
+
+
+def _shm_worker(rank, world, name, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from pnr_amd import lib
+    W = _workload()
+    lookup = lambda q6: W["traces"][np.asarray(q6, np.float32).tobytes()]
+    X = lib.ShmExchange(name, rank, world, capacity=4096)
+    parts = X.allgather(bytes([rank + 1]) * 5)  # the same segment carries the other small collectives of the C++ host
+    nodes, links, nt, iters = lib.sched_playback(W["p"], W["img"].shape, W["seeds"], lookup, rank, world, X, block_bytes=1024, window=6, poll=2, groups=2)
+    X.close()
+    q.put((rank, _same_graph(nodes, links, W) and parts == [bytes([r + 1]) * 5 for r in range(world)], iters))
+
+
+def test_sharded_trace_over_the_shared_memory_exchange():
+    """three processes joined by the library's own all-gather (pnr_shm_exchange: no Python in the scheduler's loop)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, name = 3, f"pnr_test_{os.getpid()}"
+    procs = [ctx.Process(target=_shm_worker, args=(r, world, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res) and sum(it for _, _, it in res) > 10
