@@ -187,7 +187,8 @@ def main():
 
     S = a.size
     sigs, zdist = (2.0, 4.0, 6.0), 2.0
-    shard = world > 1 and a.mode == "shard"
+    # FORCE_SHARD (with FORCE_DIST): the sharded code path -- its RCCL collectives included -- on a world of one (rehearsal)
+    shard = (world > 1 or bool(os.environ.get("PNR_BENCH_FORCE_SHARD")) and dist is not None) and a.mode == "shard"
     stack_seed = 3 + (rank if (world > 1 and a.mode == "stacks") else 0)
     img = synth.synth_torch(S, S, S, seed=stack_seed, device=f"cuda:{local}")
     torch.cuda.synchronize()
@@ -379,7 +380,7 @@ def main():
                                                   "groups overlap on their streams, host replay and polls included)")
             out["roofline"]["note"] += (f"; {groups} trace groups: this kernel's launches overlap the other group's ph_sums / ph_predict / ph_update launches, so its average "
                                         "duration includes shared time -- roofline_isolated is the same kernel with one trace group (untimed extra step)")
-        if world == 1 and not a.one_shot and not a.no_extra:
+        if world == 1 and not shard and not a.one_shot and not a.no_extra:
             s_all = ctx.score_filter_sort(ctx.extract_seeds())[:a.seeds]
             if groups > 1 and a.driver == "phased":
                 # the same step with ONE trace group (launches never overlap): what each kernel needs alone
@@ -408,7 +409,7 @@ def main():
                 "kernel": kname, "launches": n1, "avg_launch_ms": ms1 / max(n1, 1), "achieved": 8.0 * Mtot * ev1 / (ms1 * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * Mtot * ev1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "Mevals_per_s": ev1 / ms1 / 1e3,
                 "note": "all %d traces started together, traced to their map-free end (no early DENSITY stops): %d SMC iterations; measured after the timed region" % (len(T1), ev1 // (a.np + 1))}
-        if a.cpu_baseline != "off" and world == 1:
+        if a.cpu_baseline != "off" and world == 1 and not shard:
             out["cpu_baseline"] = cpu_baseline(img, list(sigs), zdist, a.np, a.ni, st, nvox, a.cpu_baseline)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -144,3 +144,16 @@ print("exchange ok")
     env = dict(os.environ, PNR_ROOT=ROOT, PNR_PORT=str(29600 + os.getpid() % 300), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "exchange ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_bench_sharded_path_over_rccl_world_of_one():
+    """the sharded step of bench.py with its RCCL collectives (broadcast, all-gather of seeds, all-reduce of the timings) on the only
+    RCCL world a one-GPU box can form, against the plain one-GPU step: same seeds, traces and nodes"""
+    common = ["--size", "160", "--seeds", "150", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra"]
+    one = _bench(common, {})
+    env = dict(PNR_BENCH_FORCE_DIST="1", PNR_BENCH_FORCE_SHARD="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200))
+    sh = _bench(common, env)
+    assert sh["config"]["record_exchange"] and sh["n_gpus"] == 1
+    for k in ("nodes", "n_seeds", "n_seeds_init", "traces_used"):
+        assert sh["counts"][k] == one["counts"][k], k
