@@ -55,6 +55,91 @@ __global__ __launch_bounds__(GX_BLOCK) void gauss_x_u8(const uint8_t *__restrict
     out[row * w + x] = acc;
 }
 
+// The x pass with the radius a compile-time constant (the radii the usual parameters give; gauss_x_u8 otherwise): a work-group
+// converts a tile of 64 rows x (32 + 2L) bytes to f32 in LDS once; lane = row, and every thread computes GR consecutive outputs
+// of its row from 2L + GR LDS reads (row pitch odd: the 64 rows of a wave-read fall into different banks), taps in scalar
+// registers, fully unrolled; the 64 x 32 results go back through LDS so that the stores are whole 128-byte rows.  Same sums as
+// gauss_x_u8: ascending taps, separate multiply and add.
+constexpr int GR = 8; // consecutive outputs per thread in the register-tiled Gaussian passes
+constexpr int GXT_W = 32, GXT_H = 64;
+template <int L>
+__global__ __launch_bounds__(256) void gauss_x_u8_t(const uint8_t *__restrict__ img, float *__restrict__ out, int w, i64 rows, int tiles_x,
+                                                     const float *__restrict__ taps)
+{
+    constexpr int SPAN = GXT_W + 2 * L, PITCH = SPAN | 1; // odd
+    __shared__ float s_in[GXT_H * PITCH];
+    __shared__ float s_out[GXT_H * (GXT_W + 1)];
+    const i64 b = blockIdx.x;
+    const int x0 = (int)(b % tiles_x) * GXT_W;
+    const i64 r0 = (b / tiles_x) * GXT_H;
+    const int tid = threadIdx.x;
+    if (x0 - L >= 0 && x0 + GXT_W + L + 3 <= w) { // interior in x: whole dwords, no clamping (the block-uniform common case)
+        constexpr int NDW = (SPAN + 6) / 4;      // dwords that cover SPAN bytes at any misalignment
+        const int a = (x0 - L) & ~3, mis = (x0 - L) - a;
+        typedef unsigned __attribute__((aligned(1))) u32u; // (rows are only dword-aligned when w and the base pointer are)
+        for (int e = tid; e < GXT_H * NDW; e += 256) {
+            const int r = e / NDW, d = e - r * NDW;
+            i64 row = r0 + r;
+            if (row > rows - 1) row = rows - 1;
+            const unsigned q = *(const u32u *)(img + row * w + a + 4 * d);
+#pragma unroll
+            for (int b8 = 0; b8 < 4; b8++) {
+                const int cidx = 4 * d + b8 - mis;
+                if (cidx >= 0 && cidx < SPAN) s_in[r * PITCH + cidx] = (float)((q >> (8 * b8)) & 0xffu);
+            }
+        }
+    } else {
+        for (int e = tid; e < GXT_H * SPAN; e += 256) { // clamp-to-edge (frangi.cpp:690)
+            const int r = e / SPAN, cidx = e - r * SPAN;
+            i64 row = r0 + r;
+            if (row > rows - 1) row = rows - 1;
+            int x = x0 - L + cidx;
+            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+            s_in[r * PITCH + cidx] = (float)img[row * w + x];
+        }
+    }
+    float tp[2 * L + 1];
+#pragma unroll
+    for (int k = 0; k <= 2 * L; k++) tp[k] = taps[k];
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6; // row, chunk of GR outputs
+    float acc[GR];
+#pragma unroll
+    for (int j = 0; j < GR; j++) acc[j] = 0.f;
+    const float *src = s_in + lane * PITCH + wv * GR;
+#pragma unroll
+    for (int t = 0; t < 2 * L + GR; t++) {
+        const float v = src[t];
+#pragma unroll
+        for (int j = 0; j < GR; j++) {
+            const int k = t - j;
+            if (k >= 0 && k <= 2 * L) acc[j] = acc[j] + v * tp[k];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < GR; j++) s_out[lane * (GXT_W + 1) + wv * GR + j] = acc[j];
+    __syncthreads();
+    for (int e = tid; e < GXT_H * GXT_W; e += 256) { // 32 consecutive floats of a row per half wave
+        const int r = e / GXT_W, cidx = e - r * GXT_W;
+        const i64 row = r0 + r;
+        const int x = x0 + cidx;
+        if (row < rows && x < w) out[row * w + x] = s_out[r * (GXT_W + 1) + cidx];
+    }
+}
+
+static bool launch_gauss_x_t(hipStream_t st, const uint8_t *src, float *dst, int w, i64 rows, const float *d_taps, int L)
+{
+    static_assert(GXT_W == 4 * GR, "four waves of GR outputs");
+    const int tiles_x = (w + GXT_W - 1) / GXT_W;
+    const dim3 grid((unsigned)(tiles_x * ((rows + GXT_H - 1) / GXT_H)));
+#define PNR_GX(LL) case LL: hipLaunchKernelGGL(gauss_x_u8_t<LL>, grid, dim3(256), 0, st, src, dst, w, rows, tiles_x, d_taps); return true;
+    switch (L) {
+        PNR_GX(6) PNR_GX(12) PNR_GX(18) PNR_GX(24)
+    default: return false;
+    }
+#undef PNR_GX
+}
+
 // ----------------------------------------------------------------------------------------
 // K2/K3: Gaussian along a strided axis (y or z), f32 -> f32 (frangi.cpp:717-782)
 // tile: 64 consecutive x (one wave-row, 256 B coalesced) x TA outputs along the axis
@@ -104,7 +189,7 @@ __global__ __launch_bounds__(256) void gauss_axis(const float *__restrict__ in, 
 // input row read from LDS feeds up to GR accumulators (2L + GR LDS reads for GR outputs instead of GR (2L + 1)), the taps are
 // scalar registers, and the loop over the input rows is fully unrolled so that all indices are static.  For every output the
 // products are still added in ascending tap order with separate multiply and add -- the reference's sum, bit for bit.
-constexpr int GR = 8, TAT = 64, GT = TAT / GR; // outputs per thread, outputs per tile along the axis, row groups (waves) per block
+constexpr int TAT = 64, GT = TAT / GR; // outputs per tile along the axis, row groups (waves) per block (GR outputs per thread)
 
 template <int L>
 __global__ __launch_bounds__(64 * GT) void gauss_axis_t(const float *__restrict__ in, float *__restrict__ out, int w, int n_axis, i64 axis_stride, int n_other,
@@ -918,7 +1003,7 @@ static int gaussian3d(pnr_ctx *c, const std::vector<float> &gxy, const std::vect
     const bool two_d = (l == 1); // single-slice stack: the 2-D imgaussian has no z pass (frangi.cpp:576-645)
     if (two_d) { bufY = d_out; bufX = (d_out == c->d_tmpA) ? c->d_tmpB : c->d_tmpA; }
     c->tic();
-    {
+    if (!launch_gauss_x_t(c->stream, c->d_img, bufX, w, (i64)h * l, d_txy, Lxy)) {
         const int tiles_x = (w + GX_BLOCK - 1) / GX_BLOCK;
         const i64 rows = (i64)h * l;
         hipLaunchKernelGGL(gauss_x_u8, dim3((unsigned)(rows * tiles_x)), dim3(GX_BLOCK), 0, c->stream, c->d_img, bufX, w,
