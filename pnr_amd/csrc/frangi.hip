@@ -1022,6 +1022,7 @@ int pnr_gauss_x_u8_launch(pnr_ctx *c, const uint8_t *src, float *dst, const floa
     const int w = (int)c->w;
     const i64 rows = c->h * c->l;
     PNR_REQUIRE(L <= MAX_L, PNR_E_ARG, "Gaussian radius %d > %d", L, MAX_L);
+    if (launch_gauss_x_t(c->stream, src, dst, w, rows, d_taps, L)) return PNR_OK;
     const int tiles_x = (w + GX_BLOCK - 1) / GX_BLOCK;
     hipLaunchKernelGGL(gauss_x_u8, dim3((unsigned)(rows * tiles_x)), dim3(GX_BLOCK), 0, c->stream, src, dst, w, rows, tiles_x, d_taps, L);
     return PNR_OK;
