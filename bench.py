@@ -207,7 +207,8 @@ def main():
     if shard:
         want = os.environ.get("PNR_BENCH_EXCHANGE", "shm" if local_world == world else "rccl")
         if want == "shm":
-            ok = torch.tensor([1], dtype=torch.int32, device=coll_dev)
+            # rank 0 probes /dev/shm and picks the segment's name (its pid + clock: never the name of a crashed earlier job)
+            ok = torch.tensor([1, os.getpid(), time.time_ns() % (1 << 40)], dtype=torch.int64, device=coll_dev)
             if rank == 0:
                 try:
                     probe = pnr_amd.lib.ShmExchange(f"pnr_probe_{os.getpid()}", 0, 1, 64)
@@ -215,8 +216,8 @@ def main():
                 except Exception:  # noqa: BLE001 -- no usable /dev/shm: every rank falls back together
                     ok[0] = 0
             dist.broadcast(ok, 0)
-            if int(ok.item()):
-                exchange = pnr_amd.lib.ShmExchange(f"pnr_bench_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}", rank, world, 1 << 20)
+            if int(ok[0].item()):
+                exchange = pnr_amd.lib.ShmExchange(f"pnr_bench_{os.getuid()}_{int(ok[1].item())}_{int(ok[2].item())}", rank, world, 1 << 20)
                 exchange_kind = "shared memory (one node)"
         if exchange is None:
             exchange = multigpu.make_exchange(dist, world, coll_dev)

@@ -25,7 +25,8 @@ def _graph_equal(a, b):
     return len(a[0]) == len(b[0]) and np.array_equal(a[1], b[1]) and all(np.array_equal(a[0][k], b[0][k], equal_nan=True) for k in a[0].dtype.names)
 
 
-@pytest.mark.parametrize("world,opts", [(2, {}), (3, dict(window=16, poll=3, exchange_block=2048)), (2, dict(groups=2, window=32))])
+@pytest.mark.parametrize("world,opts", [(2, {}), (3, dict(window=16, poll=3, exchange_block=2048)), (2, dict(groups=2, window=32)),
+                                        (8, {}), (8, dict(window=8, groups=2))])  # 8 = the ranks of one MI355X node
 def test_sharded_trace_logical_ranks(world, opts):
     img = synth.synth(96, 80, 40, seed=11)
     p = pnr_amd.make_params(sigmas=[2.0, 3.0], np_=48, ni=40, zdist=2.0, nodepervol=3, vol=5)
@@ -96,6 +97,39 @@ def test_sharded_front_half_gives_the_one_gpu_seed_list():
     for k in want.dtype.names:
         assert np.array_equal(got[k], want[k], equal_nan=True), k
     torch.cuda.synchronize()
+
+
+def test_front_half_in_8_slabs_at_bench_size():
+    """BASELINE configs[3] as the driver's 8-GPU run cuts it: the 1024^3 bench stack in 8 z-slabs of 128 planes (+ 11 halo planes a
+    side), scales {2,4,6} -- the eight ranks in sequence on one context.  Extremes, seed list and scores equal the unsharded ones."""
+    import torch
+    S = 1024
+    img = synth.synth_torch(S, S, S, seed=3)
+    p = pnr_amd.make_params(sigmas=[2.0, 4.0, 6.0], np_=200, ni=200, zdist=2.0)
+    c = pnr_amd.Context(p, 0)
+    shape = (S, S, S)
+    c.set_volume_device(img.data_ptr(), shape, keepalive=img)
+    jmin1, jmax1 = c.frangi()
+    want = c.score_filter_sort(c.extract_seeds())
+    world = 8
+    assert multigpu.frangi_halo(p) == 11
+    ext = []
+    for r in range(world):
+        z0, z1, zlo, zhi = multigpu.slab_bounds(S, r, world, 11)
+        c.set_volume_device(img.data_ptr() + zlo * S * S, (zhi - zlo, S, S), keepalive=img)
+        ext.append(c.frangi_slab(z0 - zlo, z1 - zlo))
+    gmin, gmax = min(e[0] for e in ext), max(e[1] for e in ext)
+    assert (gmin, gmax) == (jmin1, jmax1)
+    parts = []
+    for r in range(world):
+        mine, _, _ = multigpu.frangi_seeds_sharded(c, img.data_ptr(), shape, None, r, world, reduce_fn=lambda a, b: (gmin, gmax))
+        parts.append(c.score_filter(mine))
+    got = c.sort_seeds(np.concatenate(parts))
+    assert len(got) == len(want) > 10000
+    for k in want.dtype.names:
+        assert np.array_equal(got[k], want[k], equal_nan=True), k
+    torch.cuda.synchronize()
+    c.close()
 
 
 def _bench(args, env_extra):
