@@ -225,12 +225,14 @@ void pnr_shm_exchange_close(pnr_shm_exchange *x);
 /* The scheduler behind pnr_trace_replay[_sharded] (stream_sched.h) over a HOST engine that plays back map-free traces which
  * `trace(user, pos_dir[6], &T, xc[ni])` supplies (0 = ok; rows 0..min(T, ni)-1 of xc valid) -- pure host code, no GPU: the
  * multi-process tests drive the window / admission / exchange / replay logic with it, and a recorded workload can be
- * re-scheduled offline.  Same outputs as pnr_trace_replay_sharded. */
+ * re-scheduled offline.  Same outputs as pnr_trace_replay_sharded.  look0 / look_pct: the admission lookahead (options of the same
+ * name; 0 / -1 = automatic). */
 typedef int (*pnr_trace_fn)(void *user, const float *pos_dir, int32_t *T, pnr_xest *xc);
 int pnr_sched_playback(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n, int rank,
                        int world, pnr_allgather_fn exchange, void *exchange_user, int64_t block_bytes, pnr_trace_fn trace,
-                       void *trace_user, int window, int groups, int poll, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes,
-                       int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used, int64_t *n_iterations_here);
+                       void *trace_user, int window, int groups, int poll, int look0, int look_pct, pnr_node *nodes, int64_t cap_nodes,
+                       int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used,
+                       int64_t *n_iterations_here);
 
 /* reconstruct() chain of the plugin (Advantra_plugin.cpp:2096-2181), pure host: link resampling
  * (TRACE_RSMPL) -> mean-shift refinement (SIG2RADIUS, REFINE_ITER, EPSILON2) -> sphere grouping (GROUP_RADIUS) ->

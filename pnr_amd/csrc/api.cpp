@@ -712,8 +712,8 @@ struct PlaybackEngine final : pnr::StreamEngine {
 
 int pnr_sched_playback(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n, int rank, int world,
                        pnr_allgather_fn exchange, void *xuser, int64_t block_bytes, pnr_trace_fn trace, void *tuser, int window, int groups,
-                       int poll, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links,
-                       int64_t *n_traces_used, int64_t *n_iterations)
+                       int poll, int look0, int look_pct, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links,
+                       int64_t *n_links, int64_t *n_traces_used, int64_t *n_iterations)
 {
     PNR_REQUIRE(p && trace && n_nodes && n_links && (n == 0 || seeds), PNR_E_ARG, "null argument");
     PNR_REQUIRE(w > 0 && h > 0 && l > 0, PNR_E_ARG, "bad dimensions");
@@ -723,6 +723,7 @@ int pnr_sched_playback(const pnr_params *p, int64_t w, int64_t h, int64_t l, con
     PlaybackEngine eng(*p, w, h, window, trace, tuser);
     pnr::SchedOptions o;
     o.window = window; o.groups = std::max(1, groups); o.poll = std::max(1, poll);
+    o.look0 = std::max(0, look0); o.look_pct = look_pct;
     pnr::ShardSpec sh;
     sh.rank = rank; sh.world = world; sh.exchange = exchange; sh.user = xuser; sh.block_bytes = block_bytes;
     pnr::SchedStats st;

@@ -55,6 +55,13 @@ __global__ __launch_bounds__(GX_BLOCK) void gauss_x_u8(const uint8_t *__restrict
     out[row * w + x] = acc;
 }
 
+// work-group id -> tile id such that the work-groups of one XCD (id mod 8) own a contiguous range of tiles (a bijection for any n)
+__device__ __forceinline__ unsigned int xcd_contiguous(unsigned int b, unsigned int n)
+{
+    const unsigned int x = b & 7u, idx = b >> 3, q = n >> 3, r = n & 7u;
+    return x * q + (x < r ? x : r) + idx;
+}
+
 // The x pass with the radius a compile-time constant (the radii the usual parameters give; gauss_x_u8 otherwise): a work-group
 // converts a tile of 64 rows x (32 + 2L) bytes to f32 in LDS once; lane = row, and every thread computes GR consecutive outputs
 // of its row from 2L + GR LDS reads (row pitch odd: the 64 rows of a wave-read fall into different banks), taps in scalar
@@ -69,7 +76,9 @@ __global__ __launch_bounds__(256) void gauss_x_u8_t(const uint8_t *__restrict__ 
     constexpr int SPAN = GXT_W + 2 * L, PITCH = SPAN | 1; // odd
     __shared__ float s_in[GXT_H * PITCH];
     __shared__ float s_out[GXT_H * (GXT_W + 1)];
-    const i64 b = blockIdx.x;
+    // consecutive work-groups go round-robin to the 8 XCDs: with contiguous tile ranges per XCD the 128-byte lines that x-neighbours
+    // share (a tile reads 32 + 2L bytes of a row) are fetched into one L2 once instead of once per XCD
+    const i64 b = xcd_contiguous(blockIdx.x, gridDim.x);
     const int x0 = (int)(b % tiles_x) * GXT_W;
     const i64 r0 = (b / tiles_x) * GXT_H;
     const int tid = threadIdx.x;
@@ -557,13 +566,6 @@ __device__ __forceinline__ float td2(const Tile &T, int ci, int ni, int co, int 
     if (co == 0) return td1<AI>(T, ox, oy, oz, ci + same, ni) - td1<AI>(T, 0, 0, 0, ci, ni);
     if (co < no - 1) return 0.5f * (td1<AI>(T, ox, oy, oz, ci + same, ni) - td1<AI>(T, -ox, -oy, -oz, ci - same, ni));
     return td1<AI>(T, 0, 0, 0, ci, ni) - td1<AI>(T, -ox, -oy, -oz, ci - same, ni);
-}
-
-// work-group id -> tile id such that the work-groups of one XCD (id mod 8) own a contiguous range of tiles (a bijection for any n)
-__device__ __forceinline__ unsigned int xcd_contiguous(unsigned int b, unsigned int n)
-{
-    const unsigned int x = b & 7u, idx = b >> 3, q = n >> 3, r = n & 7u;
-    return x * q + (x < r ? x : r) + idx;
 }
 
 struct HessQueue {
