@@ -39,6 +39,7 @@ def main():
     ctx = pnr_amd.Context(p, 0)
     shape = (S, S, S)
     ctx.set_volume_device(img.data_ptr(), shape, keepalive=img)
+    ctx.set_profiling(True)
     ctx.frangi()
     s0 = ctx.extract_seeds()
     seeds = ctx.score_filter_sort(s0)[:a.seeds]
@@ -83,6 +84,7 @@ def main():
                         if world > 1:
                             X[r] = lib.ShmExchange(name, r, world, 1 << 20)
                         if r == 0:
+                            ctx.reset_kernel_ms()
                             t0 = time.perf_counter()
                             res = ctx.trace_replay_sharded(seeds, 0, world, X[0]) if world > 1 else ctx.trace_replay(seeds)
                             out[0] = (res, 1e3 * (time.perf_counter() - t0))
@@ -106,13 +108,15 @@ def main():
                 (nodes, links, nt, it0), ms = out[0]
                 same = len(nodes) == len(n1) and np.array_equal(links, l1) and all(np.array_equal(nodes[k], n1[k], equal_nan=True) for k in n1.dtype.names)
                 its = [it0] + [out[r][0][3] for r in range(1, world)]
+                km = {g: ctx.kernel_ms(g) for g in ("smc_predict", "smc", "smc_sums", "smc_update")}
                 if best is None or ms < best[0]:
-                    best = (ms, its, same)
-            ms, its, same = best
+                    best = (ms, its, same, km)
+            ms, its, same, km = best
             fr = min(front)
             print(f"world {world} [{spec or 'defaults'}]: front half (rank 0's slab) {fr:.1f} ms, tracing {ms:.0f} ms, step ~{fr + ms:.0f} ms -> "
                   f"{S ** 3 / (fr + ms) / 1e3:.0f} Mvox/s; iterations rank 0 {its[0]}, all ranks {sum(its)} ({sum(its) / it1:.2f} x one GPU); "
-                  f"graph {'identical' if same else 'DIFFERENT'}", flush=True)
+                  f"graph {'identical' if same else 'DIFFERENT'}; rank 0: {km['smc'][1]} SMC steps, per launch predict / sample / sums / update "
+                  + " / ".join(f"{km[g][0] / max(km[g][1], 1):.3f}" for g in ("smc_predict", "smc", "smc_sums", "smc_update")) + " ms", flush=True)
     ctx.close()
 
 
