@@ -86,6 +86,45 @@ def run_case(L, case, stats, desc, driver=None, big=False):
     n1, l1, nt1 = c.replay(sel, Tg, xc)
     n2, l2, nt2, _ = c.trace_replay(sel)
     assert nt1 == nt2 and np.array_equal(l1, l2) and all(np.array_equal(n1[k], n2[k], equal_nan=True) for k in n1.dtype.names), "streamed vs one-shot graph"
+    if case % 3 == 0 and driver != "persistent" and len(ss) >= 2:
+        # BASELINE configs[3]: more of the sorted seeds dealt to 2 / 3 logical ranks (a context and a host thread per rank, joined by an
+        # in-process all-gather) -- every rank must end with the one-GPU graph of the same seeds
+        import threading
+        from pnr_amd import multigpu
+        world = 2 + (case // 3) % 2
+        many = ss[:24]
+        nr, lr, ntr, _ = c.trace_replay(many)
+        X = multigpu.ThreadExchange(world)
+        ctxs, res = [], [None] * world
+        for r in range(world):
+            cr = pnr_amd.Context(p, 0)
+            for k, v in knobs.items():
+                cr.set_option(k, v)
+            cr.set_option("exchange_block", [0, 2048, 700][case // 3 % 3])  # small blocks: records queue up and are carried over
+            cr.set_volume(img)
+            if rad:
+                cr.soma()
+            ctxs.append(cr)
+
+        def run_rank(r):
+            try:
+                res[r] = ctxs[r].trace_replay_sharded(many, r, world, X.callback(r))
+            except Exception as e:  # noqa: BLE001
+                res[r] = e
+                X.barrier.abort()
+
+        th = [threading.Thread(target=run_rank, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        for r in range(world):
+            assert not isinstance(res[r], Exception), f"sharded rank {r}/{world}: {res[r]}"
+            assert res[r][2] == ntr and np.array_equal(res[r][1], lr) and all(np.array_equal(res[r][0][k], nr[k], equal_nan=True) for k in nr.dtype.names), \
+                f"sharded graph differs on rank {r} of {world}"
+        for cr in ctxs:
+            cr.close()
+        stats["sharded"] = stats.get("sharded", 0) + 1
     # the sequential bookkeeping (trackPos, trace loop) and the reconstruct chain against the oracle's
     so_sel = np.stack([sel[k] for k in lib.SEED_DT.names], -1).astype(np.float32)
     xcm = np.stack([mat(xc[j]) for j in range(len(Tg))]) if len(Tg) else np.zeros((0, ni, 8), np.float32)
