@@ -28,17 +28,59 @@ namespace {
 // ----------------------------------------------------------------------------------------
 // K8: batched znccBBB (seed scoring, tests)
 // ----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void zncc_chains(Vol V, Tab T, const float *__restrict__ pos_dir, int n, int n_pad,
-                                                    float *__restrict__ corr_s)
+// K8', seed scoring in two phases (what pnr_zncc_run uses): one lane per chain leaves the GPU nearly empty -- 19 117 seeds x 3 scales
+// are 900 wavefronts, each a serial walk over up to 5625 samples with eight scattered byte loads per sample (17 ms at 1024^3).
+// Sampling is order-free, so phase 1 spreads it: a work-group takes 64 poses x 64 CONSECUTIVE template samples of one scale, a
+// wavefront evaluates 64 neighbouring samples of one pose per step (the eight corner loads of a wave fall into a few cache lines)
+// and the 64 x 64 tile goes through LDS into the stash layout of the tracker's ordered sums, [sample][pose] rows of 256 bytes.
+// Phase 2 is zncc_from_stash, one wavefront per (64 poses, scale): the same values in the same order as zncc_chain.
+__global__ __launch_bounds__(256) void zncc_sample(Vol V, Tab T, const float *__restrict__ pos_dir, int n, int ngroups, float *__restrict__ stash)
 {
-    const i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (c >= (i64)T.nsig * n_pad) return;
-    const int s = __builtin_amdgcn_readfirstlane((int)(c / n_pad)); // wave-uniform: n_pad % 64 == 0
-    const int i = (int)(c - (i64)s * n_pad);
-    if (i >= n) return;
-    const float *q = pos_dir + (i64)i * 6;
-    const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
-    corr_s[(i64)s * n_pad + i] = zncc_chain(V, f, T.tmpl + T.moff[s], T.M[s], T.corrc[s]);
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // block -> (scale, group of 64 poses, chunk of 64 samples)
+    i64 b = blockIdx.x;
+    int s = 0;
+    i64 soff = 0; // floats of the scales before s
+    for (;; s++) {
+        const i64 nb = (i64)((T.M[s] + 63) / 64) * ngroups;
+        if (b < nb || s == T.nsig - 1) break;
+        b -= nb;
+        soff += (i64)T.M[s] * 64 * ngroups;
+    }
+    const int M = T.M[s], nchunk = (M + 63) / 64;
+    const int g = (int)(b / nchunk), c = (int)(b - (i64)g * nchunk);
+    if (g >= ngroups) return;
+    const float4 *tm = T.tmpl + T.moff[s];
+    const int k = c * 64 + lane;
+    const float4 t = tm[k < M ? k : M - 1];
+    for (int q = 0; q < 16; q++) {
+        const int i = g * 64 + wv * 16 + q; // wave-uniform
+        float v = 0.f;
+        if (i < n) {
+            const float *p6 = pos_dir + (i64)i * 6;
+            const Frame f = make_frame(p6[0], p6[1], p6[2], p6[3], p6[4], p6[5]);
+            v = sample(V, f, t);
+        }
+        tile[wv * 16 + q][lane] = v;
+    }
+    __syncthreads();
+    float *out = stash + soff + (i64)g * M * 64 + (i64)c * 64 * 64;
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int j = e >> 6, col = e & 63;
+        if (c * 64 + j < M) out[j * 64 + col] = tile[col][j];
+    }
+}
+
+__global__ __launch_bounds__(64) void zncc_sums(Tab T, const float *__restrict__ wd, const float *__restrict__ stash, int ngroups, int n_pad, int i0,
+                                                float *__restrict__ corr_s)
+{
+    const int s = blockIdx.x / ngroups, g = blockIdx.x - s * ngroups, lane = threadIdx.x;
+    i64 soff = 0;
+    for (int q = 0; q < s; q++) soff += (i64)T.M[q] * 64 * ngroups;
+    const int M = T.M[s];
+    const float cv = zncc_from_stash<64, 32>(stash + soff + (i64)g * M * 64 + lane, M, wd + T.moff[s], T.corrc[s]);
+    corr_s[(i64)s * n_pad + i0 + g * 64 + lane] = cv; // (n_pad is a multiple of 64: the lanes past n write padding)
 }
 
 __global__ void zncc_pick(Tab T, const float *__restrict__ corr_s, int n, int n_pad, float *__restrict__ corr,
@@ -453,24 +495,38 @@ int pnr_zncc_run(pnr_ctx *c, const float *h_pos_dir, int64_t n, float *h_corr, f
     make_tab(c, T);
     PNR_REQUIRE(n < (1LL << 28), PNR_E_ARG, "too many poses");
     const int n_pad = (int)((n + 63) / 64 * 64);
-    float *d_pd = nullptr, *d_cs = nullptr, *d_corr = nullptr, *d_sig = nullptr;
-    PNR_HIP(hipMalloc(&d_pd, (size_t)n * 24));
-    PNR_HIP(hipMalloc(&d_cs, (size_t)T.nsig * n_pad * 4));
-    PNR_HIP(hipMalloc(&d_corr, (size_t)n * 4));
-    PNR_HIP(hipMalloc(&d_sig, (size_t)n * 4));
+    float *d_pd = nullptr, *d_cs = nullptr, *d_corr = nullptr, *d_sig = nullptr, *d_stash = nullptr;
+    rc = c->scratch_get("zncc_pd", (size_t)n * 6, &d_pd);
+    if (!rc) rc = c->scratch_get("zncc_cs", (size_t)T.nsig * n_pad, &d_cs);
+    if (!rc) rc = c->scratch_get("zncc_corr", (size_t)n, &d_corr);
+    if (!rc) rc = c->scratch_get("zncc_sig", (size_t)n, &d_sig);
+    if (rc) return rc;
+    PNR_REQUIRE(c->d_wd, PNR_E_STATE, "tracker tables not loaded");
+    // poses in batches of at most 32 768: the stash of a batch is sum(M) x 4 B per pose (1.6 GB at the usual three scales)
+    i64 Mtot = 0;
+    for (int s = 0; s < T.nsig; s++) Mtot += c->tab.M[s];
+    const int batch = (int)std::min<i64>(n_pad, 32768);
+    rc = c->scratch_get("zncc_stash", (size_t)Mtot * batch, &d_stash);
+    if (rc) return rc;
     PNR_HIP(hipMemcpyAsync(d_pd, h_pos_dir, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
     c->tic();
-    const i64 chains = (i64)T.nsig * n_pad;
-    hipLaunchKernelGGL(zncc_chains, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, c->stream, V, T, d_pd, (int)n, n_pad,
-                       d_cs);
+    int launches = 1;
+    for (i64 i0 = 0; i0 < n; i0 += batch) {
+        const int nb = (int)std::min<i64>(batch, n - i0), ngroups = (nb + 63) / 64;
+        i64 blocks = 0;
+        for (int s = 0; s < T.nsig; s++) blocks += (i64)((c->tab.M[s] + 63) / 64) * ngroups;
+        hipLaunchKernelGGL(zncc_sample, dim3((unsigned)blocks), dim3(256), 0, c->stream, V, T, (const float *)(d_pd + i0 * 6), nb, ngroups, d_stash);
+        hipLaunchKernelGGL(zncc_sums, dim3((unsigned)(T.nsig * ngroups)), dim3(64), 0, c->stream, T, (const float *)c->d_wd, (const float *)d_stash, ngroups,
+                           n_pad, (int)i0, d_cs);
+        launches += 2;
+    }
     hipLaunchKernelGGL(zncc_pick, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, T, d_cs, (int)n, n_pad, d_corr,
                        d_sig);
-    c->toc("zncc", 2);
+    c->toc("zncc", launches);
     PNR_HIP(hipGetLastError());
     PNR_HIP(hipMemcpyAsync(h_corr, d_corr, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (h_sig) PNR_HIP(hipMemcpyAsync(h_sig, d_sig, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     PNR_HIP(hipStreamSynchronize(c->stream));
-    hipFree(d_pd); hipFree(d_cs); hipFree(d_corr); hipFree(d_sig);
     return PNR_OK;
 }
 
