@@ -586,11 +586,7 @@ __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash
             corra += di * wk[j];
             // corrb += pow(f32,2): the f64 product of two f32 values is exact (48 bits), so one fused multiply-add rounds exactly
             // like the multiply followed by the add -- one f64-rate instruction less per value
-#ifdef PNR_EXP_FMA32
-            corrb = __builtin_fmaf(di, di, corrb); // EXPERIMENT ONLY: one rounding instead of two, not bit-exact
-#else
             corrb = (float)__builtin_fma((double)di, (double)di, (double)corrb);
-#endif
         }
 #pragma unroll
         for (int j = 0; j < CH; j++) cur[j] = nxt[j];
