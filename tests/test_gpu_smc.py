@@ -77,6 +77,29 @@ def test_zncc_vs_oracle(oracle, sigs, zdist):
     assert c.zncc(np.zeros((0, 6), np.float32))[0].shape == (0,)
 
 
+def test_zncc_in_batches(oracle):
+    """pnr_zncc_batch scores at most 32 768 poses per pass over its stash: 70 001 poses (a ragged last group in the third batch) must give, pose by pose, the scores of the same poses evaluated a few hundred at a time -- and those the oracle's"""
+    img = synth.synth(48, 40, 24, seed=4)
+    sigs, zdist = [2.0, 3.0], 2.0
+    rs = np.random.RandomState(9)
+    m = 257
+    pos = rs.uniform(-2, 1, (m, 3)) + rs.uniform(0, 1, (m, 3)) * [50, 42, 26]
+    d = rs.randn(m, 3)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    base = np.concatenate([pos, d], 1).astype(np.float32)
+    c = pnr_amd.Context(pnr_amd.make_params(sigmas=sigs, zdist=zdist), 0)
+    c.set_volume(img)
+    small_c, small_s = c.zncc(base)
+    T = orc.Tracker(oracle, sigs, 2, 20, 5, 3.0, 0.3, zdist=zdist)
+    want_c, want_s = T.zncc(img, base)
+    assert np.array_equal(small_c, want_c, equal_nan=True) and np.array_equal(small_s, want_s)
+    n = 70001
+    idx = rs.randint(0, m, n)
+    big_c, big_s = c.zncc(base[idx])
+    assert np.array_equal(big_c, small_c[idx], equal_nan=True) and np.array_equal(big_s, small_s[idx])
+    c.close()
+
+
 def _seeds_for(oracle, img, sigs, zdist, n):
     J, jmin, jmax, Vx, Vy, Vz = orc.frangi3d(oracle, img, sigs, zdist)
     s = orc.extract_seeds(oracle, 5, orc.j8(oracle, J, jmin, jmax), Vx, Vy, Vz)
