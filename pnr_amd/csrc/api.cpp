@@ -310,6 +310,15 @@ int pnr_get_frangi(pnr_ctx *c, float *J, uint8_t *J8, uint8_t *Vx, uint8_t *Vy, 
     PNR_REQUIRE(c && c->have_j8 && c->d_J, PNR_E_STATE, "pnr_get_frangi: run pnr_frangi first");
     const size_t n = (size_t)c->N;
     int rc = PNR_OK;
+    if ((J || Vx || Vy || Vz) && c->frangi_pruned) {
+        // the last run skipped the solver where the response could not reach J8 = 1 (option frangi_prune): J8, the extremes and the
+        // seeds are exact, the f32 J and the winning scale of J8 = 0 voxels are not -- recompute without the shortcut, same extremes
+        const float jmin = c->Jmin, jmax = c->Jmax;
+        c->frangi_exact_once = true;
+        rc = pnr_frangi_run_range(c, c->fr_zs0, c->fr_zs1, false, nullptr, nullptr);
+        if (!rc) rc = pnr_j8_run(c, jmin, jmax);
+        if (rc) return rc;
+    }
     if (Vx || Vy || Vz) rc = pnr_frangi_materialise_v(c); // the pipeline itself only needs the directions at the seeds
     if (!rc) rc = download(c, J, c->d_J, n);
     if (!rc) rc = download(c, J8, c->d_J8, n);
@@ -752,7 +761,7 @@ const OptEntry OPTS[] = {
     {"trace_log", &pnr::Options::trace_log, nullptr, 0, 1},
     {"replay_batches", &pnr::Options::replay_batches, nullptr, 0, 1}, {"batch_growth", &pnr::Options::batch_growth, nullptr, 100, 100000},
     {"batch_max", &pnr::Options::batch_max, nullptr, 1, 1 << 24}, {"no_stash", &pnr::Options::no_stash, nullptr, 0, 1},
-    {"exchange_block", nullptr, &pnr::Options::exchange_block, 0, 1 << 28},
+    {"exchange_block", nullptr, &pnr::Options::exchange_block, 0, 1 << 28}, {"frangi_prune", &pnr::Options::frangi_prune, nullptr, 0, 1},
 };
 } // namespace
 

@@ -71,6 +71,7 @@ struct Options {
     int replay_batches = 0;   // 1: seed-rank batches instead of the streaming window (always so with the persistent driver)
     int batch_growth = 200, batch_max = 1024;
     int no_stash = 0;         // persistent driver: in-lane two-pass sums
+    int frangi_prune = 1;       // skip the eigen-solver where the response cannot reach the first non-zero J8 level (frangi.hip)
     int64_t exchange_block = 0; // bytes per rank and exchange of the sharded tracer; 0 = automatic (256 KB / world, at least 32 KB)
 };
 int host_threads(const Options &o); // worker threads to use on this host
@@ -101,6 +102,8 @@ struct pnr_ctx {
     unsigned int *d_minmax = nullptr; // [0]=min bits, [1]=max bits
     float *d_F[PNR_MAX_SIGMAS] = {};  // smoothed volume of every scale, kept for the direction bytes (frangi.hip)
     uint8_t *d_scale = nullptr;       // per voxel: the scale whose response is in J
+    bool frangi_pruned = false, frangi_exact_once = false; // J / the winning scale of J8 = 0 voxels are not exact (option frangi_prune); next run without it
+    int64_t fr_zs0 = 0, fr_zs1 = 0;                         // planes the extremes of the last Frangi run were taken over
     bool have_scale = false, have_v = false; // d_scale + d_F valid / the direction volumes Vx, Vy, Vz are filled
     float *d_taps = nullptr;          // Gaussian taps of all scales
     float *d_qh = nullptr;            // survivor queue of the Hessian stage: [region][6][entries]

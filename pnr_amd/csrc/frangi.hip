@@ -20,6 +20,8 @@
 #include "smc_device.h" // expf_libm: the device expf that equals the host libm value
 #include <cfloat>
 #include <cmath>
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -576,10 +578,12 @@ struct HessQueue {
 
 template <bool DUMP>
 __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restrict__ F, int w, int h, int l, int tiles_x, int tiles_y, int zc0, int zc1,
-                                                           float s2, HessQueue Q, unsigned int *__restrict__ minmax, int first, int zs0, int zs1, HessOut dump)
+                                                           float s2, HessQueue Q, unsigned int *__restrict__ minmax, int first, int zs0, int zs1, HessOut dump,
+                                                           float two_c2, int prune)
 {
     __shared__ float ring[HT_RING][HT_PLANE];
     __shared__ unsigned int s_cnt, s_zero;
+    __shared__ double s_s2max;
     const int tid = threadIdx.x, tx = tid & (HT_X - 1), ty = tid >> 6;
     // consecutive work-groups go round-robin to the 8 XCDs, each with its own L2: give every XCD a contiguous range of tiles, so
     // that the halo a tile shares with its x / y neighbours is found in the L2 of the same XCD
@@ -591,7 +595,29 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
     const int x0 = bx * HT_X, y0 = by * HT_Y, z0 = zc0 + bz * HT_Z;
     const int z1 = z0 + HT_Z < zc1 ? z0 + HT_Z : zc1;
     const i64 wh = (i64)w * h;
-    if (tid == 0) { s_cnt = 0; s_zero = 0; }
+    if (tid == 0) {
+        s_cnt = 0; s_zero = 0;
+        // Fourth way past the solver (option frangi_prune): a response that cannot reach the first non-zero J8 level.  The response
+        // is at most its factor 1 - exp(-S^2 / 2c^2), and S^2 = l1^2 + l2^2 + l3^2 is the squared Frobenius norm of the matrix -- no
+        // eigenvalues needed.  J8 = round(255 (J - Jmin) / (Jmax - Jmin)) is 0 below (Jmax - Jmin) / 510 (Advantra_plugin.cpp:2499-2512);
+        // once an exact 0 has been written in the planes this context owns, Jmin is 0 for good (a response is never negative), and
+        // the largest response written SO FAR is a lower bound of the final Jmax (of the global one when the stack is sharded).  A
+        // voxel whose bound lies below that / 510 -- with margins far above the rounding of the solver, of 1 - exp() and of the
+        // quantisation -- ends as J8 = 0 whatever its exact response: it is skipped like a proven zero, except that it is none (it
+        // does not establish Jmin = 0).  J8, Jmin, Jmax and every voxel with J8 > 0 (all seeds) keep their exact values and winning
+        // scale; the f32 J and the scale of J8 = 0 voxels do not, so pnr_get_frangi recomputes without this test when J or the
+        // direction volumes are asked for.  Which voxels are skipped depends on the order the work-groups run in; the results above do not.
+        double s2max = 0.0;
+        if (!DUMP && prune) {
+            const unsigned int mn = __hip_atomic_load(&minmax[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int mx = __hip_atomic_load(&minmax[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mn == f2ord(0.f) && mx != 0u) {
+                const double th = (double)ord2f(mx) / 510.0 * (1.0 - 1e-5) - 1e-15;
+                if (th > 0.0 && th < 0.5) s2max = -(double)two_c2 * log1p(-th) * (1.0 - 1e-9);
+            }
+        }
+        s_s2max = s2max;
+    }
     // a plane of the ring: HT_PLANE floats, two per thread; out-of-volume halo cells repeat the border (never read: the
     // one-sided border rules of the reference do not look past the border)
     const int e0 = tid, e1 = tid + HT_THREADS;
@@ -624,6 +650,7 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
     unsigned int *const qi = DUMP ? nullptr : Q.idx + (size_t)region * HT_REGION;
     int s0 = 0; // slot of plane z - 2
     bool zero_here = false;
+    const double s2max = s_s2max; // (written before the barrier above)
 #pragma unroll 1
     for (int z = z0; z < z1; z++) {
         float na = 0.f, nc = 0.f;
@@ -633,7 +660,7 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
 #pragma unroll
         for (int k = 0; k < 5; k++) { const int sl = s0 + k; T.pl[k] = ring[sl >= HT_RING ? sl - HT_RING : sl]; }
         T.o = o;
-        bool surv = false;
+        bool surv = false, skipped = false;
         float Dzz = 0, Dyy = 0, Dyz = 0, Dxx = 0, Dxy = 0, Dxz = 0;
         if (inside) {
             // six second derivatives, each x sigma^2 (frangi.cpp:319,339,345,368,374,380)
@@ -668,12 +695,16 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
                 const double tr = (double)Dxx + (double)Dyy + (double)Dzz;
                 const double nrm = fabs((double)Dxx) + fabs((double)Dyy) + fabs((double)Dzz) + 2.0 * (fabs((double)Dxy) + fabs((double)Dxz) + fabs((double)Dyz));
                 surv = !(tr > 1e-9 * nrm);
+                const double xx = Dxx, yy = Dyy, zz = Dzz, xy = Dxy, xz = Dxz, yz = Dyz;
+                if (surv && s2max > 0.0) { // cannot reach J8 = 1 (see the top of the kernel): skipped, but not a proven zero
+                    const double S2 = (xx * xx + yy * yy + zz * zz) + 2.0 * (xy * xy + xz * xz + yz * yz);
+                    if (S2 < s2max) { surv = false; skipped = true; }
+                }
                 if (surv) {
                     // Second proof of a zero response: TWO positive eigenvalues.  With all roots real, Descartes' rule on the
                     // characteristic polynomial l^3 - c2 l^2 + c1 l - c0 (c2 = trace <= 0 here) gives exactly two positive roots iff
                     // c1 < 0 and c0 < 0; then (p1 + p2) |n| > -c1 puts the larger positive root above 5e-10 of the norm -- far above
                     // the solver's rounding -- and at least one of the two largest-magnitude eigenvalues is that positive one.
-                    const double xx = Dxx, yy = Dyy, zz = Dzz, xy = Dxy, xz = Dxz, yz = Dyz;
                     const double c1 = (xx * yy - xy * xy) + (xx * zz - xz * xz) + (yy * zz - yz * yz);
                     const double c0 = xx * (yy * zz - yz * yz) - xy * (xy * zz - yz * xz) + xz * (xy * yz - yy * xz);
                     const double n2 = nrm * nrm, n3 = n2 * nrm;
@@ -685,7 +716,7 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
                     const bool one_pos_big = c0 > 1e-9 * n3 && (tr * c1 - c0) > 1e-9 * n3;
                     surv = !(two_pos || one_pos_big);
                 }
-                if (!surv && z >= zs0 && z < zs1) zero_here = true;
+                if (!surv && !skipped && z >= zs0 && z < zs1) zero_here = true;
             }
         }
         if (!DUMP) {
@@ -1070,7 +1101,7 @@ int pnr_hessian_run(pnr_ctx *c, float sig, float *const d_out[6])
     unsigned blocks;
     tile_grid(c, 0, l, tiles_x, tiles_y, blocks);
     hipLaunchKernelGGL(hessian_tile<true>, dim3(blocks), dim3(HT_THREADS), 0, c->stream, (const float *)c->d_tmpA, w, h, l, tiles_x, tiles_y, 0, l,
-                       sig * sig, HessQueue{}, (unsigned int *)nullptr, 1, 0, l, dump);
+                       sig * sig, HessQueue{}, (unsigned int *)nullptr, 1, 0, l, dump, 0.f, 0);
     PNR_HIP(hipGetLastError());
     PNR_HIP(hipStreamSynchronize(c->stream));
     return PNR_OK;
@@ -1150,6 +1181,10 @@ int pnr_frangi_run_range(pnr_ctx *c, int64_t zs0, int64_t zs1, bool finish, floa
     // f32 products, as "2*alpha*alpha" etc. in frangi.cpp:214-216
     const float two_a2 = 2 * P.alpha * P.alpha, two_b2 = 2 * P.beta * P.beta, two_c2 = 2 * P.C * P.C;
     const int cz = hess_chunk_planes(c);
+    const int prune = (c->opt.frangi_prune && !c->frangi_exact_once) ? 1 : 0;
+    c->frangi_exact_once = false;
+    c->fr_zs0 = zs0; c->fr_zs1 = zs1;
+    c->frangi_pruned = prune && l > 1;
     if (l > 1) {
         int tx, ty;
         unsigned blocks;
@@ -1177,15 +1212,26 @@ int pnr_frangi_run_range(pnr_ctx *c, int64_t zs0, int64_t zs1, bool finish, floa
             c->toc("hessian_eigen");
             continue;
         }
-        for (int zc0 = 0; zc0 < l; zc0 += cz) {
-            const int zc1 = std::min(l, zc0 + cz);
+        // z-chunks of at most cz planes.  With the J8 shortcut the first scale starts with one march (HT_Z planes) from the middle of
+        // the stack: the responses found there give the other chunks a lower bound of Jmax to prune with from their first voxel
+        std::vector<std::pair<int, int>> chunks;
+        if (prune && s == 0 && l > 2 * HT_Z) {
+            const int m0 = (l / 2) / HT_Z * HT_Z, m1 = m0 + HT_Z;
+            chunks.push_back({m0, m1});
+            for (int z = 0; z < m0; z += cz) chunks.push_back({z, std::min(m0, z + cz)});
+            for (int z = m1; z < l; z += cz) chunks.push_back({z, std::min(l, z + cz)});
+        } else {
+            for (int z = 0; z < l; z += cz) chunks.push_back({z, std::min(l, z + cz)});
+        }
+        for (const auto &ch : chunks) {
+            const int zc0 = ch.first, zc1 = ch.second;
             int tiles_x, tiles_y;
             unsigned blocks;
             tile_grid(c, zc0, zc1, tiles_x, tiles_y, blocks);
             const HessQueue Q{c->d_qh, c->d_qidx, c->d_qcount};
             c->tic();
             hipLaunchKernelGGL(hessian_tile<false>, dim3(blocks), dim3(HT_THREADS), 0, c->stream, (const float *)Fs, w, h, l, tiles_x, tiles_y, zc0, zc1,
-                               P.sig[s] * P.sig[s], Q, c->d_minmax, s == 0 ? 1 : 0, (int)zs0, (int)zs1, HessOut{});
+                               P.sig[s] * P.sig[s], Q, c->d_minmax, s == 0 ? 1 : 0, (int)zs0, (int)zs1, HessOut{}, two_c2, prune);
             c->toc("hessian_tile");
             c->tic();
             hipLaunchKernelGGL(eigen_queue, dim3(blocks * EQ_SUB), dim3(EQ_BLOCK), 0, c->stream, Q, c->d_J, c->d_scale, w, h, tiles_x, tiles_y, zc0,

@@ -49,8 +49,10 @@ def run_case(L, case, stats, desc, driver=None, big=False):
         fg = np.flatnonzero(smap.reshape(-1) > 0)
         assert np.array_equal(sm["E8"], E8o) and sm["threshold"] == tho and np.array_equal(sm["vox"], fg) and np.array_equal(sm["lab"], smap.reshape(-1)[fg]), "soma"
         stats["somas"] = stats.get("somas", 0) + len(n4)
-    c.frangi()
-    g = c.get_frangi(J=True, J8=True, V=True)
+    gext = c.frangi()
+    fast8 = c.get_frangi(J=False, J8=True, V=False)["J8"]  # what the pipeline uses: the run that skips the solver below the first J8 level
+    fast_seeds = c.extract_seeds()
+    g = c.get_frangi(J=True, J8=True, V=True)              # asking for J / V recomputes without that shortcut
     if two_d:
         J, jmin, jmax, Vx, Vy, Vz = orc.frangi2d(L, img, sigs)
     else:
@@ -58,8 +60,10 @@ def run_case(L, case, stats, desc, driver=None, big=False):
     J8 = orc.j8(L, J, jmin, jmax)
     for k, want in (("J", J), ("J8", J8), ("Vx", Vx), ("Vy", Vy), ("Vz", Vz)):
         assert np.array_equal(g[k].reshape(want.shape), want), f"frangi {k}: {(g[k].reshape(want.shape) != want).sum()} voxels differ"
+    assert np.array_equal(fast8.reshape(J8.shape), J8) and gext == (jmin, jmax), "J8 / extremes of the pruned run"
     so = orc.extract_seeds(L, tol, J8, Vx, Vy, Vz)
     sg = c.extract_seeds()
+    assert len(fast_seeds) == len(sg) and all(np.array_equal(fast_seeds[k], sg[k], equal_nan=True) for k in sg.dtype.names), "seeds of the pruned run"
     assert len(sg) == len(so) and np.array_equal(mat(sg)[:, :6], so[:, :6]), "seeds"
     if rad and len(so):  # seeds inside a soma are dropped (Advantra_plugin.cpp:2561-2564)
         vx = np.round(so[:, 2]).astype(np.int64) * w * h + np.round(so[:, 1]).astype(np.int64) * w + np.round(so[:, 0]).astype(np.int64)

@@ -35,6 +35,10 @@ def test_frangi_vs_golden(golden):
     c = ctx_for(golden["sigs"], float(golden["zdist"]))
     c.set_volume(golden["img"])
     jmin, jmax = c.frangi()
+    # J8 and the extremes as the pipeline uses them: from the run that skips the solver below the first J8 level (option
+    # frangi_prune); asking for J or V afterwards recomputes without that shortcut
+    fast8 = c.get_frangi(J=False, J8=True, V=False)["J8"]
+    assert np.array_equal(fast8, golden["J8_restated"])
     g = c.get_frangi()
     # the contract is J_RTOL (fp64 exp of the device library vs glibc, < 1 ulp each, before the f32 store); what is MEASURED on
     # gfx950 with this ROCm is identity on every golden voxel, and that is what is asserted for these fixed inputs
@@ -55,6 +59,7 @@ def test_frangi_vs_oracle_ragged(oracle, shape, sigs, zdist):
     c = ctx_for(sigs, zdist)
     c.set_volume(img)
     gmin, gmax = c.frangi()
+    assert np.array_equal(c.get_frangi(J=False, J8=True, V=False)["J8"], orc.j8(oracle, J, jmin, jmax))  # the pruned run's J8
     g = c.get_frangi()
     assert np.allclose(g["J"], J, rtol=J_RTOL, atol=0)
     assert gmin == jmin and abs(gmax - jmax) <= J_RTOL * jmax
