@@ -355,9 +355,9 @@ def main():
                 "device_ms_per_step": smc_all_ms / a.steps, "Mevals_per_s": evals * a.steps / smc_all_ms / 1e3,
                 "note": "SURVEY 8(d): 8*sum(M) algorithmic bytes x particle evaluations / device time of the whole SMC kernel group (t_smc)"},
             "roofline_frangi": None if not fr_vox or fr_ms <= 0 else {
-                "kernels": "gauss_x_u8+gauss_axis(y,z)+hessian_tile+eigen_queue+j8", "bound": "hbm", "achieved": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9,
+                "kernels": "gauss_x_u8_t+gauss_axis_t(y,z)+hessian_tile+eigen_queue+j8", "bound": "hbm", "achieved": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "device_ms_per_step": fr_ms,
-                "note": "(S+12) B/voxel compulsory bytes over the Frangi kernel group; the fp64 JAMA eigen-solver (parity-mandated) is the limiter"},
+                "note": "(S+12) B/voxel compulsory bytes over the Frangi kernel group; VALU-bound: three Gaussian passes with separate multiply and add (the reference's rounding) and the Hessian stencil with its zero-response tests; the fp64 JAMA eigen-solver runs only where the response can reach J8 > 0"},
             "roofline_sums": None if a.driver != "phased" or km["smc_sums"][0] <= 0 else {
                 "kernel": "ph_sums", "bound": "hbm", "launches": km["smc_sums"][1], "avg_launch_ms": km["smc_sums"][0] / max(km["smc_sums"][1], 1),
                 "achieved": 2.0 * 4 * Mtot * stash_row_floats(a.np) * st["iters"] * a.steps / (km["smc_sums"][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -108,7 +108,11 @@ int pnr_frangi(pnr_ctx *ctx, float *Jmin, float *Jmax);
 int pnr_frangi_slab(pnr_ctx *ctx, int64_t z_keep0, int64_t z_keep1, float *Jmin, float *Jmax);
 int pnr_quantise_j8(pnr_ctx *ctx, float Jmin, float Jmax);
 
-/* Optional read-back of the Frangi outputs (any pointer may be NULL); N = w*h*l each. */
+/* Optional read-back of the Frangi outputs (any pointer may be NULL); N = w*h*l each.  J8 is always what pnr_frangi left in HBM.
+ * With option frangi_prune (default 1) pnr_frangi skips the eigen-solver where the response provably cannot reach the first
+ * non-zero J8 level: J8, Jmin / Jmax and everything at voxels with J8 > 0 (all seeds) are exact, but the f32 J and the winning
+ * scale of J8 = 0 voxels are not -- so asking for J or for the direction volumes first recomputes the response without that
+ * shortcut (one more pnr_frangi worth of GPU time; tests and --save-midres only). */
 int pnr_get_frangi(pnr_ctx *ctx, float *J, uint8_t *J8, uint8_t *Vx, uint8_t *Vy, uint8_t *Vz);
 /* Test taps: Frangi::imgaussian (frangi.cpp:647) and Frangi::hessian3d (:291) for one sigma.
  * Host outputs, N floats each; Hessian order Dzz,Dyy,Dyz,Dxx,Dxy,Dxz (any may be NULL). */
@@ -259,7 +263,8 @@ int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
  *   local_ranks) workers of the seed flood fill and of pnr_reconstruct_ctx | local_ranks (1) processes sharing this host |
  *   trace_timing, seed_timing (0/1) statistics on stderr | trace_log (0/1) keep every trace's end for pnr_get_trace_log | replay_batches (0/1), batch_growth, batch_max: rank batches instead
  *   of the streaming window | no_stash (0/1) persistent driver without the sample stash | exchange_block (0 = 256 KB / world) bytes per rank
- *   and exchange of pnr_trace_replay_sharded.   pnr_get_option also knows "host_threads_effective". */
+ *   and exchange of pnr_trace_replay_sharded | frangi_prune (1) skip the eigen-solver below the first J8 level (pnr_get_frangi).
+ *   pnr_get_option also knows "host_threads_effective". */
 int pnr_set_option(pnr_ctx *ctx, const char *key, int64_t value);
 int pnr_get_option(pnr_ctx *ctx, const char *key, int64_t *value);
 
