@@ -112,7 +112,9 @@ int pnr_quantise_j8(pnr_ctx *ctx, float Jmin, float Jmax);
  * With option frangi_prune (default 1) pnr_frangi skips the eigen-solver where the response provably cannot reach the first
  * non-zero J8 level: J8, Jmin / Jmax and everything at voxels with J8 > 0 (all seeds) are exact, but the f32 J and the winning
  * scale of J8 = 0 voxels are not -- so asking for J or for the direction volumes first recomputes the response without that
- * shortcut (one more pnr_frangi worth of GPU time; tests and diagnostics). */
+ * shortcut (one more pnr_frangi worth of GPU time; tests and diagnostics), and so does pnr_quantise_j8 when it is given extremes
+ * the shortcut did not assume (Jmin other than 0, or a Jmax below the run's own maximum; the global extremes of a sharded stack
+ * never are). */
 int pnr_get_frangi(pnr_ctx *ctx, float *J, uint8_t *J8, uint8_t *Vx, uint8_t *Vy, uint8_t *Vz);
 /* Test taps: Frangi::imgaussian (frangi.cpp:647) and Frangi::hessian3d (:291) for one sigma.
  * Host outputs, N floats each; Hessian order Dzz,Dyy,Dyz,Dxx,Dxy,Dxz (any may be NULL). */

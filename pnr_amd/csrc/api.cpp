@@ -302,6 +302,13 @@ int pnr_quantise_j8(pnr_ctx *c, float Jmin, float Jmax)
 {
     PNR_REQUIRE(c && c->d_img, PNR_E_STATE, "pnr_quantise_j8: no volume set");
     PNR_HIP(hipSetDevice(c->device));
+    if (c->frangi_pruned && !(Jmin == 0.f && Jmax >= c->Jmax_run)) {
+        // the last run skipped the solver below the first J8 level of ITS extremes (Jmin = 0, Jmax at least its own maximum): the
+        // global extremes of a sharded stack satisfy that; anything else needs the exact response
+        c->frangi_exact_once = true;
+        const int rc = pnr_frangi_run_range(c, c->fr_zs0, c->fr_zs1, false, nullptr, nullptr);
+        if (rc) return rc;
+    }
     return pnr_j8_run(c, Jmin, Jmax);
 }
 

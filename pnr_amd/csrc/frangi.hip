@@ -1245,6 +1245,8 @@ int pnr_frangi_run_range(pnr_ctx *c, int64_t zs0, int64_t zs1, bool finish, floa
     PNR_HIP(hipGetLastError());
     c->Jmin = ord2f(mm[0]);
     c->Jmax = ord2f(mm[1]);
+    c->Jmax_run = c->Jmax;
+    if (c->frangi_pruned && c->Jmin != 0.f) c->frangi_pruned = false; // (no exact zero was ever written: nothing was skipped)
     c->have_j8 = false;
     c->have_scale = l > 1;
     c->have_v = l == 1; // the 2-D kernel writes the direction bytes itself

@@ -97,3 +97,24 @@ def test_frangi_properties_larger():
     d = np.abs(a["J8"].astype(int) - b["J8"][:, ::-1, :].astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 0.01
     assert a["J8"].max() == 255 and (a["J8"] > 0).mean() < 0.5
+
+
+def test_j8_shortcut_and_foreign_extremes(oracle):
+    """the solver is skipped where the response cannot reach J8 = 1 OF THE RUN'S OWN extremes (option frangi_prune); quantising with
+    other extremes -- a smaller Jmax, a Jmin above 0 -- needs the exact response and gets it; the option off gives the same bytes"""
+    img = synth.synth(96, 80, 40, seed=7)
+    sigs, zdist = [2.0, 4.0], 2.0
+    J, jmin, jmax, Vx, Vy, Vz = orc.frangi3d(oracle, img, sigs, zdist)
+    c = ctx_for(sigs, zdist)
+    c.set_volume(img)
+    assert c.frangi() == (jmin, jmax) and jmin == 0.0
+    fast = c.get_frangi(J=False, J8=True, V=False)["J8"]
+    assert np.array_equal(fast, orc.j8(oracle, J, jmin, jmax)) and (fast > 0).mean() < 0.5
+    for lo, hi in ((0.0, jmax / 7), (jmax / 300, jmax), (0.0, jmax * 3)):
+        c.frangi()
+        c.quantise_j8(lo, hi)
+        assert np.array_equal(c.get_frangi(J=False, J8=True, V=False)["J8"], orc.j8(oracle, J, np.float32(lo), np.float32(hi))), (lo, hi)
+    c.set_option("frangi_prune", 0)
+    assert c.frangi() == (jmin, jmax)
+    assert np.array_equal(c.get_frangi(J=False, J8=True, V=False)["J8"], fast)
+    c.close()
