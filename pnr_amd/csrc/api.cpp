@@ -241,6 +241,7 @@ static int set_dims(pnr_ctx *c, int64_t w, int64_t h, int64_t l)
     c->N = w * h * l;
     c->have_j8 = false;
     c->have_v = c->have_scale = false;
+    c->frangi_pruned = false;
     c->seeds.clear();
     c->have_soma = false;
     if ((l == 1) != c->tab.is2d) { // the tracker tables depend on the dimensionality (Tracker(..., P == 1, ...))
@@ -387,6 +388,7 @@ int pnr_set_j8_v(pnr_ctx *c, const uint8_t *J8, const uint8_t *Vx, const uint8_t
     c->have_j8 = true;
     c->have_v = true;
     c->have_scale = false;
+    c->frangi_pruned = false; // what is in HBM now is the caller's, not a run of pnr_frangi
     return PNR_OK;
 }
 
