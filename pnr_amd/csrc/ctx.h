@@ -168,10 +168,13 @@ struct pnr_ctx {
         std::string group;
         hipEvent_t a, b;
         int launches;
+        bool a_shared = false; // a is the b of the entry before (chained timers): not freed twice
     };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> free_events;
-    hipEvent_t cur_a = nullptr;
+    hipEvent_t cur_a = nullptr, last_b = nullptr; // last_b: the closing event of the last toc(), reusable as the next opening event
+    hipStream_t last_b_stream = nullptr;
+    bool cur_a_shared = false;
     std::map<std::string, pnr::KernelTimer> timers;
 
     // grow-only named device scratch (per-layer tables, candidate keys, ...): nothing is allocated or freed inside a timed stage
@@ -209,19 +212,31 @@ struct pnr_ctx {
         (void)hipEventCreate(&e);
         return e;
     }
-    void tic(hipStream_t on = nullptr)
+    // chain = true: nothing was queued on the stream since the last toc() on it -- its closing event opens this timer as well (one
+    // event per kernel instead of two in the SMC loops, where the events are ~2 % of a step)
+    void tic(hipStream_t on = nullptr, bool chain = false)
     {
         if (!profiling) return;
+        hipStream_t s = on ? on : stream;
+        if (chain && last_b && last_b_stream == s) {
+            cur_a = last_b;
+            cur_a_shared = true;
+            return;
+        }
         cur_a = get_event();
-        (void)hipEventRecord(cur_a, on ? on : stream);
+        cur_a_shared = false;
+        (void)hipEventRecord(cur_a, s);
     }
     void toc(const char *group, int launches = 1, hipStream_t on = nullptr)
     {
         if (!profiling || !cur_a) return;
+        hipStream_t s = on ? on : stream;
         hipEvent_t b = get_event();
-        (void)hipEventRecord(b, on ? on : stream);
-        pending.push_back(Pending{group, cur_a, b, launches});
+        (void)hipEventRecord(b, s);
+        pending.push_back(Pending{group, cur_a, b, launches, cur_a_shared});
         cur_a = nullptr;
+        last_b = b;
+        last_b_stream = s;
     }
     void resolve_timers()
     {
@@ -232,10 +247,11 @@ struct pnr_ctx {
             auto &t = timers[p.group];
             t.ms += ms;
             t.launches += p.launches;
-            free_events.push_back(p.a);
+            if (!p.a_shared) free_events.push_back(p.a);
             free_events.push_back(p.b);
         }
         pending.clear();
+        last_b = nullptr;
     }
 };
 

@@ -998,19 +998,19 @@ struct PhasedEngine final : pnr::StreamEngine {
         for (int k = 0; k < poll; k++) { // `poll` SMC steps over the group's active list (every trace at its own iteration)
             const int lp = q.lp;
             const int nsplit = pick_nsplit(active, E.ncu, E.max_split, split_x10);
-            c->tic(st);
+            c->tic(st, k > 0); // (the first step of a poll follows the admission copies: its own opening event)
             hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
             c->toc("smc_predict", 1, st);
-            c->tic(st);
+            c->tic(st, true);
             if (E.V.l == 1)
                 hipLaunchKernelGGL((ph_sample<PH_CS, true>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
             else
                 hipLaunchKernelGGL((ph_sample<PH_CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
             c->toc("smc", 1, st);
-            c->tic(st);
+            c->tic(st, true);
             hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp, ng);
             c->toc("smc_sums", 1, st);
-            c->tic(st);
+            c->tic(st, true);
             hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), E.upd_lds, st, E.V, E.T, P, np, np_pad, ni, -1, lp, c->prm.Kc, c->prm.znccth,
                                c->prm.neff_ratio, c->d_den, c->prm.nodepervol, O);
             c->toc("smc_update", 1, st);
