@@ -84,6 +84,27 @@ def cpu_info():
     return model, os.cpu_count()
 
 
+class heartbeat:
+    """a line on stderr every minute while a long, silent host computation runs (the oracle's C calls release the GIL)"""
+
+    def __init__(self, what):
+        import threading
+        self.what, self.stop, self.t0 = what, threading.Event(), time.perf_counter()
+        self.th = threading.Thread(target=self.run, daemon=True)
+
+    def run(self):
+        while not self.stop.wait(60.0):
+            print(f"[bench] {self.what}: {time.perf_counter() - self.t0:.0f} s ...", file=sys.stderr, flush=True)
+
+    def __enter__(self):
+        self.th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        self.th.join()
+
+
 def cpu_baseline(img_dev, sigs, zdist, np_, ni, counts, nvox, kind):
     """Oracle (oracle/pnr_oracle.c, the C restatement of the reference's scalar loops; 1 thread) on a bounded sample of the SAME
     stack: Frangi + J8 + seed extraction on a z-slab of full xy extent (so the strided y / z passes see the real
@@ -411,7 +432,8 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * Mtot * ev1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "Mevals_per_s": ev1 / ms1 / 1e3,
                 "note": "all %d traces started together, traced to their map-free end (no early DENSITY stops): %d SMC iterations; measured after the timed region" % (len(T1), ev1 // (a.np + 1))}
         if a.cpu_baseline != "off" and world == 1 and not shard:
-            out["cpu_baseline"] = cpu_baseline(img, list(sigs), zdist, a.np, a.ni, st, nvox, a.cpu_baseline)
+            with heartbeat("cpu baseline (oracle, one host core)"):
+                out["cpu_baseline"] = cpu_baseline(img, list(sigs), zdist, a.np, a.ni, st, nvox, a.cpu_baseline)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
