@@ -144,6 +144,9 @@ __device__ __forceinline__ float zncc_chain(const Vol &V, const Frame &f, const 
     }
     for (; k < M; ++k) ag += sample(V, f, tm[k]);
     ag /= (float)M;
+#ifdef PNR_SMC_STAMPS
+    if (stamp_pass1) *stamp_pass1 = __builtin_amdgcn_s_memtime();
+#endif
     float corra = 0.f, corrb = 0.f;
     for (k = 0; k + ZB <= M; k += ZB) {
         float v[ZB], w[ZB];
@@ -536,7 +539,11 @@ __device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, 
 // per lane in flight.  All 64 lanes of the wave must call it (template weights are broadcast).
 template <int STRIDE = 64, int CH = 32>
 __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash_lane, int M, const float *__restrict__ wd,
-                                                 float corrc)
+                                                 float corrc
+#ifdef PNR_SMC_STAMPS
+                                                 , unsigned long long *stamp_pass1 = nullptr // diagnostic build: shader clock at the end of pass 1
+#endif
+)
 {
     // M = nfull full chunks of CH values + a tail.  The full chunks run without any per-value test (each value is a handful of
     // dependent VALU operations: a branch per value doubled the serial time of a chain); the next chunk is in flight meanwhile.

@@ -425,8 +425,16 @@ __global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, 
     const float *wd = X.wd + gr.off;
     float cv;
     bool valid = true;
+#ifdef PNR_SMC_STAMPS
+    const unsigned long long sst0 = __builtin_amdgcn_s_memtime();
+    unsigned long long sst1 = sst0;
+#endif
     if (g < ngf) {
+#ifdef PNR_SMC_STAMPS
+        cv = zncc_from_stash<64, PH_CH>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI], &sst1);
+#else
         cv = zncc_from_stash<64, PH_CH>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI]);
+#endif
     } else { // last group: narrow rows; lanes without a chain re-read a valid column (same 64 B granules)
         valid = lane < rem;
         const int j = valid ? lane : rem - 1;
@@ -438,6 +446,14 @@ __global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, 
         }
     }
     if (valid) P.corr[((i64)tr * S + sI) * np_pad + g * 64 + lane] = cv; // indexed by chain
+#ifdef PNR_SMC_STAMPS
+    if (lane == 0 && g < ngf && sI == S - 1) { // full groups of the longest template: [5] pass 1, [6] pass 2, [7] waves
+        const unsigned long long sst2 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_ph_stamps[5], sst1 - sst0);
+        atomicAdd(&g_ph_stamps[6], sst2 - sst1);
+        atomicAdd(&g_ph_stamps[7], 1ull);
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np, int np_pad, int ni, int it_arg, int lp, float Kc, float znccth,

@@ -18,4 +18,5 @@ L.pnr_debug_ph_stamps(st, 1)
 c.trace_replay(s)
 L.pnr_debug_ph_stamps(st, 0)
 stage, items, wgs, nit = st[0], st[1], st[2], st[3]
+print(f"ph_sums, full groups of the longest template: pass 1 {st[5] / max(st[7], 1):.0f} cycles, pass 2 {st[6] / max(st[7], 1):.0f} cycles per wave ({st[7]} waves; s_memtime ticks)")
 print(f"flags wait {st[4] / wgs:.0f} cycles; work-groups {wgs}, staging {stage / wgs:.0f} cycles per work-group, item loop of wave 0 {items / wgs:.0f} cycles ({nit / wgs:.2f} items), staging share {stage / (stage + items):.3f}")
