@@ -266,7 +266,9 @@ int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
  *   trace_timing, seed_timing (0/1) statistics on stderr | trace_log (0/1) keep every trace's end for pnr_get_trace_log | replay_batches (0/1), batch_growth, batch_max: rank batches instead
  *   of the streaming window | no_stash (0/1) persistent driver without the sample stash | exchange_block (0 = 256 KB / world) bytes per rank
  *   and exchange of pnr_trace_replay_sharded | frangi_prune (1) skip the eigen-solver below the first J8 level (pnr_get_frangi).
- *   pnr_get_option also knows "host_threads_effective". */
+ *   pnr_get_option also knows "host_threads_effective" and "frangi_recomputes" (how often pnr_get_frangi / pnr_quantise_j8 had to
+ *   re-run Frangi without the frangi_prune shortcut -- one pnr_frangi worth of GPU time each; also printed with trace_timing /
+ *   seed_timing).  The kernel timers (pnr_get_kernel_ms) include those re-runs. */
 int pnr_set_option(pnr_ctx *ctx, const char *key, int64_t value);
 int pnr_get_option(pnr_ctx *ctx, const char *key, int64_t *value);
 

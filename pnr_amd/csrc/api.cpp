@@ -307,6 +307,8 @@ int pnr_quantise_j8(pnr_ctx *c, float Jmin, float Jmax)
         // the last run skipped the solver below the first J8 level of ITS extremes (Jmin = 0, Jmax at least its own maximum): the
         // global extremes of a sharded stack satisfy that; anything else needs the exact response
         c->frangi_exact_once = true;
+        c->frangi_recomputes++;
+        if (c->opt.trace_timing || c->opt.seed_timing) fprintf(stderr, "[pnr frangi] pnr_quantise_j8(%g, %g): extremes the pruned run did not assume -- exact re-run of every scale\n", Jmin, Jmax);
         const int rc = pnr_frangi_run_range(c, c->fr_zs0, c->fr_zs1, false, nullptr, nullptr);
         if (rc) return rc;
     }
@@ -323,6 +325,8 @@ int pnr_get_frangi(pnr_ctx *c, float *J, uint8_t *J8, uint8_t *Vx, uint8_t *Vy, 
         // seeds are exact, the f32 J and the winning scale of J8 = 0 voxels are not -- recompute without the shortcut, same extremes
         const float jmin = c->Jmin, jmax = c->Jmax;
         c->frangi_exact_once = true;
+        c->frangi_recomputes++;
+        if (c->opt.trace_timing || c->opt.seed_timing) fprintf(stderr, "[pnr frangi] pnr_get_frangi: J / V asked for after a pruned run -- exact re-run of every scale\n");
         rc = pnr_frangi_run_range(c, c->fr_zs0, c->fr_zs1, false, nullptr, nullptr);
         if (!rc) rc = pnr_j8_run(c, jmin, jmax);
         if (rc) return rc;
@@ -570,22 +574,32 @@ static int trace_replay_impl(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int64
                              int64_t *n_iterations)
 {
     PNR_REQUIRE(c && n_nodes && n_links && (n == 0 || seeds), PNR_E_ARG, "null argument");
-    PNR_REQUIRE(c->d_img, PNR_E_STATE, "no volume set");
-    PNR_HIP(hipSetDevice(c->device));
     const int ni = c->prm.ni;
-    PNR_REQUIRE(c->prm.somaradius == 0 || c->have_soma, PNR_E_STATE, "somaradius > 0: call pnr_soma first");
+    // Sharded: a rank that fails here, before its scheduler runs, still owes the other ranks the exchange they are about to enter
+    // (include/pnr_hip.h: "a rank that fails says so in one last exchange") -- one block with the abort word set.  n == 0 is the
+    // same on every rank and exchanges nothing.
+    auto prepare = [&]() -> int {
+        PNR_REQUIRE(c->d_img, PNR_E_STATE, "no volume set");
+        PNR_HIP(hipSetDevice(c->device));
+        PNR_REQUIRE(c->prm.somaradius == 0 || c->have_soma, PNR_E_STATE, "somaradius > 0: call pnr_soma first");
+        PNR_REQUIRE((c->smc_driver == 0 && !c->opt.replay_batches) || sh.world <= 1, PNR_E_STATE,
+                    "sharded tracing needs the phased driver with the streaming scheduler");
+        return pnr_density_reset(c);
+    };
     c->have_graph = false;
+    c->graph_log.clear();
+    int rc = prepare();
+    if (rc) {
+        if (n > 0) pnr::abort_exchange(sh, ni);
+        return rc;
+    }
     pnr::Replayer r(c->prm, c->w, c->h, c->l);
     r.set_soma(&c->soma_map, c->soma_nodes);
     std::vector<pnr::Replayer::TraceEnd> ends;
     if (c->opt.trace_log) r.log = &ends;
-    c->graph_log.clear();
-    int rc = pnr_density_reset(c);
-    if (rc) return rc;
     int64_t iters = 0;
     // phased driver: a window of trace slots refilled as traces stop (smc_phased.hip); `first_batch` has no meaning there
     const bool streaming = c->smc_driver == 0 && !c->opt.replay_batches;
-    PNR_REQUIRE(streaming || sh.world <= 1, PNR_E_STATE, "sharded tracing needs the phased driver with the streaming scheduler");
     if (streaming) {
         rc = pnr_trace_replay_stream(c, seeds, n, r, sh, &iters);
         if (rc) return rc;
@@ -736,14 +750,19 @@ int pnr_sched_playback(const pnr_params *p, int64_t w, int64_t h, int64_t l, con
     PNR_REQUIRE(p && trace && n_nodes && n_links && (n == 0 || seeds), PNR_E_ARG, "null argument");
     PNR_REQUIRE(w > 0 && h > 0 && l > 0, PNR_E_ARG, "bad dimensions");
     PNR_REQUIRE(world >= 1 && rank >= 0 && rank < world && (world == 1 || exchange), PNR_E_ARG, "bad rank / world / exchange");
+    pnr::ShardSpec sh;
+    sh.rank = rank; sh.world = world; sh.exchange = exchange; sh.user = xuser; sh.block_bytes = block_bytes;
+    if (window < 2) { // the playback engine's "set-up failure" (what an out-of-memory GPU is to the HIP engine): the other ranks must hear of it
+        set_error("playback engine: a window of %d trace slots", window);
+        if (n > 0) pnr::abort_exchange(sh, p->ni);
+        return PNR_E_ARG;
+    }
     pnr::Replayer r(*p, w, h, l);
-    window = std::max(2, window) & ~1;
+    window &= ~1;
     PlaybackEngine eng(*p, w, h, window, trace, tuser);
     pnr::SchedOptions o;
     o.window = window; o.groups = std::max(1, groups); o.poll = std::max(1, poll);
     o.look0 = std::max(0, look0); o.look_pct = look_pct;
-    pnr::ShardSpec sh;
-    sh.rank = rank; sh.world = world; sh.exchange = exchange; sh.user = xuser; sh.block_bytes = block_bytes;
     pnr::SchedStats st;
     std::string err;
     const int rc = pnr::run_stream(eng, seeds, n, p->ni, o, sh, r, &st, err);
@@ -791,6 +810,7 @@ int pnr_get_option(pnr_ctx *c, const char *key, int64_t *value)
 {
     PNR_REQUIRE(c && key && value, PNR_E_ARG, "null argument");
     if (std::strcmp(key, "host_threads_effective") == 0) { *value = pnr::host_threads(c->opt); return PNR_OK; }
+    if (std::strcmp(key, "frangi_recomputes") == 0) { *value = c->frangi_recomputes; return PNR_OK; } // exact Frangi re-runs so far (one pnr_frangi of GPU time each)
     for (const OptEntry &e : OPTS)
         if (std::strcmp(e.key, key) == 0) {
             *value = e.i32 ? (int64_t)(c->opt.*(e.i32)) : c->opt.*(e.i64);

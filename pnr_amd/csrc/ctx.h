@@ -104,6 +104,7 @@ struct pnr_ctx {
     uint8_t *d_scale = nullptr;       // per voxel: the scale whose response is in J
     bool frangi_pruned = false, frangi_exact_once = false; // J / the winning scale of J8 = 0 voxels are not exact (option frangi_prune); next run without it
     float Jmax_run = 0.f;                                   // the maximum the last Frangi run found itself (before pnr_quantise_j8)
+    int64_t frangi_recomputes = 0;                          // exact re-runs pnr_get_frangi / pnr_quantise_j8 had to make (pnr_get_option "frangi_recomputes")
     int64_t fr_zs0 = 0, fr_zs1 = 0;                         // planes the extremes of the last Frangi run were taken over
     bool have_scale = false, have_v = false; // d_scale + d_F valid / the direction volumes Vx, Vy, Vz are filled
     float *d_taps = nullptr;          // Gaussian taps of all scales

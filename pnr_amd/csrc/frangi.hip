@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256) void gauss_x_u8_t(const uint8_t *__restrict__ 
     const int x0 = (int)(b % tiles_x) * GXT_W;
     const i64 r0 = (b / tiles_x) * GXT_H;
     const int tid = threadIdx.x;
-    if (x0 - L >= 0 && x0 + GXT_W + L + 3 <= w) { // interior in x: whole dwords, no clamping (the block-uniform common case)
+    // interior in x: whole dwords, no clamping (the block-uniform common case).  The last dword read ends at byte x0 + L + 35 - mis
+    // of the row at most (NDW dwords from the aligned-down start), so x0 + GXT_W + L + 4 <= w keeps every read inside the row --
+    // the last row of a caller-owned buffer (pnr_set_volume_device) must not be read past its end
+    if (x0 - L >= 0 && x0 + GXT_W + L + 4 <= w) {
         constexpr int NDW = (SPAN + 6) / 4;      // dwords that cover SPAN bytes at any misalignment
         const int a = (x0 - L) & ~3, mis = (x0 - L) - a;
         typedef unsigned __attribute__((aligned(1))) u32u; // (rows are only dword-aligned when w and the base pointer are)

@@ -19,20 +19,23 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <thread>
+#include <time.h>
 #include <unistd.h>
 
 namespace pnr { void set_error(const char *fmt, ...); }
 
 namespace {
 struct ShmHeader {
-    std::atomic<uint32_t> magic;   // set last by the creator
+    std::atomic<uint32_t> magic;   // set last by the creator; SHM_DEAD once a later job's rank 0 has found the segment stale
     uint32_t world;
     uint64_t capacity;             // bytes per rank and buffer
     std::atomic<uint32_t> arrived; // barrier: ranks that have arrived in this phase
     std::atomic<uint32_t> phase;   // barrier: generation
-    std::atomic<uint32_t> attached, failed;
+    std::atomic<uint32_t> attached, failed; // attached: ranks that mapped the segment (reported when the attach barrier times out)
+    uint64_t stamp;                // CLOCK_REALTIME ns at creation (diagnostics)
 };
 constexpr uint32_t SHM_MAGIC = 0x504e5258u; // "PNRX"
+constexpr uint32_t SHM_DEAD = 0x44454144u;  // "DEAD"
 constexpr size_t HDR = 256;
 } // namespace
 
@@ -56,15 +59,18 @@ static bool shm_barrier(pnr_shm_exchange *x)
         h->phase.store(gen + 1, std::memory_order_release);
         return true;
     }
+    // a short spin (an exchange between ranks in step takes microseconds), then sleep in growing slices: a rank that waits for a
+    // slower one must not burn the core its own host threads were counted on (host_threads = CPUs / local_ranks)
     const auto t0 = std::chrono::steady_clock::now();
+    int64_t nap_us = 20;
     for (uint64_t spins = 0; h->phase.load(std::memory_order_acquire) == gen; spins++) {
         if (h->failed.load(std::memory_order_relaxed)) return false;
-        if ((spins & 1023) == 1023) {
-            std::this_thread::yield();
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > x->timeout_s) {
-                h->failed.store(1, std::memory_order_relaxed);
-                return false;
-            }
+        if (spins < 4096) continue;
+        std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
+        if (nap_us < 500) nap_us += nap_us / 2;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > x->timeout_s) {
+            h->failed.store(1, std::memory_order_relaxed);
+            return false;
         }
     }
     return true;
@@ -86,7 +92,23 @@ int pnr_shm_exchange_open(const char *name, int rank, int world, int64_t capacit
     x->bytes = HDR + 2 * (size_t)world * cap;
     const auto t0 = std::chrono::steady_clock::now();
     if (rank == 0) {
-        shm_unlink(x->name.c_str()); // a stale segment of a crashed run
+        // A stale segment of a crashed run under the same name: a rank of THIS job may have opened it already (it was there before
+        // we were) -- mark it dead first, so that whoever waits on it gives up and opens the name again, then remove the name.
+        {
+            const int ofd = shm_open(x->name.c_str(), O_RDWR, 0600);
+            struct stat sb;
+            if (ofd >= 0 && fstat(ofd, &sb) == 0 && (size_t)sb.st_size >= HDR) {
+                void *m = mmap(nullptr, HDR, PROT_READ | PROT_WRITE, MAP_SHARED, ofd, 0);
+                if (m != MAP_FAILED) {
+                    ShmHeader *old = (ShmHeader *)m;
+                    old->magic.store(SHM_DEAD, std::memory_order_release);
+                    old->failed.store(1, std::memory_order_release);
+                    munmap(m, HDR);
+                }
+            }
+            if (ofd >= 0) close(ofd);
+        }
+        shm_unlink(x->name.c_str());
         x->fd = shm_open(x->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
         if (x->fd < 0 || ftruncate(x->fd, (off_t)x->bytes) != 0) {
             pnr::set_error("shm_open / ftruncate of %s (%zu B) failed: %s", x->name.c_str(), x->bytes, strerror(errno));
@@ -95,58 +117,76 @@ int pnr_shm_exchange_open(const char *name, int rank, int world, int64_t capacit
             return PNR_E_NOMEM;
         }
         x->owner = true;
-    } else {
-        for (;;) { // the creator may not be there yet
-            x->fd = shm_open(x->name.c_str(), O_RDWR, 0600);
-            struct stat sb;
-            if (x->fd >= 0 && fstat(x->fd, &sb) == 0 && (size_t)sb.st_size >= x->bytes) break;
-            if (x->fd >= 0) { close(x->fd); x->fd = -1; }
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
-                pnr::set_error("shared segment %s did not appear", x->name.c_str());
+    }
+    auto unmap = [&]() {
+        if (x->base && x->base != (unsigned char *)MAP_FAILED) munmap(x->base, x->bytes);
+        if (x->fd >= 0) close(x->fd);
+        x->base = nullptr; x->h = nullptr; x->fd = -1;
+    };
+    auto late = [&](double limit) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit; };
+    for (;;) { // (a non-owner comes back here when the segment it found turns out to be a dead one)
+        if (rank != 0) {
+            for (;;) { // the creator may not be there yet
+                x->fd = shm_open(x->name.c_str(), O_RDWR, 0600);
+                struct stat sb;
+                if (x->fd >= 0 && fstat(x->fd, &sb) == 0 && (size_t)sb.st_size >= x->bytes) break;
+                if (x->fd >= 0) { close(x->fd); x->fd = -1; }
+                if (late(120.0)) {
+                    pnr::set_error("shared segment %s did not appear", x->name.c_str());
+                    delete x;
+                    return PNR_E_STATE;
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+        }
+        x->base = (unsigned char *)mmap(nullptr, x->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, x->fd, 0);
+        if (x->base == (unsigned char *)MAP_FAILED) {
+            pnr::set_error("mmap of %s failed: %s", x->name.c_str(), strerror(errno));
+            x->base = nullptr;
+            unmap();
+            if (x->owner) shm_unlink(x->name.c_str());
+            delete x;
+            return PNR_E_NOMEM;
+        }
+        x->h = (ShmHeader *)x->base;
+        if (rank == 0) {
+            struct timespec now;
+            clock_gettime(CLOCK_REALTIME, &now);
+            x->h->world = (uint32_t)world;
+            x->h->capacity = cap;
+            x->h->stamp = (uint64_t)now.tv_sec * 1000000000ull + (uint64_t)now.tv_nsec;
+            x->h->arrived.store(0); x->h->phase.store(0); x->h->attached.store(0); x->h->failed.store(0);
+            x->h->magic.store(SHM_MAGIC, std::memory_order_release);
+        } else {
+            uint32_t mg;
+            while ((mg = x->h->magic.load(std::memory_order_acquire)) != SHM_MAGIC && mg != SHM_DEAD) {
+                if (late(120.0)) {
+                    pnr::set_error("shared segment %s was never initialised", x->name.c_str());
+                    unmap();
+                    delete x;
+                    return PNR_E_STATE;
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+            if (mg == SHM_DEAD) { unmap(); std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; } // a crashed job's segment: open the name again
+            if (x->h->world != (uint32_t)world || x->h->capacity != cap) {
+                pnr::set_error("shared segment %s belongs to a different job (world %u, capacity %llu)", x->name.c_str(), x->h->world, (unsigned long long)x->h->capacity);
+                unmap();
                 delete x;
                 return PNR_E_STATE;
             }
-            std::this_thread::sleep_for(std::chrono::milliseconds(2));
         }
-    }
-    x->base = (unsigned char *)mmap(nullptr, x->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, x->fd, 0);
-    if (x->base == (unsigned char *)MAP_FAILED) {
-        pnr::set_error("mmap of %s failed: %s", x->name.c_str(), strerror(errno));
-        close(x->fd);
-        if (x->owner) shm_unlink(x->name.c_str());
-        delete x;
-        return PNR_E_NOMEM;
-    }
-    x->h = (ShmHeader *)x->base;
-    if (rank == 0) {
-        x->h->world = (uint32_t)world;
-        x->h->capacity = cap;
-        x->h->arrived.store(0); x->h->phase.store(0); x->h->attached.store(0); x->h->failed.store(0);
-        x->h->magic.store(SHM_MAGIC, std::memory_order_release);
-    } else {
-        while (x->h->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
-                pnr::set_error("shared segment %s was never initialised", x->name.c_str());
-                munmap(x->base, x->bytes); close(x->fd);
-                delete x;
-                return PNR_E_STATE;
-            }
-            std::this_thread::sleep_for(std::chrono::milliseconds(1));
-        }
-        if (x->h->world != (uint32_t)world || x->h->capacity != cap) {
-            pnr::set_error("shared segment %s belongs to a different job (world %u, capacity %llu)", x->name.c_str(), x->h->world, (unsigned long long)x->h->capacity);
-            munmap(x->base, x->bytes); close(x->fd);
+        x->h->attached.fetch_add(1);
+        if (!shm_barrier(x)) { // everybody is attached: the name can go (the mappings stay)
+            if (rank != 0 && x->h->magic.load(std::memory_order_acquire) == SHM_DEAD && !late(120.0)) { unmap(); continue; } // it was a stale one after all
+            pnr::set_error("ranks did not all attach to %s (%u of %d did)", x->name.c_str(), x->h->attached.load(), world);
+            unmap();
+            if (x->owner) shm_unlink(x->name.c_str());
             delete x;
             return PNR_E_STATE;
         }
-    }
-    x->h->attached.fetch_add(1);
-    if (!shm_barrier(x)) { // everybody is attached: the name can go (the mappings stay)
-        pnr::set_error("ranks did not all attach to %s", x->name.c_str());
-        munmap(x->base, x->bytes); close(x->fd);
-        if (x->owner) shm_unlink(x->name.c_str());
-        delete x;
-        return PNR_E_STATE;
+        if (rank != 0 && x->h->magic.load(std::memory_order_acquire) != SHM_MAGIC) { unmap(); continue; } // (a dead segment whose old barrier count let us through)
+        break;
     }
     if (x->owner) shm_unlink(x->name.c_str());
     *out = x;

@@ -1082,7 +1082,11 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
     PhasedEngine eng(c);
     eng.split_x10 = c->opt.split_x10 > 0 ? c->opt.split_x10 : (std::min(std::max(1, o.groups), (int)pnr_phased::MAXG) > 1 ? 22 : 40);
     int rc = eng.init(window);
-    if (rc) { pnr::set_error("%s", eng.error()); return rc; }
+    if (rc) { // (the other ranks are about to enter their first exchange: tell them)
+        pnr::set_error("%s", eng.error());
+        if (n > 0) pnr::abort_exchange(sh, c->prm.ni);
+        return rc;
+    }
     pnr::SchedStats st;
     std::string err;
     rc = pnr::run_stream(eng, seeds, n, c->prm.ni, o, sh, r, &st, err);

@@ -69,6 +69,30 @@ public:
 
 namespace sched_detail {
 enum { HDR_WORDS = 4 }; // payload words, busy, abort, reserved
+enum { STALL_TURNS = 12 }; // synchronised turns without progress before every rank gives up -- a constant, so that ranks whose
+                           // window allows fewer trace groups (G is local: the stash budget differs per GPU) still stop in the same turn
+}
+
+// bytes every rank contributes to one exchange: a function of the options, the world and ni only -- the same on every rank
+inline int64_t exchange_block_bytes(int64_t block_opt, int world, int ni)
+{
+    using namespace sched_detail;
+    const size_t rec_max_words = 4 + (size_t)ni * 8;
+    int64_t block = block_opt > 0 ? block_opt : std::max<int64_t>(32768, 262144 / std::max(1, world)); // a rank's share of the finished traces shrinks with the world
+    block = std::max<int64_t>(block, (int64_t)(HDR_WORDS + rec_max_words) * 4);
+    return (block + 15) / 16 * 16;
+}
+
+// A rank that fails BEFORE its scheduler runs (engine set-up: out of memory, bad state) must still take part in the first
+// exchange the other ranks are about to enter, or they wait for it for ever: one block whose abort word is set.
+inline void abort_exchange(const ShardSpec &sh, int ni)
+{
+    using namespace sched_detail;
+    if (sh.world <= 1 || !sh.exchange) return;
+    const int64_t block = exchange_block_bytes(sh.block_bytes, sh.world, ni);
+    std::vector<int32_t> send((size_t)block / 4, 0), recv((size_t)block / 4 * (size_t)sh.world, 0);
+    send[2] = 1;
+    (void)sh.exchange(sh.user, send.data(), recv.data(), block);
 }
 
 // Returns 0 or a PNR_E_* code (message in `err`).  `r` ends up holding the node graph; *stats the local counters.
@@ -86,7 +110,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     if (o.look_pct < 0) o.look_pct = std::min(400, 50 * world);
     o.poll = std::max(1, o.poll);
     const int NT = E.slots() - (E.slots() & 1);
-    if (NT < 2) { err = "no trace slots"; return PNR_E_STATE; }
+    if (NT < 2) { err = "no trace slots"; abort_exchange(sh, ni); return PNR_E_STATE; }
     int G = std::min(std::max(1, o.groups), E.max_groups());
     if (NT < 4 * G) G = 1;
     const int64_t look0 = o.look0, look_pct = o.look_pct;
@@ -111,10 +135,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     // ---- records: [seed, dir (-1 = skipped), T, rows] + rows x 8 floats, as 32-bit words
     std::vector<int32_t> outbox; // finished on this rank, not yet applied / sent
     size_t out_head = 0;
-    const size_t rec_max_words = 4 + (size_t)ni * 8;
-    int64_t block = sh.block_bytes > 0 ? sh.block_bytes : std::max<int64_t>(32768, 262144 / world); // a rank's share of the finished traces shrinks with the world
-    block = std::max<int64_t>(block, (int64_t)(HDR_WORDS + rec_max_words) * 4);
-    block = (block + 15) / 16 * 16;
+    const int64_t block = exchange_block_bytes(sh.block_bytes, world, ni);
     const size_t block_words = (size_t)block / 4;
     std::vector<int32_t> sendbuf, recvbuf;
     if (world > 1) { sendbuf.assign(block_words, 0); recvbuf.assign(block_words * (size_t)world, 0); }
@@ -176,10 +197,11 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
         }
         return PNR_OK;
     };
-    // a failing rank tells the others in one last exchange, so that nobody is left waiting for it
+    // a failing rank tells the others in one last exchange, so that nobody is left waiting for it -- unless the run is over for
+    // everybody (the last exchange has brought the frontier to the end, or MAX_TRACE_COUNT): then nobody exchanges again
     auto fail = [&](int code) -> int {
         E.drain();
-        if (world > 1 && !aborted) { int b = 0, a = -1; std::string keep = err; (void)exchange(0, 1, &b, &a); err = keep; }
+        if (world > 1 && !aborted && frontier < n && !r.stopped) { int b = 0, a = -1; std::string keep = err; (void)exchange(0, 1, &b, &a); err = keep; }
         return code;
     };
 
@@ -298,7 +320,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             for (int k = 0; k < G; k++) any = any || grp[(size_t)k].inflight;
         }
         idle_turns = any ? 0 : idle_turns + 1;
-        if (idle_turns > 2 * G + 2) {
+        if (idle_turns > STALL_TURNS) {
             E.drain();
             err = "trace scheduler stalled at seed " + std::to_string((long long)frontier) + " of " + std::to_string((long long)n);
             return PNR_E_STATE; // every rank sees the same counters and stops in the same turn

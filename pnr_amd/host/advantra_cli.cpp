@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 
 int main(int argc, char **argv)
@@ -41,7 +42,10 @@ int main(int argc, char **argv)
     if (ranks <= 1) return advantra::advantra_func(infiles, paras, device, raw_dims) ? 0 : 1;
     if (ranks > 64) { fprintf(stderr, "--ranks: at most 64\n"); return 1; }
     // one process per GPU, forked here -- nothing has touched a GPU yet -- and joined through a shared-memory segment
-    const std::string name = "pnr_cli_" + std::to_string((long long)getpid());
+    // unique to this job, not only to this pid (a recycled pid must never meet the segment of a crashed earlier job)
+    struct timespec now;
+    clock_gettime(CLOCK_REALTIME, &now);
+    const std::string name = "pnr_cli_" + std::to_string((long long)getpid()) + "_" + std::to_string((long long)now.tv_sec) + "_" + std::to_string((long long)now.tv_nsec);
     std::vector<pid_t> kids;
     for (int r = 0; r < ranks; r++) {
         const pid_t pid = fork();

@@ -175,6 +175,95 @@ def test_failing_rank_aborts_the_others(workload):
     assert isinstance(out[1], lib.PnrError)
 
 
+@pytest.mark.parametrize("groups_bad", [1, 2])
+def test_rank_failing_before_its_scheduler_runs_aborts_the_others(workload, groups_bad):
+    """a rank whose engine cannot even be set up (on a GPU: no memory for the sample stash) never enters the scheduler -- it still
+    owes the others the exchange they are about to enter (one block with the abort word), or they would wait for ever.  The
+    surviving rank runs another number of trace groups than the failing one would have."""
+    from pnr_amd import lib, multigpu
+    W = workload
+    X = multigpu.ThreadExchange(2)
+    out = [None, None]
+    lookup = lambda q6: W["traces"][np.asarray(q6, np.float32).tobytes()]
+
+    def run(r):
+        try:
+            out[r] = lib.sched_playback(W["p"], W["img"].shape, W["seeds"], lookup, r, 2, X.callback(r), window=0 if r == 1 else 8, poll=1,
+                                        groups=groups_bad if r == 1 else 2)
+        except lib.PnrError as e:
+            out[r] = e
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    assert isinstance(out[1], lib.PnrError) and "window" in str(out[1])
+    assert isinstance(out[0], lib.PnrError) and "aborted" in str(out[0])
+
+
+def test_ranks_with_different_group_counts_end_together(workload):
+    """G is local (a rank whose window is smaller than 4 G slots falls back to one trace group): ranks with different G exchange
+    in lock step all the same and end with the same graph"""
+    from pnr_amd import lib, multigpu
+    W = workload
+    X = multigpu.ThreadExchange(2)
+    out = [None, None]
+    lookup = lambda q6: W["traces"][np.asarray(q6, np.float32).tobytes()]
+
+    def run(r):
+        try:
+            out[r] = lib.sched_playback(W["p"], W["img"].shape, W["seeds"], lookup, r, 2, X.callback(r), window=4 if r == 1 else 16, poll=2, groups=2)
+        except Exception as e:  # noqa: BLE001
+            out[r] = e
+            X.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    for r in range(2):
+        assert not isinstance(out[r], Exception), out[r]
+        assert _same_graph(out[r][0], out[r][1], W), f"rank {r}"
+
+
+def test_shm_exchange_survives_a_stale_segment_under_its_name():
+    """a crashed job's segment under the same name, found by a rank that arrives before rank 0: rank 0 marks it dead before it
+    removes the name, the early rank opens the name again, and the exchange works (pnr_shm_exchange_open)"""
+    import struct
+    import time
+    from pnr_amd import lib
+    name = f"pnr_stale_{os.getpid()}"
+    world, cap = 2, 4096
+    path = "/dev/shm/" + name
+    hdr = struct.pack("<IIQIIIIQ", 0x504e5258, world, cap, 0, 0, 1, 0, 1)  # magic, world, capacity, arrived, phase, attached, failed, stamp
+    with open(path, "wb") as f:
+        f.write(hdr.ljust(256, b"\0") + b"\xee" * (2 * world * cap))
+    out = [None, None]
+
+    def run(r):
+        try:
+            if r == 0:
+                time.sleep(0.5)  # rank 1 has attached to the stale segment by now
+            X = lib.ShmExchange(name, r, world, cap)
+            out[r] = X.allgather(bytes([65 + r]) * 7)
+            X.close()
+        except Exception as e:  # noqa: BLE001
+            out[r] = e
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=60)
+        assert not t.is_alive()
+    assert out[0] == out[1] == [b"A" * 7, b"B" * 7], out
+    assert not os.path.exists(path)  # the name is gone once everybody is attached
+
+
 def _shm_worker(rank, world, name, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
