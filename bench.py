@@ -19,9 +19,11 @@ global seed order: early DENSITY stops as on one GPU, every rank ends with the s
 `--mode stacks` is the replica mode: every rank owns an independent stack (weak scaling, no data-path
 collective, one final gather of the node graphs).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
-HIP-event time measured live on the kernel's stream), `roofline_smc_group` (the whole particle-filter
-kernel group), `roofline_frangi`, and `cpu_baseline` (oracle C restatement, 1 core, bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the whole particle
+evaluation: ph_predict + ph_sample + ph_sums + ph_update, HIP-event times measured live on the kernels'
+streams), `roofline_sample` / `roofline_sums` (its two halves alone), `roofline_frangi`,
+`full_trace_loop` (all sorted seeds until MAX_TRACE_COUNT, untimed extra) and `cpu_baseline` (oracle C
+restatement, 1 core, bounded sample).
 Scheduler options for experiments: PNR_BENCH_OPTS="groups=2,window=1024" (pnr_set_option keys).
 """
 import argparse
@@ -45,7 +47,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=1024, help="cubic stack edge (BASELINE configs[2]: 1024)")
-    ap.add_argument("--seeds", type=int, default=2000, help="sorted seeds traced per stack (configs[3]: 2000)")
+    ap.add_argument("--seeds", type=int, default=2000, help="sorted seeds traced per stack (configs[3]: 2000); 0 = ALL sorted seeds until MAX_TRACE_COUNT traces (the reference's full trace loop)")
     ap.add_argument("--np", type=int, default=200)
     ap.add_argument("--ni", type=int, default=200)
     ap.add_argument("--mode", choices=["shard", "stacks"], default="shard", help="N > 1: one stack sharded over the ranks (configs[3]) or one stack per rank")
@@ -254,7 +256,8 @@ def main():
             mine = ctx.score_filter(mine)  # znccBBB of this slab's seeds on the whole stack, threshold
             t2 = time.perf_counter()
             s0 = multigpu.gather_seeds(mine, dist, rank, world, coll_dev)
-            s = ctx.sort_seeds(s0)[:a.seeds]
+            s = ctx.sort_seeds(s0)
+            s = s[:a.seeds] if a.seeds > 0 else s
             t3 = time.perf_counter()
             nodes, links, ntr, iters = ctx.trace_replay_sharded(s, rank, world, exchange)
         else:
@@ -263,7 +266,8 @@ def main():
             s0 = ctx.extract_seeds()
             n_init = len(s0)
             t2 = time.perf_counter()
-            s = ctx.score_filter_sort(s0)[:a.seeds]
+            s = ctx.score_filter_sort(s0)
+            s = s[:a.seeds] if a.seeds > 0 else s
             t3 = time.perf_counter()
             if a.one_shot:
                 T, stop, xc, _ = ctx.trace_batch(s)
@@ -319,34 +323,44 @@ def main():
                 dist.destroy_process_group()
             return
         km = {g: ctx.kernel_ms(g) for g in ("gauss", "hessian_tile", "hessian_eigen", "j8", "seed_maxima", "zncc", "smc", "smc_sums", "smc_predict", "smc_update")}
-        # dominant kernel: the sampling kernel of the particle filter -- ph_sample (one launch per SMC step over all
-        # active traces; the "smc" timer group) with the phased driver, smc_trace (one launch per batch, sampling +
-        # sums + update) with the persistent one.  Algorithmic bytes: 8 corner bytes x sum(M_sigma)
-        # samples per particle evaluation, (np+1) evaluations per SMC iteration; ph_sample performs every one of them
-        # (rank 0's kernels and rank 0's iterations when the seeds are sharded).
-        kname = "ph_sample<54, false>" if a.driver == "phased" else "smc_trace"
+        # The dominant kernels are the particle evaluation of the SMC step (tracker.cpp:1891-1964 is ONE evaluation: the gather and
+        # the ordered ZNCC sums): ph_predict + ph_sample + ph_sums + ph_update with the phased driver (one launch of each per SMC
+        # step over all active traces), smc_trace with the persistent one.  Algorithmic bytes: 8 corner bytes x
+        # sum(M_sigma) samples per particle evaluation, (np + 1) evaluations per SMC iteration (rank 0's when the seeds are sharded).
+        # `roofline` prices the WHOLE evaluation: bytes of a step / duration of a step, where the duration is the summed device
+        # time of the step's four launches with one trace group, and the wall time of the tracing stage per step with several
+        # (their launches overlap on separate streams, so summed durations would count shared time twice).
         Mtot = sum(len(ctx.table(f"model_wgt{s}")) for s in range(len(sigs)))
-        smc_ms, smc_n = km["smc"]
-        smc_all_ms = sum(km[g][0] for g in ("smc", "smc_sums", "smc_predict", "smc_update"))
+        groups = ctx.get_option("groups")
+        EV = ("smc_predict", "smc", "smc_sums", "smc_update")
+        KNAME = {"smc_predict": "ph_predict", "smc": "ph_sample<54, false>", "smc_sums": "ph_sums", "smc_update": "ph_update"} if a.driver == "phased" else {"smc": "smc_trace"}
+        smc_n = km["smc"][1]
+        smc_all_ms = sum(km[g][0] for g in EV)
         evals = st["iters"] * (a.np + 1)
-        # several launches per step: bytes per launch / average launch duration = total bytes of the timed region / total device time
-        bytes_launch = 8.0 * Mtot * evals * a.steps / max(smc_n, 1)
-        achieved = bytes_launch / (smc_ms / max(smc_n, 1) * 1e-3) / 1e9 if smc_ms > 0 else 0.0
+        bytes_total = 8.0 * Mtot * evals * a.steps            # the timed region
+        steps_smc = max(smc_n, 1)                              # SMC steps (= launches of each kernel) in the timed region
+        tr_ms = st.get("trace_replay_gather_ms", st.get("trace_replay_exchange_ms"))
+        overlapped = groups > 1 and a.driver == "phased"
+        step_ms = (tr_ms * a.steps / steps_smc) if overlapped else (smc_all_ms / steps_smc)
+        achieved = bytes_total / steps_smc / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
         fr_ms = (km["gauss"][0] + km["hessian_tile"][0] + km["hessian_eigen"][0] + km["j8"][0]) / a.steps
         fr_vox = nvox if not shard else None  # a rank's slab + halo when sharded: no per-stack Frangi figure then
-        # HBM traffic per launch: PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, calibrated on
-        # a known byte count in the same access pattern: scripts/prof_traffic.sh), collected for THIS workload and
+        # HBM traffic per SMC step: PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, calibrated on a known
+        # byte count in the same access pattern: scripts/prof_traffic.sh), collected for THIS workload with one trace group and
         # committed under profiles/ -- read from that file, not measured in this run; null for any other workload
-        traffic, traffic_src = None, None
-        for cand in ("r02_traffic_1024_s2000.json", "r01h_traffic_1024_s2000.json"):
+        traffic, traffic_src, traffic_k = None, None, {}
+        for cand in ("r03_traffic_1024_s2000.json", "r02_traffic_1024_s2000.json"):
             tpath = os.path.join(ROOT, "profiles", cand if a.driver == "phased" else "r01_traffic_1024_s2000.json")
             if S == 1024 and a.seeds == 2000 and a.np == 200 and a.ni == 200 and not a.one_shot and world == 1 and os.path.exists(tpath):
-                tj = json.load(open(tpath)).get("smc_trace" if a.driver == "persistent" else "ph_sample", {})
-                if "FETCH_SIZE" in tj and "WRITE_SIZE" in tj:
-                    traffic = tj["FETCH_SIZE"]["bytes_per_launch"] + tj["WRITE_SIZE"]["bytes_per_launch"]
+                tj = json.load(open(tpath))
+                for key in (("ph_predict", "ph_sample", "ph_sums", "ph_update") if a.driver == "phased" else ("smc_trace",)):
+                    e = tj.get(key, {})
+                    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+                        traffic_k[key] = e["FETCH_SIZE"]["bytes_per_launch"] + e["WRITE_SIZE"]["bytes_per_launch"]
+                if ("ph_sample" in traffic_k and "ph_sums" in traffic_k) or "smc_trace" in traffic_k:
+                    traffic = sum(traffic_k.values())
                     traffic_src = "profiles/" + os.path.basename(tpath)
                     break
-        group_GBs = 8.0 * Mtot * evals * a.steps / (smc_all_ms * 1e-3) / 1e9 if smc_all_ms > 0 else None
         if world == 1:
             par = "1 GPU"
         elif shard:
@@ -355,82 +369,95 @@ def main():
                    "every rank replays in global seed order")
         else:
             par = f"{world} independent stacks, one per GPU; RCCL gather of node graphs"
+
+        def kernel_block(g, bytes_tot, note):  # one kernel of the evaluation against the bytes named in `note`
+            ms, n = km[g]
+            if ms <= 0 or n <= 0:
+                return None
+            gb = bytes_tot / (ms * 1e-3) / 1e9
+            return {"kernel": KNAME[g], "launches": n, "avg_launch_ms": ms / n, "bytes_per_launch": bytes_tot / n, "achieved": gb, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "share_of_evaluation_device_time": ms / smc_all_ms if smc_all_ms > 0 else None, "note": note}
+
+        stash_bytes = 2.0 * 4 * Mtot * stash_row_floats(a.np) * st["iters"] * a.steps
+        dominant = max((g for g in EV if g in KNAME), key=lambda g: km[g][0])  # by measured device time, not by hand
         out = {
             "metric": "Mvox/s traced (Frangi+SMC step) on 1024^3 synthetic stack; % HBM roofline" if S == 1024 else f"Mvox/s traced (Frangi+SMC step) on {S}^3 synthetic stack; % HBM roofline",
             "value": value, "unit": "Mvox/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak" if (world > 1 and a.mode == "stacks") else "strong", "vs_baseline": None,
             "dtype": "f32 (+f64 3x3 eigen-solver)", "data": "synthetic",
             "config": {"workload": f"{S}^3 synthetic u8 stack (tests/synth.py seed {stack_seed}), scales={{2,4,6}}, zdist=2, np={a.np}, ni={a.ni}, "
-                                   f"first {a.seeds} sorted seeds traced in both directions per stack, tolerance=5, znccth=0.3, step=2, kappa=3",
-                       "parallelism": par, "backend": backend if world > 1 else None, "record_exchange": exchange_kind, "options": opts or None},
-            "roofline": {"kernel": kname, "bound": "lds-gather/valu", "bytes_per_launch": bytes_launch, "avg_launch_ms": smc_ms / max(smc_n, 1), "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "note": "ALGORITHMIC gather bytes, 8*sum(M_sigma)=%d B per particle evaluation, over the launch time of the sampling kernel alone, "
-                                 "priced against the HBM peak as SURVEY 8(d) prescribes; the gather is served from the LDS cube (PMC: VALU issue ~80 %%, LDS "
-                                 "bank conflicts ~60 %% of LDS cycles), so the kernel is VALU / LDS-gather bound, not HBM bound; `traffic` (real HBM bytes per "
-                                 "launch, PMC) is read from the committed profile named in traffic_source, not measured in this run; the ordered sums of "
-                                 "the same evaluations are the separate kernel ph_sums -- roofline_smc_group prices the whole evaluation" % (8 * Mtot)},
-            "roofline_smc_group": None if smc_all_ms <= 0 else {
-                "kernels": "ph_predict+ph_sample+ph_sums+ph_update" if a.driver == "phased" else "smc_trace", "bound": "lds-gather/valu + hbm (stash)",
-                "achieved": group_GBs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": group_GBs / HBM_PEAK_GBS,
-                "device_ms_per_step": smc_all_ms / a.steps, "Mevals_per_s": evals * a.steps / smc_all_ms / 1e3,
-                "note": "SURVEY 8(d): 8*sum(M) algorithmic bytes x particle evaluations / device time of the whole SMC kernel group (t_smc)"},
+                                   + (f"first {a.seeds} sorted seeds" if a.seeds > 0 else "ALL sorted seeds until MAX_TRACE_COUNT = 5000 traces (the reference's full trace loop)")
+                                   + " traced in both directions per stack, tolerance=5, znccth=0.3, step=2, kappa=3",
+                       "parallelism": par, "backend": backend if world > 1 else None, "record_exchange": exchange_kind, "options": opts or None,
+                       "trace_groups": groups},
+            "roofline": {
+                "kernel": "+".join(KNAME[g] for g in EV if g in KNAME), "dominant_by_device_time": KNAME[dominant],
+                "bound": "hbm", "bound_detail": "priced against the HBM peak as SURVEY 8(d) prescribes; what binds is the LDS gather + VALU of ph_sample and the stash round trip (HBM) + serial f32 chains of ph_sums",
+                "bytes_per_launch": bytes_total / steps_smc, "avg_launch_ms": step_ms, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_per_kernel": traffic_k or None,
+                "launch": "one SMC step = one launch of each kernel over all active traces of a trace group",
+                "time_base": (f"wall time of the tracing stage / SMC steps ({groups} trace groups on separate streams: launches overlap, host replay and polls included)"
+                              if overlapped else "summed device time of the four launches of a step (HIP events on the launching stream)"),
+                "device_ms_per_stack": smc_all_ms / a.steps, "Mevals_per_s": bytes_total / (8.0 * Mtot) / (step_ms * steps_smc) / 1e3 if step_ms > 0 else None,
+                "note": "ALGORITHMIC bytes of the whole particle evaluation (znccBBB, tracker.cpp:1891-1964: gather AND ordered sums): 8*sum(M_sigma)=%d B per "
+                        "evaluation x (np+1) evaluations x the trace-iterations of a step, over the duration of the step; `traffic` = real HBM bytes per step (PMC, "
+                        "sum over the kernels) read from the committed profile named in traffic_source, not measured in this run" % (8 * Mtot)},
+            "roofline_sample": kernel_block("smc", bytes_total, "the gather half alone: the evaluation's algorithmic gather bytes over the sampling kernel's own launch time (served from the LDS cube: VALU / LDS bound, not HBM)"),
+            "roofline_sums": None if a.driver != "phased" else kernel_block("smc_sums", stash_bytes, "ordered sums alone against their REAL stash bytes: every stashed f32 sample is streamed twice (mean, then corr), 2 x 4 x sum(M) x %d B per SMC iteration -- an upper bound, exact duplicate poses are evaluated once" % stash_row_floats(a.np)),
             "roofline_frangi": None if not fr_vox or fr_ms <= 0 else {
                 "kernels": "gauss_x_u8_t+gauss_axis_t(y,z)+hessian_tile+eigen_queue+j8", "bound": "hbm", "achieved": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "device_ms_per_step": fr_ms,
                 "note": "(S+12) B/voxel compulsory bytes over the Frangi kernel group; VALU-bound: three Gaussian passes with separate multiply and add (the reference's rounding) and the Hessian stencil with its zero-response tests; the fp64 JAMA eigen-solver runs only where the response can reach J8 > 0"},
-            "roofline_sums": None if a.driver != "phased" or km["smc_sums"][0] <= 0 else {
-                "kernel": "ph_sums", "bound": "hbm", "launches": km["smc_sums"][1], "avg_launch_ms": km["smc_sums"][0] / max(km["smc_sums"][1], 1),
-                "achieved": 2.0 * 4 * Mtot * stash_row_floats(a.np) * st["iters"] * a.steps / (km["smc_sums"][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": 2.0 * 4 * Mtot * stash_row_floats(a.np) * st["iters"] * a.steps / (km["smc_sums"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "stash bytes of np + 1 chains: the ordered sums stream every stashed f32 sample twice (mean, then corr): 2 x 4 x sum(M) x %d B per SMC iteration; an upper bound since exact duplicate poses are evaluated once (PMC: 15 %% fewer bytes on this workload)" % stash_row_floats(a.np)},
             "stages_ms": {k: v for k, v in st.items() if k.endswith("_ms")},
             "kernel_ms_per_step": {g: km[g][0] / a.steps for g in km},
             "counts": {k: v for k, v in st.items() if not k.endswith("_ms")},
             "smc_launches_per_step": smc_n / a.steps,
             "Mvox_per_s_frangi": (nvox / (fr_ms * 1e-3) / 1e6) if (fr_vox and fr_ms > 0) else None,
         }
-        groups = ctx.get_option("groups")
-        out["config"]["trace_groups"] = groups
-        if groups > 1 and a.driver == "phased":
-            # launches of different trace groups overlap: a kernel's duration includes the time it shares the CUs, and the sum of the
-            # durations counts that time twice -- the group figure is taken over the wall time of the tracing stage instead
-            tr_ms = st.get("trace_replay_gather_ms", st.get("trace_replay_exchange_ms"))
-            g2 = 8.0 * Mtot * evals / (tr_ms * 1e-3) / 1e9
-            out["roofline_smc_group"].update(achieved=g2, frac=g2 / HBM_PEAK_GBS, device_ms_per_step=None, wall_ms_per_step=tr_ms, Mevals_per_s=evals / tr_ms / 1e3,
-                                             note=f"SURVEY 8(d): 8*sum(M) algorithmic bytes x particle evaluations / WALL time of the tracing stage (kernels of the {groups} trace "
-                                                  "groups overlap on their streams, host replay and polls included)")
-            out["roofline"]["note"] += (f"; {groups} trace groups: this kernel's launches overlap the other group's ph_sums / ph_predict / ph_update launches, so its average "
-                                        "duration includes shared time -- roofline_isolated is the same kernel with one trace group (untimed extra step)")
         if world == 1 and not shard and not a.one_shot and not a.no_extra:
-            s_all = ctx.score_filter_sort(ctx.extract_seeds())[:a.seeds]
-            if groups > 1 and a.driver == "phased":
-                # the same step with ONE trace group (launches never overlap): what each kernel needs alone
+            s_sorted = ctx.score_filter_sort(ctx.extract_seeds())
+            s_all = s_sorted[:a.seeds] if a.seeds > 0 else s_sorted
+            if overlapped:
+                # the same step with ONE trace group (launches never overlap): what each kernel needs alone, and the evaluation
+                # over summed device time -- what rocprofv3 --kernel-trace --stats shows with option groups=1
                 ctx.set_option("groups", 1)
                 ctx.reset_kernel_ms()
                 t0i = time.perf_counter()
                 _, _, _, it_iso = ctx.trace_replay(s_all)
                 t_iso = 1e3 * (time.perf_counter() - t0i)
                 ctx.set_option("groups", groups)
-                ki = {g: ctx.kernel_ms(g) for g in ("smc", "smc_sums", "smc_predict", "smc_update")}
+                ki = {g: ctx.kernel_ms(g) for g in EV}
                 ev_i = it_iso * (a.np + 1)
                 all_i = sum(v[0] for v in ki.values())
+                n_i = max(ki["smc"][1], 1)
                 out["roofline_isolated"] = {
-                    "kernel": kname, "bound": "lds-gather/valu", "launches": ki["smc"][1], "avg_launch_ms": ki["smc"][0] / max(ki["smc"][1], 1),
-                    "achieved": 8.0 * Mtot * ev_i / (ki["smc"][0] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * Mtot * ev_i / (ki["smc"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "smc_group_frac": 8.0 * Mtot * ev_i / (all_i * 1e-3) / 1e9 / HBM_PEAK_GBS, "smc_group_device_ms": all_i, "trace_wall_ms": t_iso,
-                    "sums_avg_launch_ms": ki["smc_sums"][0] / max(ki["smc_sums"][1], 1),
+                    "kernel": out["roofline"]["kernel"], "bound": "hbm", "launches": ki["smc"][1], "avg_launch_ms": all_i / n_i, "bytes_per_launch": 8.0 * Mtot * ev_i / n_i,
+                    "achieved": 8.0 * Mtot * ev_i / (all_i * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * Mtot * ev_i / (all_i * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "per_kernel_avg_launch_ms": {KNAME[g]: ki[g][0] / max(ki[g][1], 1) for g in EV}, "trace_wall_ms": t_iso,
+                    "sample_frac": 8.0 * Mtot * ev_i / (ki["smc"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "sums_GBs": 2.0 * 4 * Mtot * stash_row_floats(a.np) * it_iso / (ki["smc_sums"][0] * 1e-3) / 1e9,
-                    "note": "one trace group, same seeds, after the timed region: per-kernel durations without overlap (what rocprofv3 shows with option groups=1)"}
-            # the same kernel with every CU busy: ONE launch over all traces (outside the timed region)
-            ctx.reset_kernel_ms()
-            T1, _, _, _ = ctx.trace_batch(s_all)
-            ms1, n1 = ctx.kernel_ms("smc")
-            ev1 = int((T1 + (T1 < a.ni)).sum()) * (a.np + 1)
-            out["roofline_full_occupancy"] = {
-                "kernel": kname, "launches": n1, "avg_launch_ms": ms1 / max(n1, 1), "achieved": 8.0 * Mtot * ev1 / (ms1 * 1e-3) / 1e9,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * Mtot * ev1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "Mevals_per_s": ev1 / ms1 / 1e3,
-                "note": "all %d traces started together, traced to their map-free end (no early DENSITY stops): %d SMC iterations; measured after the timed region" % (len(T1), ev1 // (a.np + 1))}
+                    "note": "one trace group, same seeds, after the timed region: the whole evaluation over the summed device time of its four kernels (no overlap)"}
+            if a.seeds > 0:
+                # the same sampling kernel with every CU busy: ONE launch over all traces (outside the timed region)
+                ctx.reset_kernel_ms()
+                T1, _, _, _ = ctx.trace_batch(s_all)
+                ms1, n1 = ctx.kernel_ms("smc")
+                ev1 = int((T1 + (T1 < a.ni)).sum()) * (a.np + 1)
+                out["roofline_full_occupancy"] = {
+                    "kernel": KNAME["smc"], "launches": n1, "avg_launch_ms": ms1 / max(n1, 1), "achieved": 8.0 * Mtot * ev1 / (ms1 * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8.0 * Mtot * ev1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, "Mevals_per_s": ev1 / ms1 / 1e3,
+                    "note": "sampling kernel alone, all %d traces started together, traced to their map-free end (no early DENSITY stops): %d SMC iterations; measured after the timed region" % (len(T1), ev1 // (a.np + 1))}
+                # the reference's own trace loop (Advantra_plugin.cpp:2658-2710): EVERY sorted seed until MAX_TRACE_COUNT = 5000
+                # traces (:72, :2702) -- what a user of advantra_func sees; once, after the timed region
+                t0f = time.perf_counter()
+                nodes_f, _, ntr_f, it_f = ctx.trace_replay(s_sorted)
+                t_full = 1e3 * (time.perf_counter() - t0f)
+                front_ms = sum(v for k, v in st.items() if k in ("frangi_ms", "seeds_ms", "score_ms"))
+                out["full_trace_loop"] = {
+                    "seeds_sorted": len(s_sorted), "traces_used": int(ntr_f), "nodes": len(nodes_f) - 1, "smc_iterations": int(it_f), "trace_replay_ms": t_full,
+                    "step_ms": front_ms + t_full, "Mvox_per_s": nvox / ((front_ms + t_full) * 1e-3) / 1e6,
+                    "note": "all sorted seeds until MAX_TRACE_COUNT = 5000 traces are used (Advantra_plugin.cpp:72, 2702): the trace loop as the reference runs it; "
+                            "Frangi + seeds + scores of the timed region + this tracing; one run after the timed region (bench.py --seeds 0 times exactly this)"}
         if a.cpu_baseline != "off" and world == 1 and not shard:
             with heartbeat("cpu baseline (oracle, one host core)"):
                 out["cpu_baseline"] = cpu_baseline(img, list(sigs), zdist, a.np, a.ni, st, nvox, a.cpu_baseline)

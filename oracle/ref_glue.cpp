@@ -5,8 +5,12 @@
 // TEST INFRASTRUCTURE ONLY: used to validate oracle/pnr_oracle.c and to
 // generate tests/golden/*.npz (tests/golden/make_golden.py).  This file is our
 // own code; no reference source is copied -- the reference headers are found
-// through -I at build time, in this container only (/root/reference does not
-// exist on the GPU box; the prebuilt .so travels, the sources never do).
+// through -I at build time, in this container only.  Neither the reference's
+// sources nor this compiled library leave the container: the licence forbids
+// redistribution (pnr-vaa3d/LICENSE:4-5), oracle/_ref/ is listed in .gitignore
+// AND .gpurunignore, and the GPU-side tests run on the committed fixtures
+// (tests/golden/*.npz) that this library produced here (tests/orc.py:load_ref
+// returns None where it is absent).
 #include "frangi.h"
 #include "seed.h"
 #include <cstdint>

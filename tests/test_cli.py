@@ -3,6 +3,7 @@
 SWC as the Python mirror for a multi-page TIFF input."""
 import os
 import subprocess
+import sys
 import numpy as np
 import pytest
 import synth
@@ -10,6 +11,8 @@ import pnr_amd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "pnr_amd", "host", "advantra_cli")
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import swc_diff  # noqa: E402  -- the numeric SWC diff tool (ids / types / parents identical, x / y / z / r within 2e-3)
 
 
 def run(*args):
@@ -43,16 +46,24 @@ def test_cli_matches_python_pipeline(tmp_path):
     assert r.returncode == 0, r.stderr
     swc = tif + "_Advantra.swc"
     assert os.path.exists(swc)
-    rows = np.array([[float(v) for v in ln.split()] for ln in open(swc) if ln[0] != "#"])
     p = pnr_amd.make_params(sigmas=[2, 3], tolerance=5, znccth=0.3, kappa=3, step=2, ni=40, np_=50, zdist=2, nodepervol=4, vol=5)
     ctx = pnr_amd.Context(p, 0)
     res = pnr_amd.advantra.run_pipeline(ctx, img)
     ref = str(tmp_path / "ref.swc")
     pnr_amd.write_swc_tree(ref, res["tree"], res["parent"])
-    want = np.array([[float(v) for v in ln.split()] for ln in open(ref) if ln[0] != "#"])
-    assert rows.shape == want.shape and len(rows) > 50
-    assert np.array_equal(rows[:, [0, 1, 6]], want[:, [0, 1, 6]])  # ids, types, parents
-    assert np.allclose(rows[:, 2:6], want[:, 2:6], atol=2e-3)      # %.3f text
+    ok, msg = swc_diff.diff(swc, ref, tol=2e-3)
+    assert ok and len(swc_diff.read_swc(swc)[0]) > 50, msg
+    # the tool as a command: equal files -> 0, a moved node -> 1 with the first difference named
+    tool = [sys.executable, os.path.join(ROOT, "scripts", "swc_diff.py")]
+    assert subprocess.run(tool + [swc, ref], capture_output=True, text=True).returncode == 0
+    lines = open(ref).read().splitlines()
+    k = next(i for i, ln in enumerate(lines) if ln and ln[0] != "#") + 3
+    t = lines[k].split()
+    t[3] = f"{float(t[3]) + 0.5:.3f}"
+    moved = str(tmp_path / "moved.swc")
+    open(moved, "w").write("\n".join(lines[:k] + [" ".join(t)] + lines[k + 1:]) + "\n")
+    r2 = subprocess.run(tool + [swc, moved], capture_output=True, text=True)
+    assert r2.returncode == 1 and "y differs at node #3" in r2.stdout, r2.stdout
 
 
 @pytest.mark.gpu
@@ -73,16 +84,15 @@ def test_cli_soma_and_single_slice(tmp_path, case):
     assert r.returncode == 0, r.stderr
     if case == "soma":
         assert "soma regions" in r.stdout
-    rows = np.array([[float(v) for v in ln.split()] for ln in open(tif + "_Advantra.swc") if ln[0] != "#"])
     ctx = pnr_amd.Context(pnr_amd.make_params(sigmas=[2, 3], tolerance=5, znccth=0.3, kappa=3, step=2, zdist=2, nodepervol=4, **kw), 0)
     res = pnr_amd.advantra.run_pipeline(ctx, img)
     ref = str(tmp_path / "ref.swc")
     pnr_amd.write_swc_tree(ref, res["tree"], res["parent"])
-    want = np.array([[float(v) for v in ln.split()] for ln in open(ref) if ln[0] != "#"])
-    assert rows.shape == want.shape and len(rows) > 20
-    assert np.array_equal(rows[:, [0, 1, 6]], want[:, [0, 1, 6]]) and np.allclose(rows[:, 2:6], want[:, 2:6], atol=2e-3)
+    ok, msg = swc_diff.diff(tif + "_Advantra.swc", ref, tol=2e-3)
+    ids, types, _, _ = swc_diff.read_swc(tif + "_Advantra.swc")
+    assert ok and len(ids) > 20, msg
     if case == "soma":
-        assert (rows[:, 1] == 1).sum() >= 1  # a SOMA-typed node in the SWC
+        assert (types == 1).sum() >= 1  # a SOMA-typed node in the SWC
 
 
 def test_cli_rejects_malformed_tiff(tmp_path):

@@ -23,6 +23,25 @@ def test_gaussian_bit_exact(golden):
     assert np.array_equal(F, golden["F_sig0"])
 
 
+@pytest.mark.parametrize("w,sig", [(47, 4.0), (111, 4.0), (59, 8.0), (79, 2.0), (48, 4.0)])
+def test_gaussian_row_ends_on_exactly_sized_device_buffer(oracle, w, sig):
+    """widths at which the dword loads of the x pass's interior path end exactly at the row end (w % 32 = 15 for L = 12, 27 for
+    L = 24, ...): the volume is a caller-owned device buffer of exactly w*h*l bytes (pnr_set_volume_device) -- no byte past its
+    end may be read -- and F equals the oracle's"""
+    import torch
+    h, l = 9, 5
+    img = synth.synth(w, h, l, seed=9)
+    dev = torch.from_numpy(img.copy()).cuda()
+    assert dev.numel() == w * h * l
+    c = ctx_for([sig], 2.0)
+    c.set_volume_device(dev.data_ptr(), img.shape, keepalive=dev)
+    F = c.gaussian(sig)
+    want = np.empty(img.shape, np.float32)
+    oracle.orc_imgaussian3d(img, w, h, l, sig, 2.0, want)
+    assert np.array_equal(F, want)
+    c.close()
+
+
 def test_hessian_bit_exact(golden):
     c = ctx_for(golden["sigs"], float(golden["zdist"]))
     c.set_volume(golden["img"])

@@ -132,6 +132,97 @@ def test_front_half_in_8_slabs_at_bench_size():
     c.close()
 
 
+def test_sharded_trace_8_ranks_at_bench_size():
+    """BASELINE configs[3] at its real size: the 1024^3 bench stack, the first 2000 sorted seeds dealt to the 8 ranks of one node.
+    Rank 0 is the real thing -- its share of the seeds through pnr_trace_replay_sharded on the GPU -- and ranks 1..7 are host
+    threads that play the recorded map-free traces of their seeds through the same scheduler (pnr_sched_playback), all joined by
+    the library's shared-memory all-gather (what scripts/emulate_ranks.py measures).  Every rank must end with the one-GPU node
+    graph, and all ranks together with no more SMC iterations than tracing every seed to its map-free end
+    (the sequential semantics: Advantra_plugin.cpp:2658-2710, tracker.cpp:855,870-882)."""
+    import torch
+    S, world = 1024, 8
+    img = synth.synth_torch(S, S, S, seed=3)
+    p = pnr_amd.make_params(sigmas=[2.0, 4.0, 6.0], np_=200, ni=200, zdist=2.0)
+    c = pnr_amd.Context(p, 0)
+    shape = (S, S, S)
+    c.set_volume_device(img.data_ptr(), shape, keepalive=img)
+    c.frangi()
+    seeds = c.score_filter_sort(c.extract_seeds())[:2000]
+    assert len(seeds) == 2000
+    n1, l1, nt1, it1 = c.trace_replay(seeds)
+    assert len(n1) > 50000
+    T, stop, xc, _ = c.trace_batch(seeds)  # every trace to its map-free end: what the played-back ranks hold
+    free_iters = int((T + (T < p.ni)).sum())
+    assert it1 <= free_iters
+    xcf = np.ascontiguousarray(xc).view(np.float32).reshape(2 * len(seeds), p.ni, 8)
+    traces = {}
+    for i, sd in enumerate(seeds):
+        for d, sgn in enumerate((1.0, -1.0)):
+            q6 = np.array([sd["x"], sd["y"], sd["z"], sgn * sd["vx"], sgn * sd["vy"], sgn * sd["vz"]], np.float32)
+            traces[q6.tobytes()] = (int(T[2 * i + d]), xcf[2 * i + d])
+    lookup = lambda q6: traces[np.asarray(q6, np.float32).tobytes()]
+    name = f"pnr_t8_{os.getpid()}"
+    out, X = [None] * world, [None] * world
+
+    def run(r):
+        try:
+            X[r] = lib.ShmExchange(name, r, world, 1 << 20)
+            out[r] = c.trace_replay_sharded(seeds, 0, world, X[0]) if r == 0 else lib.sched_playback(p, shape, seeds, lookup, r, world, X[r], groups=2)
+        except Exception as e:  # noqa: BLE001
+            out[r] = e
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+        assert not t.is_alive()
+    for x in X:
+        if x is not None:
+            x.close()
+    for r in range(world):
+        assert not isinstance(out[r], Exception) and out[r] is not None, (r, out[r])
+        assert out[r][2] == nt1 and _graph_equal((out[r][0], out[r][1]), (n1, l1)), f"rank {r} of {world}"
+    assert sum(o[3] for o in out) <= free_iters
+    torch.cuda.synchronize()
+    c.close()
+
+
+def test_rank_without_memory_for_its_stash_aborts_the_others():
+    """a rank whose engine cannot be set up (stash budget of 1 MB: not one trace slot fits) fails before its scheduler runs; it still
+    sends the abort block (include/pnr_hip.h), so the other rank returns an error instead of waiting in its first exchange"""
+    img = synth.synth(96, 80, 40, seed=11)
+    p = pnr_amd.make_params(sigmas=[2.0, 3.0], np_=48, ni=40, zdist=2.0)
+    ctxs = []
+    for r in range(2):
+        c = pnr_amd.Context(p, 0)
+        c.set_smc_driver("phased")
+        c.set_volume(img)
+        ctxs.append(c)
+    ctxs[0].frangi()
+    seeds = ctxs[0].score_filter_sort(ctxs[0].extract_seeds())[:40]
+    ctxs[1].set_option("stash_mb", 1)
+    X = multigpu.ThreadExchange(2)
+    out = [None, None]
+
+    def run(r):
+        try:
+            out[r] = ctxs[r].trace_replay_sharded(seeds, r, 2, X.callback(r))
+        except lib.PnrError as e:
+            out[r] = e
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+        assert not t.is_alive()
+    assert isinstance(out[1], lib.PnrError) and "stash" in str(out[1]), out[1]
+    assert isinstance(out[0], lib.PnrError) and "aborted" in str(out[0]), out[0]
+    for c in ctxs:
+        c.close()
+
+
 def _bench(args, env_extra):
     env = dict(os.environ, **env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=900)
@@ -151,8 +242,9 @@ def test_bench_gpus_2_starts_two_ranks_and_matches_one_gpu():
     assert two["counts"]["nodes"] == one["counts"]["nodes"] > 50
     assert two["counts"]["n_seeds"] == one["counts"]["n_seeds"] and two["counts"]["n_seeds_init"] == one["counts"]["n_seeds_init"]
     assert two["counts"]["traces_used"] == one["counts"]["traces_used"]
-    for k in ("roofline", "roofline_smc_group"):
+    for k in ("roofline", "roofline_sample", "roofline_sums"):
         assert two[k]["frac"] > 0 and one[k]["frac"] > 0
+    assert one["roofline"]["kernel"] == "ph_predict+ph_sample<54, false>+ph_sums+ph_update" and one["roofline"]["dominant_by_device_time"] in one["roofline"]["kernel"]
 
 
 def test_exchange_callback_over_rccl_one_rank():

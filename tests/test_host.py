@@ -164,3 +164,27 @@ def test_reconstruct_degenerate_inputs():
     assert len(t3) == 1  # single-node trees are dropped by bfs2
     with pytest.raises(pnr_amd.PnrError, match="link index out of range"):
         lib.reconstruct(nodes, np.array([[1, 99]], np.int32))
+
+
+def test_swc_diff_tool(tmp_path):
+    """scripts/swc_diff.py: ids / types / parents exactly, x / y / z / r within the tolerance, first difference reported"""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import swc_diff
+    a = tmp_path / "a.swc"
+    b = tmp_path / "b.swc"
+    a.write_text("# name x\n#param=1\n1 2 1.000 2.000 3.000 1.500 -1\n2 2 2.000 2.500 3.000 1.500 1\n3 6 3.000 3.000 3.250 0.750 2\n")
+    b.write_text("#other header\n1 2 1.0004 2.000 3.000 1.5 -1\n2 2 2.000 2.5009 3.000 1.500 1\n\n3 6 3.000 3.000 3.250 0.75 2\n")
+    ok, msg = swc_diff.diff(str(a), str(b))
+    assert ok and "3 nodes" in msg, msg
+    assert not swc_diff.diff(str(a), str(b), tol=5e-4)[0]
+    b.write_text("1 2 1.0 2.0 3.0 1.5 -1\n2 2 2.0 2.5 3.0 1.5 1\n3 6 3.0 3.0 3.25 0.75 1\n")
+    ok, msg = swc_diff.diff(str(a), str(b))
+    assert not ok and "parent differs at node #2" in msg, msg
+    b.write_text("3 6 3.0 3.0 3.25 0.75 2\n1 2 1.0 2.0 3.0 1.5 -1\n2 2 2.0 2.5 3.0 1.5 1\n")
+    assert not swc_diff.diff(str(a), str(b))[0] and swc_diff.diff(str(a), str(b), unordered=True)[0]
+    tool = [sys.executable, os.path.join(ROOT, "scripts", "swc_diff.py")]
+    assert subprocess.run(tool + [str(a), str(b), "--unordered", "--quiet"]).returncode == 0
+    assert subprocess.run(tool + [str(a), str(b), "--quiet"]).returncode == 1
+    assert subprocess.run(tool + [str(a), str(tmp_path / "missing.swc")], capture_output=True).returncode == 2
