@@ -252,6 +252,7 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
         Box Bx;
         Bx.lds = (lds_cu8 *)cube;
         Bx.ox = sbox[6]; Bx.oy = sbox[7]; Bx.oz = sbox[8];
+        Bx.org = 0; // (only the FAST variants of the phased sampling kernel address the cube through it)
         { // stage the cube: one wave per (z,y) row, lanes along x (coalesced bytes), 4 rows in flight
             const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6;
             const int xg = Bx.ox + lane < V.w ? Bx.ox + lane : V.w - 1; // beyond the volume: never addressed, load anything valid

@@ -25,7 +25,18 @@ namespace {
 enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_IT = 3, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_FAST = 12, FL_NCH = 13, FL_N = 16 };
 constexpr int PH_THREADS = 1024; // sampling work-group: 16 waves (<= 128 VGPRs each)
 constexpr int PH_CS = 54; // the sampling kernel holds nothing but the cube in LDS: 54 x 54 rows of 56 bytes = 163 296 B of the 160 KB (53 costs 1.5 %)
-constexpr int PH_PITCH = 56; // row pitch: a multiple of 4, so that the dword granules of the LDS-DMA staging never straddle two rows
+constexpr int PH_PITCH = 56; // row pitch: a multiple of 4, so that every staged dword lands with one aligned ds_write_b32
+// Experiment build -DPNR_PH_W7=1 (make variant NAME=w7 DEFS=-DPNR_PH_W7=1): the rows as 7 overlapping 8-byte windows, corner pairs by
+// ds_read_b64 + v_perm_b32 (smc_device.h, interp_group_w7).  Bit-identical and the LDS bank-conflict cycles halve, but the kernel
+// gets SLOWER (dead end (o)): it is bound by VALU issue, and the window arithmetic costs 6 VALU per sample.  Default off.
+#ifndef PNR_PH_W7
+#define PNR_PH_W7 0
+#endif
+constexpr bool PH_W7 = PNR_PH_W7 != 0;
+constexpr int PH_CSX = PH_W7 ? W7_CSX : PH_CS;                                  // extent of the cube in x
+constexpr int PH_PLANE = PH_W7 ? PH_CS * PH_PITCH + 8 : PH_CS * PH_PITCH;       // plane pitch (W7: an odd number of windows)
+constexpr int PH_W7PLANE = PH_W7 ? PH_PLANE : 0;
+static_assert((size_t)PH_CS * PH_PLANE <= 160 * 1024, "the cube must fit the LDS of a CU");
 
 struct PhState {
     float *part;   // [NT][2][np][9]
@@ -60,7 +71,7 @@ __device__ __forceinline__ int last_group_stride(int rem) { return rem > 32 ? 64
 
 
 __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, const float *__restrict__ seeds6, Vol V, int np, int ni, int it_arg,
-                                                   int lp, int CS)
+                                                   int lp, int CS, int CSX)
 {
     const int tid = threadIdx.x, B = blockDim.x;
     if (blockIdx.x == 0 && tid == 0) P.cnt[lp ^ 1] = 0; // filled by ph_update of this step
@@ -154,8 +165,9 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
             int hi = sbox[3 + a] > dim[a] - 1 ? dim[a] - 1 : (sbox[3 + a] < lo ? lo : sbox[3 + a]);
             if (lo > dim[a] - 2) lo = dim[a] - 2 < 0 ? 0 : dim[a] - 2;
             if (hi < 1) hi = dim[a] - 1 < 1 ? dim[a] - 1 : 1;
-            int o = (lo + hi + 1) / 2 - CS / 2;
-            if (o > dim[a] - CS) o = dim[a] - CS;
+            const int csa = a == 0 ? CSX : CS; // (the cube is narrower in x: rows of 7-voxel windows)
+            int o = (lo + hi + 1) / 2 - csa / 2;
+            if (o > dim[a] - csa) o = dim[a] - csa;
             if (o < 0) o = 0;
             fl[FL_OX + a] = o;
             if (a > 0) { // rows of the cube that can be sampled at all: only those are staged
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
             }
             sbox[a] = o; // origin for the per-sigma test below
         }
-        sbox[7] = (1 << T.nsig) - 1;
+        sbox[7] = ((1 << T.nsig) - 1) * 0x101; // bits 0..7: inside cube and volume, bits 8..15: inside the volume
     }
     __syncthreads();
     // Per sigma: do ALL templates of this trace lie inside the cube and inside the volume?  Then the sampling kernel takes
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     {
         const int dim[3] = {V.w, V.h, V.l};
         const float hi_lim[3] = {V.xmax, V.ymax, V.zmax};
-        unsigned ok = (1u << T.nsig) - 1u;
+        unsigned ok = (1u << T.nsig) - 1u, okv = ok; // inside cube and volume | inside the volume
         for (int k = tid; k <= np; k += B) {
             const float *q;
             if (k == np) { if (pending < 0) continue; q = xc_pen; }
@@ -185,18 +197,21 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
             const float av[3] = {fabsf(q[3]), fabsf(q[4]), fabsf(q[5])};
             const float auw[3] = {fabsf(f.ux) + fabsf(f.wx), fabsf(f.uy) + fabsf(f.wy), fabsf(f.uz) + fabsf(f.wz)};
             for (int s = 0; s < T.nsig; s++) {
-                bool fit = true;
+                bool fit = true, fitv = true;
                 for (int a = 0; a < (V.l == 1 ? 2 : 3); a++) {
                     const float e = X.ext_vs[s] * av[a] + X.ext_uws[s] * auw[a] + 0.5f;
                     const float lo = q[a] - e, hi = q[a] + e;
                     // inside the volume: the clamp to [0, dim - 1.001] is the identity; inside the cube: (int)coord - origin <= CS - 2
-                    fit = fit && lo >= 0.f && hi <= hi_lim[a] && floorf(lo) >= (float)sbox[a] && floorf(hi) + 1.f <= (float)(sbox[a] + CS - 1);
+                    const bool inv = lo >= 0.f && hi <= hi_lim[a]; // (false for NaN poses)
+                    fitv = fitv && inv;
+                    fit = fit && inv && floorf(lo) >= (float)sbox[a] && floorf(hi) + 1.f <= (float)(sbox[a] + (a == 0 ? CSX : CS) - 1);
                 }
                 (void)dim;
                 if (!fit) ok &= ~(1u << s);
+                if (!fitv) okv &= ~(1u << s);
             }
         }
-        if (ok != (1u << T.nsig) - 1u) atomicAnd(&sbox[7], (int)ok);
+        if (ok != (1u << T.nsig) - 1u || okv != (1u << T.nsig) - 1u) atomicAnd(&sbox[7], (int)(ok | (okv << 8)));
     }
     __syncthreads();
     if (tid == 0) fl[FL_FAST] = sbox[7];
@@ -258,7 +273,12 @@ __device__ unsigned long long g_ph_stamps[8];
 #endif
 
 template <int CS, bool IS2D>
-__global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it_arg, int lp, int nslots)
+#if PNR_PH_W7
+#define PH_SAMPLE_ATTR __attribute__((amdgpu_waves_per_eu(5, 5))) // 96 VGPRs: a ph_sums wave must fit beside four sampling waves on a SIMD
+#else
+#define PH_SAMPLE_ATTR
+#endif
+__global__ __launch_bounds__(PH_THREADS) PH_SAMPLE_ATTR void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it_arg, int lp, int nslots)
 {
     extern __shared__ unsigned char cube[];
     // part-major: the first nslots work-groups are one per trace, the later ones join whatever is left of their trace
@@ -272,6 +292,7 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
     Box Bx;
     Bx.lds = (lds_cu8 *)cube;
     Bx.ox = fl[FL_OX]; Bx.oy = fl[FL_OY]; Bx.oz = fl[FL_OZ];
+    Bx.org = (unsigned)(Bx.oz * PH_PLANE + Bx.oy * PH_PITCH + Bx.ox);
 #ifdef PNR_SMC_STAMPS
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
     unsigned long long st_items = 0;
@@ -286,10 +307,11 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
       // count per load and four byte writes per dword.  The (plane, row) pair now advances incrementally, and the rows are
       // PH_PITCH = 56 bytes apart in LDS so that every dword lands with one aligned ds_write_b32 (the last dword of a row carries
       // two pad bytes).
-        static_assert(PH_PITCH % 4 == 0 && PH_PITCH >= CS && PH_PITCH <= 64, "one dword per lane, 16 lanes per row");
+        static_assert(PH_PITCH % 4 == 0 && PH_PITCH >= PH_CSX && PH_PITCH <= 64 && (!PH_W7 || PH_PITCH == 8 * W7_NWIN), "one dword per lane, 16 lanes per row");
         constexpr int NR = 16;
         typedef unsigned __attribute__((aligned(1))) u32u;
-        const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6, sub = lane >> 4, l4 = (lane & 15) * 4;
+        // dword d of a row holds the voxels x = 4 d .. 4 d + 3 (W7: half (d & 1) of window d >> 1 = the voxels 7 (d >> 1) + 4 (d & 1) .. + 3)
+        const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6, sub = lane >> 4, l4 = (lane & 15) * 4, sx = PH_W7 ? 7 * ((lane & 15) >> 1) + 4 * (lane & 1) : l4;
         const int y0 = fl[FL_Y0], ny = fl[FL_Y1] - y0, z0 = fl[FL_Z0], nrows = (fl[FL_Z1] - z0) * ny;
         const i64 nvox = V.wh * V.l;
         unsigned *const cube32 = (unsigned *)cube;
@@ -306,7 +328,7 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
                 ok[j] = r < nrows;
                 const int zz = z0 + (ok[j] ? zq : 0), yy = y0 + (ok[j] ? yr : 0);
                 const int zg = Bx.oz + zz < V.l ? Bx.oz + zz : V.l - 1, yg = Bx.oy + yy < V.h ? Bx.oy + yy : V.h - 1;
-                const i64 idx = (i64)zg * V.wh + (i64)yg * V.w + Bx.ox + l4;
+                const i64 idx = (i64)zg * V.wh + (i64)yg * V.w + Bx.ox + sx;
                 if (idx + 3 < nvox) {
                     v[j] = *(const u32u *)(V.img + idx);
                 } else { // the last bytes of the volume: byte loads, clamped (values past the row end are never addressed)
@@ -314,7 +336,7 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
 #pragma unroll
                     for (int q = 0; q < 4; q++) v[j] |= (unsigned)V.img[idx + q < nvox ? idx + q : nvox - 1] << (8 * q);
                 }
-                at[j] = ((zz * CS + yy) * PH_PITCH + l4) >> 2;
+                at[j] = (zz * PH_PLANE + yy * PH_PITCH + l4) >> 2;
                 r += stride; zq += sq; yr += sr;
                 if (yr >= ny) { yr -= ny; zq++; }
             }
@@ -330,7 +352,9 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
     const int nch = __builtin_amdgcn_readfirstlane(fl[FL_NCH]);
     const int ngf = nch >> 6, rem = nch & 63, Rt = last_group_stride(rem);
     const int *uidx = P.uidx + (i64)tr * P.np_pad;
-    const int fastmask = __builtin_amdgcn_readfirstlane(fl[FL_FAST]); // sigmas whose templates all lie inside the cube and the volume
+    const int fastword = __builtin_amdgcn_readfirstlane(fl[FL_FAST]);
+    const int fastmask = fastword & 0xff;        // sigmas whose templates all lie inside the cube and the volume
+    const int volmask = (fastword >> 8) & 0xff;  // sigmas whose templates all lie inside the volume (no clamp), whatever the cube holds
     // work items: a full group's item is ROWS template rows (iu) of one v-slice; the last group's chains are spread over the wave
     // `parts` times (sample_slice_packed) and its item is ROWS rounds of `parts` rows each
     constexpr int ROWS = 5;
@@ -381,16 +405,18 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
             const float *q = (k >= np) ? xc_pen : cur + k * PSTRIDE; // (the centroid before the first one exists: zeros, discarded)
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
             if (fastmask >> sI & 1)
-                sample_slice<CS, IS2D, true, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+                sample_slice<CS, IS2D, true, PH_PITCH, PH_W7PLANE>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+            else if (!PH_W7 && (volmask >> sI & 1))
+                sample_slice<CS, IS2D, false, PH_PITCH, PH_W7PLANE, true>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
             else
-                sample_slice<CS, IS2D, false, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+                sample_slice<CS, IS2D, false, PH_PITCH, PH_W7PLANE>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
         } else {
             const bool act = lane < parts * rem;
             const int pp = act ? lane / rem : 0, j = act ? lane - pp * rem : 0;
             const int k = uidx[ngf * 64 + j];
             const float *q = (k >= np) ? xc_pen : cur + k * PSTRIDE;
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
-            sample_slice_packed<CS, IS2D, false, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, parts, pp, act, sbase + (i64)ngf * Ms * 64 + j, Rt, r2 * ROWS, r2 * ROWS + ROWS);
+            sample_slice_packed<CS, IS2D, false, PH_PITCH, PH_W7PLANE>(V, Bx, f, nv, nu, nw, ax, iv, parts, pp, act, sbase + (i64)ngf * Ms * 64 + j, Rt, r2 * ROWS, r2 * ROWS + ROWS);
         }
     }
 #ifdef PNR_SMC_STAMPS
@@ -809,7 +835,7 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     PNR_HIP(hipGetDeviceProperties(&prop, c->device));
     E.ncu = prop.multiProcessorCount;
     E.np = np; E.ni = ni; E.S = S; E.np_pad = np_pad; E.ng = ngf + (rem > 0 ? 1 : 0); E.dbg_iters = dbg_iters;
-    E.cube_bytes = (size_t)PH_CS * PH_CS * PH_PITCH;
+    E.cube_bytes = (size_t)PH_CS * PH_PLANE;
     E.upd_lds = ((size_t)np * PSTRIDE + 4 * (size_t)np + (size_t)S * np_pad + 2 + 2 + 8) * 4;
     E.trace_floats = trace_floats;
     E.NT = NT;
@@ -878,7 +904,7 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
             }
             const int nsplit = pick_nsplit(active, ncu, max_split, c->opt.split_x10);
             c->tic(st);
-            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, T, X, P, (const float *)h->d_s6, V, np, ni, it, it & 1, CS);
+            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, T, X, P, (const float *)h->d_s6, V, np, ni, it, it & 1, CS, PH_CSX);
             c->toc("smc_predict", 1, st);
             c->tic(st);
             if (V.l == 1)
@@ -1015,7 +1041,7 @@ struct PhasedEngine final : pnr::StreamEngine {
             const int lp = q.lp;
             const int nsplit = pick_nsplit(active, E.ncu, E.max_split, split_x10);
             c->tic(st, k > 0); // (the first step of a poll follows the admission copies: its own opening event)
-            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
+            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS, PH_CSX);
             c->toc("smc_predict", 1, st);
             c->tic(st, true);
             if (E.V.l == 1)

@@ -79,6 +79,7 @@ def main():
     rng = np.random.default_rng(0)
     CS, PITCH = 54, 56
     PLANE = CS * PITCH
+    PLANE64 = PLANE + int(os.environ.get("SIM_PLANE_PAD", "0"))  # plane pitch of the window layout (multiple of 8)
     tot = {k: [0, 0] for k in ("P-u8", "P-b64", "S-u8", "S-b64")}
     for si in order:
         Tn, stop, xc, xf, idx, neff = T.trace(img, seeds[si, :6], max_dbg=12)
@@ -103,7 +104,8 @@ def main():
                                     tot["P-u8"][0] += wave_cycles_u8(row + c[:, 0] + dx)
                                     tot["P-u8"][1] += 1
                                 xw = np.minimum(c[:, 0], 48) // 7
-                                tot["P-b64"][0] += wave_cycles_b64(row + 8 * xw)
+                                row64 = (c[:, 2] + dz) * PLANE64 + (c[:, 1] + dy) * PITCH
+                                tot["P-b64"][0] += wave_cycles_b64(row64 + 8 * xw)
                                 tot["P-b64"][1] += 1
                 # ---- lane = sample: 64 consecutive samples of one particle
                 for p in rng.choice(len(P), 12, replace=False):
@@ -119,7 +121,8 @@ def main():
                                     tot["S-u8"][0] += wave_cycles_u8(row + c[:, 0] + dx)
                                     tot["S-u8"][1] += 1
                                 xw = np.minimum(c[:, 0], 48) // 7
-                                tot["S-b64"][0] += wave_cycles_b64(row + 8 * xw)
+                                row64 = (c[:, 2] + dz) * PLANE64 + (c[:, 1] + dy) * PITCH
+                                tot["S-b64"][0] += wave_cycles_b64(row64 + 8 * xw)
                                 tot["S-b64"][1] += 1
     print("layout   LDS cycles per wave-instruction   instructions per sample   LDS cycles per sample-wave")
     for k, (cyc, n) in tot.items():

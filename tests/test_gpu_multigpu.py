@@ -217,7 +217,7 @@ def test_rank_without_memory_for_its_stash_aborts_the_others():
     for t in th:
         t.join(timeout=120)
         assert not t.is_alive()
-    assert isinstance(out[1], lib.PnrError) and "stash" in str(out[1]), out[1]
+    assert isinstance(out[1], lib.PnrError) and "device memory" in str(out[1]), out[1]
     assert isinstance(out[0], lib.PnrError) and "aborted" in str(out[0]), out[0]
     for c in ctxs:
         c.close()
