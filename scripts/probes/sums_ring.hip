@@ -144,7 +144,10 @@ __device__ __forceinline__ float zncc_ring(const float *__restrict__ lane_base, 
             for (int i = 0; i < 8; i++) { ag += ring[b].q[i].x; ag += ring[b].q[i].y; ag += ring[b].q[i].z; ag += ring[b].q[i].w; }
         }
     }
-    // which ring slot holds chunk nfull (the partial one)?  slot = nfull % NB by construction; everything is waited for
+    // the loop's last prefetches are never summed: tie every buffer to a full wait, or a load that is still in flight lands in a
+    // register the compiler has already given to something else (this faulted in the library's first version)
+#pragma unroll
+    for (int b = 0; b < NB; b++) wait_for<0>(ring[b]);
     {
         Chunk &t = ring[0]; // (whatever is still in flight into the ring lands before the wait below returns)
         issue(t, lane_base, nchunk - 1);
@@ -183,6 +186,8 @@ __device__ __forceinline__ float zncc_ring(const float *__restrict__ lane_base, 
             }
         }
     }
+#pragma unroll
+    for (int b = 0; b < NB; b++) wait_for<0>(ring[b]);
     {
         Chunk &t = ring[0];
         issue(t, lane_base, nchunk - 1);
