@@ -193,7 +193,8 @@ void pnr_destroy(pnr_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     pnr_job_destroy(c->job);
     pnr_phased_destroy(c->phased);
-    if (c->h_j8) hipHostFree(c->h_j8);
+    if (c->h_j8) (void)hipHostFree(c->h_j8);
+    if (c->h_j8v) (void)hipHostFree(c->h_j8v);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (int k = 0; k < pnr_ctx::J8_CHUNKS; k++)
         if (c->j8_ev[k]) (void)hipEventDestroy(c->j8_ev[k]);

@@ -147,8 +147,8 @@ struct pnr_ctx {
     bool have_soma = false;
 
     // seeds
-    unsigned char *h_j8 = nullptr; // pinned staging buffer for the J8 download
-    size_t h_j8_cap = 0;
+    unsigned char *h_j8 = nullptr, *h_j8v = nullptr; // pinned staging of the sparse J8 hand-over to the flood fill: bitmap | values (seeds.hip)
+    size_t h_j8_cap = 0, h_j8v_cap = 0;
     static constexpr int J8_CHUNKS = 16;   // the download is cut into chunks of layers so that the flood fill starts on the first ones
     hipStream_t copy_stream = nullptr;
     hipEvent_t j8_ev[J8_CHUNKS] = {}, j8_start = nullptr;

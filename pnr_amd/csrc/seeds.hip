@@ -66,23 +66,58 @@ __global__ __launch_bounds__(256) void layer_minmax(const unsigned char *__restr
     }
 }
 
-// COUNT pass: counts per layer.  WRITE pass: keys into [off[zl], off[zl+1]).
+// COUNT pass: candidate counts per layer; and, for the host's flood fill, which pixels lie above their layer's minimum -- one bit
+// per pixel (a 64-pixel word per wavefront) and their number per row.  WRITE pass: keys into [off[zl], off[zl+1]); the values of
+// those pixels, in raster order, into [voff[zl] + rowoff[row] ...).  The host rebuilds a layer from the bits and the values
+// (everything else IS the layer's minimum): 1 bit per pixel + 1 byte per pixel above the minimum cross PCIe instead of the whole
+// J8 volume (174 MB instead of 1 GiB on the bench stack, 95.7 % of which is the minimum).
+struct SparseJ8 {
+    unsigned long long *bitmap; // [row][wpr] words, row = zl * h + y
+    unsigned int *rowcnt;       // [row] pixels above the layer minimum (COUNT pass, atomics of the row's waves)
+    const unsigned int *rowoff; // [row] exclusive prefix of rowcnt inside the layer (row_scan)
+    const i64 *voff;            // [zl] first value of the layer
+    unsigned char *vals;
+    int wpr;                    // 64-pixel words per row
+};
+
 template <bool WRITE>
 __global__ __launch_bounds__(256) void layer_maxima(const unsigned char *__restrict__ J8, int w, int h, int z0, int tiles_x,
                                                      const int *__restrict__ vmin, const float *__restrict__ vfactor,
                                                      unsigned int *__restrict__ count, const i64 *__restrict__ off,
-                                                     i64 *__restrict__ keys)
+                                                     i64 *__restrict__ keys, SparseJ8 SP)
 {
     i64 b = blockIdx.x;
     const int x = (int)(b % tiles_x) * 256 + threadIdx.x;
     b /= tiles_x;
     const int y = (int)(b % h);
     const int zl = (int)(b / h);
-    if (x <= 0 || x >= w - 1 || y <= 0 || y >= h - 1) return; // border pixels are never maxima (seed.cpp:595)
     const unsigned char *L = J8 + (i64)(z0 + zl) * w * h;
     const int p = y * w + x;
-    const int v = L[p];
-    if (v == vmin[zl]) return; // seed.cpp:594
+    const int lmin = vmin[zl];
+    const int v = x < w ? (int)L[p] : lmin;
+    { // the sparse hand-over: every wavefront covers 64 consecutive pixels of one row
+        const unsigned long long above = __builtin_amdgcn_ballot_w64(v > lmin);
+        const int lane = threadIdx.x & 63, word = x >> 6; // (wave-uniform)
+        const i64 row = (i64)zl * h + y;
+        if ((x & ~63) < w) {
+            if (!WRITE) {
+                if (lane == 0) {
+                    SP.bitmap[row * SP.wpr + word] = above;
+                    if (above) atomicAdd(&SP.rowcnt[row], (unsigned int)__builtin_popcountll(above));
+                }
+            } else if (above) {
+                // pixels of the row in front of this word: the popcounts of the row's earlier words (at most a few dozen)
+                unsigned int before = 0;
+                for (int k = lane; k < word; k += 64) before += (unsigned int)__builtin_popcountll(SP.bitmap[row * SP.wpr + k]);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+                if (v > lmin)
+                    SP.vals[SP.voff[zl] + SP.rowoff[row] + before + (unsigned int)__builtin_popcountll(above & ((1ull << lane) - 1ull))] = (unsigned char)v;
+            }
+        }
+    }
+    if (x <= 0 || x >= w - 1 || y <= 0 || y >= h - 1) return; // border pixels are never maxima (seed.cpp:595)
+    if (v == lmin) return; // seed.cpp:594
     const unsigned char *r0 = L + p - w, *r2 = L + p + w;
     const int m = max(max(max((int)r0[-1], (int)r0[0]), max((int)r0[1], (int)L[p - 1])),
                       max(max((int)L[p + 1], (int)r2[-1]), max((int)r2[0], (int)r2[1])));
@@ -91,11 +126,41 @@ __global__ __launch_bounds__(256) void layer_maxima(const unsigned char *__restr
         atomicAdd(&count[zl], 1u);
     } else {
         // seed.cpp:616,626: iValue = (int)((fValue - globalMin) * vFactor), f32 arithmetic
-        const float fValue = (float)v, gmin = (float)vmin[zl];
+        const float fValue = (float)v, gmin = (float)lmin;
         const int iValue = (int)((fValue - gmin) * vfactor[zl]);
         const unsigned int slot = atomicAdd(&count[zl], 1u);
         keys[off[zl] + slot] = (i64)(((unsigned long long)(i64)iValue << 32) | (unsigned int)p);
     }
+}
+
+// exclusive prefix of the row counts inside every layer (one work-group per layer) and the layer totals
+__global__ __launch_bounds__(256) void row_scan(const unsigned int *__restrict__ rowcnt, int h, unsigned int *__restrict__ rowoff,
+                                                 unsigned int *__restrict__ layer_total)
+{
+    __shared__ unsigned int wsum[4];
+    __shared__ unsigned int carry;
+    const int zl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int y0 = 0; y0 < h; y0 += 256) {
+        const int y = y0 + tid;
+        const unsigned int c = y < h ? rowcnt[(i64)zl * h + y] : 0u;
+        unsigned int incl = c; // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        unsigned int base = carry;
+        for (int k = 0; k < wv; k++) base += wsum[k];
+        if (y < h) rowoff[(i64)zl * h + y] = base + incl - c;
+        __syncthreads();
+        if (tid == 255) carry = base + incl;
+        __syncthreads();
+    }
+    if (tid == 0) layer_total[zl] = carry;
 }
 
 __global__ void gather_dirs(const unsigned char *__restrict__ Vx, const unsigned char *__restrict__ Vy,
@@ -117,7 +182,43 @@ struct LayerFinder {
     int w, h;
     std::vector<unsigned char> flags;
     std::vector<int> list;
-    LayerFinder(int w_, int h_) : w(w_), h(h_), flags((size_t)w_ * h_ + 8), list((size_t)w_ * h_) {}
+    std::vector<unsigned char> img; // the layer, rebuilt from the sparse hand-over: the layer's minimum everywhere but at the set bits
+    int img_fill = -1;
+    LayerFinder(int w_, int h_) : w(w_), h(h_), flags((size_t)w_ * h_ + 8), list((size_t)w_ * h_), img((size_t)w_ * h_) {}
+
+    // bits: [h][wpr] words; vals: the values of the set bits in raster order.  restore() puts the minimum back at exactly those pixels.
+    const unsigned char *load(const unsigned long long *bits, int wpr, const unsigned char *vals, int layer_min)
+    {
+        if (img_fill != layer_min) { std::memset(img.data(), layer_min, img.size()); img_fill = layer_min; }
+        for (int y = 0; y < h; y++) {
+            unsigned char *row = img.data() + (size_t)y * w;
+            const unsigned long long *bw = bits + (size_t)y * wpr;
+            for (int k = 0; k < wpr; k++) {
+                unsigned long long m = bw[k];
+                while (m) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    row[k * 64 + bit] = *vals++;
+                }
+            }
+        }
+        return img.data();
+    }
+    void restore(const unsigned long long *bits, int wpr)
+    {
+        for (int y = 0; y < h; y++) {
+            unsigned char *row = img.data() + (size_t)y * w;
+            const unsigned long long *bw = bits + (size_t)y * wpr;
+            for (int k = 0; k < wpr; k++) {
+                unsigned long long m = bw[k];
+                while (m) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    row[k * 64 + bit] = (unsigned char)img_fill;
+                }
+            }
+        }
+    }
 
     static inline bool inside(int x, int y, int d, int w, int h)
     {
@@ -245,78 +346,107 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     const i64 wh = (i64)w * h;
 
     int *d_min = nullptr, *d_max = nullptr;
-    unsigned int *d_cnt = nullptr;
+    unsigned int *d_cnt = nullptr, *d_rowcnt = nullptr, *d_rowoff = nullptr, *d_ltot = nullptr;
+    unsigned long long *d_bits = nullptr;
+    unsigned char *d_vals = nullptr;
     float *d_vf = nullptr;
-    i64 *d_off = nullptr, *d_keys = nullptr;
+    i64 *d_off = nullptr, *d_voff = nullptr, *d_keys = nullptr;
+    const int wpr = (w + 63) / 64; // 64-pixel bitmap words per row
+    const size_t nrows = (size_t)nl * h, nwords = nrows * (size_t)wpr;
     int rc = c->scratch_get("seed_min", (size_t)nl, &d_min); // context-owned scratch, sized by the first pass
     if (!rc) rc = c->scratch_get("seed_max", (size_t)nl, &d_max);
     if (!rc) rc = c->scratch_get("seed_cnt", (size_t)nl, &d_cnt);
     if (!rc) rc = c->scratch_get("seed_vf", (size_t)nl, &d_vf);
     if (!rc) rc = c->scratch_get("seed_off", (size_t)nl + 1, &d_off);
+    if (!rc) rc = c->scratch_get("seed_voff", (size_t)nl + 1, &d_voff);
+    if (!rc) rc = c->scratch_get("seed_ltot", (size_t)nl, &d_ltot);
+    if (!rc) rc = c->scratch_get("seed_rowcnt", nrows, &d_rowcnt);
+    if (!rc) rc = c->scratch_get("seed_rowoff", nrows, &d_rowoff);
+    if (!rc) rc = c->scratch_get("seed_bits", nwords, &d_bits);
     if (rc) return rc;
     std::vector<int> vmin(nl), vmax(nl);
-    std::vector<unsigned int> cnt(nl);
+    std::vector<unsigned int> cnt(nl), ltot(nl);
     std::vector<float> vf(nl);
-    std::vector<i64> off(nl + 1, 0);
+    std::vector<i64> off(nl + 1, 0), voff(nl + 1, 0);
 
-    // start the J8 download for the host flood-fill while the kernels run
-    if (c->h_j8_cap < (size_t)(wh * nl)) { // pinned staging buffer, kept across calls (allocating 1 GiB of pinned memory costs ~50 ms)
-        if (c->h_j8) hipHostFree(c->h_j8);
-        c->h_j8 = nullptr;
-        c->h_j8_cap = 0;
-        PNR_HIP(hipHostMalloc(&c->h_j8, (size_t)(wh * nl), hipHostMallocDefault));
-        c->h_j8_cap = (size_t)(wh * nl);
-    }
-    unsigned char *h_j8 = c->h_j8;
-    // ... on a second stream, in chunks of layers with an event each: the kernels below run beside it, and the fill of a layer
-    // only waits for its own chunk (1 GiB takes 20 ms over PCIe, the fill of the first layers starts after ~6 ms)
+    // The host's flood fill gets J8 in sparse form: one bit per pixel (above its layer's minimum or not) and the values of the
+    // set pixels in raster order -- on a second stream, in chunks of layers with an event each, so that the fill of a layer only
+    // waits for its own chunk.  Pinned staging buffers are kept across calls (allocating pinned memory costs ~50 ms per GiB).
     constexpr int NCH = pnr_ctx::J8_CHUNKS;
     if (!c->copy_stream) {
         PNR_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         PNR_HIP(hipEventCreateWithFlags(&c->j8_start, hipEventDisableTiming));
         for (int k = 0; k < NCH; k++) PNR_HIP(hipEventCreateWithFlags(&c->j8_ev[k], hipEventDisableTiming));
     }
+    auto pinned = [&](unsigned char *&buf, size_t &cap, size_t need) -> int {
+        if (cap >= need) return PNR_OK;
+        if (buf) (void)hipHostFree(buf);
+        buf = nullptr; cap = 0;
+        need += need / 4 + 4096; // (the value count changes a little from stack to stack)
+        PNR_HIP(hipHostMalloc(&buf, need, hipHostMallocDefault));
+        cap = need;
+        return PNR_OK;
+    };
+    rc = pinned(c->h_j8, c->h_j8_cap, nwords * 8);
+    if (rc) return rc;
+    const unsigned long long *h_bits = (const unsigned long long *)c->h_j8;
     const int per_chunk = (nl + NCH - 1) / NCH;
-    PNR_HIP(hipEventRecord(c->j8_start, c->stream)); // J8 is complete at this point of the context's stream
-    PNR_HIP(hipStreamWaitEvent(c->copy_stream, c->j8_start, 0));
-    for (int k = 0; k < NCH; k++) {
-        const int l0 = k * per_chunk, l1 = std::min(nl, l0 + per_chunk);
-        if (l0 < l1)
-            PNR_HIP(hipMemcpyAsync(h_j8 + (size_t)l0 * wh, c->d_J8 + (z0 + l0) * wh, (size_t)(l1 - l0) * wh, hipMemcpyDeviceToHost, c->copy_stream));
-        PNR_HIP(hipEventRecord(c->j8_ev[k], c->copy_stream));
-    }
 
     c->tic();
     PNR_HIP(hipMemsetAsync(d_min, 0x7f, nl * 4, c->stream));
     PNR_HIP(hipMemsetAsync(d_max, 0, nl * 4, c->stream));
     hipLaunchKernelGGL(layer_minmax, dim3(nl * LM_PARTS), dim3(256), 0, c->stream, c->d_J8, wh, (int)z0, d_min, d_max);
     PNR_HIP(hipMemsetAsync(d_cnt, 0, nl * 4, c->stream));
+    PNR_HIP(hipMemsetAsync(d_rowcnt, 0, nrows * 4, c->stream));
     const int tiles_x = (w + 255) / 256;
     const unsigned nblk = (unsigned)((i64)tiles_x * h * nl);
+    SparseJ8 SP{d_bits, d_rowcnt, d_rowoff, d_voff, nullptr, wpr};
     hipLaunchKernelGGL(layer_maxima<false>, dim3(nblk), dim3(256), 0, c->stream, c->d_J8, w, h, (int)z0, tiles_x, d_min,
-                       (const float *)nullptr, d_cnt, (const i64 *)nullptr, (i64 *)nullptr);
-    c->toc("seed_maxima", 2);
+                       (const float *)nullptr, d_cnt, (const i64 *)nullptr, (i64 *)nullptr, SP);
+    hipLaunchKernelGGL(row_scan, dim3(nl), dim3(256), 0, c->stream, (const unsigned int *)d_rowcnt, h, d_rowoff, d_ltot);
+    c->toc("seed_maxima", 3);
     PNR_HIP(hipMemcpyAsync(vmin.data(), d_min, nl * 4, hipMemcpyDeviceToHost, c->stream));
     PNR_HIP(hipMemcpyAsync(vmax.data(), d_max, nl * 4, hipMemcpyDeviceToHost, c->stream));
     PNR_HIP(hipMemcpyAsync(cnt.data(), d_cnt, nl * 4, hipMemcpyDeviceToHost, c->stream));
+    PNR_HIP(hipMemcpyAsync(ltot.data(), d_ltot, nl * 4, hipMemcpyDeviceToHost, c->stream));
+    // the bitmap is complete: its download (1 bit per pixel) starts now, beside the second pass
+    PNR_HIP(hipEventRecord(c->j8_start, c->stream));
+    PNR_HIP(hipStreamWaitEvent(c->copy_stream, c->j8_start, 0));
+    PNR_HIP(hipMemcpyAsync(c->h_j8, d_bits, nwords * 8, hipMemcpyDeviceToHost, c->copy_stream));
     PNR_HIP(hipStreamSynchronize(c->stream));
     for (int k = 0; k < nl; k++) {
         off[k + 1] = off[k] + cnt[k];
+        voff[k + 1] = voff[k] + ltot[k];
         vf[k] = (float)(2e9 / ((float)vmax[k] - (float)vmin[k])); // seed.cpp:616 (inf on flat layers: no maxima there)
     }
-    const i64 total = off[nl];
+    const i64 total = off[nl], nvals = voff[nl];
     std::vector<i64> keys((size_t)total);
-    if (total > 0) {
+    rc = pinned(c->h_j8v, c->h_j8v_cap, (size_t)std::max<i64>(nvals, 1));
+    if (rc) return rc;
+    const unsigned char *h_vals = c->h_j8v;
+    if (total > 0) { // (no candidate anywhere: nothing to fill, nothing to hand over)
         rc = c->scratch_get("seed_keys", (size_t)total, &d_keys);
+        if (!rc) rc = c->scratch_get("seed_vals", (size_t)std::max<i64>(nvals, 1), &d_vals);
         if (rc) return rc;
+        SP.vals = d_vals;
         PNR_HIP(hipMemcpyAsync(d_off, off.data(), (nl + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        PNR_HIP(hipMemcpyAsync(d_voff, voff.data(), (nl + 1) * 8, hipMemcpyHostToDevice, c->stream));
         PNR_HIP(hipMemcpyAsync(d_vf, vf.data(), nl * 4, hipMemcpyHostToDevice, c->stream));
         PNR_HIP(hipMemsetAsync(d_cnt, 0, nl * 4, c->stream));
         c->tic();
         hipLaunchKernelGGL(layer_maxima<true>, dim3(nblk), dim3(256), 0, c->stream, c->d_J8, w, h, (int)z0, tiles_x, d_min,
-                           d_vf, d_cnt, d_off, d_keys);
+                           d_vf, d_cnt, d_off, d_keys, SP);
         c->toc("seed_maxima", 1);
         PNR_HIP(hipMemcpyAsync(keys.data(), d_keys, (size_t)total * 8, hipMemcpyDeviceToHost, c->stream));
+        // the values follow the bitmap on the copy stream, in chunks of layers
+        PNR_HIP(hipEventRecord(c->j8_start, c->stream));
+        PNR_HIP(hipStreamWaitEvent(c->copy_stream, c->j8_start, 0));
+        for (int k = 0; k < NCH; k++) {
+            const int l0 = std::min(nl, k * per_chunk), l1 = std::min(nl, l0 + per_chunk);
+            if (voff[l1] > voff[l0])
+                PNR_HIP(hipMemcpyAsync(c->h_j8v + voff[l0], d_vals + voff[l0], (size_t)(voff[l1] - voff[l0]), hipMemcpyDeviceToHost, c->copy_stream));
+            PNR_HIP(hipEventRecord(c->j8_ev[k], c->copy_stream));
+        }
     }
     PNR_HIP(hipGetLastError());
     PNR_HIP(hipStreamSynchronize(c->stream));
@@ -335,10 +465,13 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
                 const int k = next.fetch_add(1);
                 if (k >= nl) break;
                 if (cnt[k] == 0) continue;
-                (void)hipEventSynchronize(c->j8_ev[k / per_chunk]); // this layer's bytes have arrived
                 i64 *kb = keys.data() + off[k];
                 std::sort(kb, kb + cnt[k]); // unique keys: order fully defined (seed.cpp:632)
-                lf.run(h_j8 + (size_t)k * wh, kb, cnt[k], tol, vmin[k], acc[k]);
+                (void)hipEventSynchronize(c->j8_ev[k / per_chunk]); // this layer's bits and values have arrived
+                const unsigned long long *lb = h_bits + (size_t)k * h * wpr;
+                const unsigned char *L8 = lf.load(lb, wpr, h_vals + voff[k], vmin[k]);
+                lf.run(L8, kb, cnt[k], tol, vmin[k], acc[k]);
+                lf.restore(lb, wpr);
             }
         };
         std::vector<std::thread> th;
