@@ -67,17 +67,21 @@ __global__ __launch_bounds__(256) void layer_minmax(const unsigned char *__restr
 }
 
 // COUNT pass: candidate counts per layer; and, for the host's flood fill, which pixels lie above their layer's minimum -- one bit
-// per pixel (a 64-pixel word per wavefront) and their number per row.  WRITE pass: keys into [off[zl], off[zl+1]); the values of
-// those pixels, in raster order, into [voff[zl] + rowoff[row] ...).  The host rebuilds a layer from the bits and the values
-// (everything else IS the layer's minimum): 1 bit per pixel + 1 byte per pixel above the minimum cross PCIe instead of the whole
-// J8 volume (174 MB instead of 1 GiB on the bench stack, 95.7 % of which is the minimum).
+// per pixel and their number per row.  WRITE pass: keys into [off[zl], off[zl+1]); the values of those pixels into
+// [voff[zl] + rowoff[row] ...).  The host rebuilds a layer from the bits and the values (everything else IS the layer's minimum):
+// 1 bit per pixel + 1 byte per pixel above the minimum cross PCIe instead of the whole J8 volume (174 MB instead of 1 GiB on the
+// bench stack, 95.7 % of which is the minimum).
+// A wavefront covers 256 consecutive pixels of a row, four per lane (one dword load); its four bitmap words are the ballots of
+// the four byte positions: bit l of word b <-> pixel 256 * wt + 4 * l + b.  The values follow in (row, wave tile, b, bit) order --
+// any fixed order serves, the host scatters them back by the same rule.  The WRITE pass is driven by the bitmap: a wavefront
+// whose four words are zero (nine in ten on the bench stack) touches no pixel at all.
 struct SparseJ8 {
-    unsigned long long *bitmap; // [row][wpr] words, row = zl * h + y
+    unsigned long long *bitmap; // [row][wpr] words, row = zl * h + y, wpr = 4 * ceil(w / 256)
     unsigned int *rowcnt;       // [row] pixels above the layer minimum (COUNT pass, atomics of the row's waves)
     const unsigned int *rowoff; // [row] exclusive prefix of rowcnt inside the layer (row_scan)
     const i64 *voff;            // [zl] first value of the layer
     unsigned char *vals;
-    int wpr;                    // 64-pixel words per row
+    int wpr;
 };
 
 template <bool WRITE>
@@ -87,49 +91,83 @@ __global__ __launch_bounds__(256) void layer_maxima(const unsigned char *__restr
                                                      i64 *__restrict__ keys, SparseJ8 SP)
 {
     i64 b = blockIdx.x;
-    const int x = (int)(b % tiles_x) * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wt = (int)(b % tiles_x) * 4 + (threadIdx.x >> 6); // wave tile of 256 pixels in the row
     b /= tiles_x;
     const int y = (int)(b % h);
     const int zl = (int)(b / h);
+    if (wt * 256 >= w) return; // (wave-uniform)
     const unsigned char *L = J8 + (i64)(z0 + zl) * w * h;
-    const int p = y * w + x;
+    const int x0 = wt * 256 + 4 * lane;
+    const i64 row = (i64)zl * h + y;
     const int lmin = vmin[zl];
-    const int v = x < w ? (int)L[p] : lmin;
-    { // the sparse hand-over: every wavefront covers 64 consecutive pixels of one row
-        const unsigned long long above = __builtin_amdgcn_ballot_w64(v > lmin);
-        const int lane = threadIdx.x & 63, word = x >> 6; // (wave-uniform)
-        const i64 row = (i64)zl * h + y;
-        if ((x & ~63) < w) {
-            if (!WRITE) {
-                if (lane == 0) {
-                    SP.bitmap[row * SP.wpr + word] = above;
-                    if (above) atomicAdd(&SP.rowcnt[row], (unsigned int)__builtin_popcountll(above));
-                }
-            } else if (above) {
-                // pixels of the row in front of this word: the popcounts of the row's earlier words (at most a few dozen)
-                unsigned int before = 0;
-                for (int k = lane; k < word; k += 64) before += (unsigned int)__builtin_popcountll(SP.bitmap[row * SP.wpr + k]);
+    unsigned long long *bw = SP.bitmap + row * SP.wpr + wt * 4;
+    unsigned long long words[4];
+    if (WRITE) {
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
-                if (v > lmin)
-                    SP.vals[SP.voff[zl] + SP.rowoff[row] + before + (unsigned int)__builtin_popcountll(above & ((1ull << lane) - 1ull))] = (unsigned char)v;
-            }
+        for (int q = 0; q < 4; q++) words[q] = bw[q]; // (uniform address)
+        if ((words[0] | words[1] | words[2] | words[3]) == 0ull) return; // nothing above the minimum here: no value, no candidate
+    }
+    // the lane's four pixels (beyond the row: the minimum)
+    int v[4];
+    {
+        const i64 p0 = (i64)y * w + x0;
+        typedef unsigned __attribute__((aligned(1))) u32u;
+        if (x0 + 3 < w) {
+            const unsigned q = *(const u32u *)(L + p0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = (int)((q >> (8 * k)) & 0xffu);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = x0 + k < w ? (int)L[p0 + k] : lmin;
         }
     }
-    if (x <= 0 || x >= w - 1 || y <= 0 || y >= h - 1) return; // border pixels are never maxima (seed.cpp:595)
-    if (v == lmin) return; // seed.cpp:594
-    const unsigned char *r0 = L + p - w, *r2 = L + p + w;
-    const int m = max(max(max((int)r0[-1], (int)r0[0]), max((int)r0[1], (int)L[p - 1])),
-                      max(max((int)L[p + 1], (int)r2[-1]), max((int)r2[0], (int)r2[1])));
-    if (m > v) return;
     if (!WRITE) {
-        atomicAdd(&count[zl], 1u);
+        unsigned int n = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            words[q] = __builtin_amdgcn_ballot_w64(v[q] > lmin);
+            n += (unsigned int)__builtin_popcountll(words[q]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) bw[q] = words[q];
+            if (n) atomicAdd(&SP.rowcnt[row], n);
+        }
+        if (n == 0) return;
     } else {
-        // seed.cpp:616,626: iValue = (int)((fValue - globalMin) * vFactor), f32 arithmetic
-        const float fValue = (float)v, gmin = (float)lmin;
-        const int iValue = (int)((fValue - gmin) * vfactor[zl]);
-        const unsigned int slot = atomicAdd(&count[zl], 1u);
-        keys[off[zl] + slot] = (i64)(((unsigned long long)(i64)iValue << 32) | (unsigned int)p);
+        // pixels of the row in front of this wave tile: the popcounts of the row's earlier words
+        unsigned int before = 0;
+        for (int k = lane; k < wt * 4; k += 64) before += (unsigned int)__builtin_popcountll(SP.bitmap[row * SP.wpr + k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+        unsigned char *dst = SP.vals + SP.voff[zl] + SP.rowoff[row] + before;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (words[q] >> lane & 1ull) dst[__builtin_popcountll(words[q] & ((1ull << lane) - 1ull))] = (unsigned char)v[q];
+            dst += __builtin_popcountll(words[q]);
+        }
+    }
+    // 8-neighbour local maxima among the pixels above the minimum (seed.cpp:589-614)
+    if (y <= 0 || y >= h - 1) return; // border pixels are never maxima (:595)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int x = x0 + q;
+        if (v[q] == lmin || x <= 0 || x >= w - 1) continue; // :594, :595 (pixels beyond the row carry the minimum)
+        const int p = y * w + x;
+        const unsigned char *r0 = L + p - w, *r2 = L + p + w;
+        const int m = max(max(max((int)r0[-1], (int)r0[0]), max((int)r0[1], (int)L[p - 1])),
+                          max(max((int)L[p + 1], (int)r2[-1]), max((int)r2[0], (int)r2[1])));
+        if (m > v[q]) continue;
+        if (!WRITE) {
+            atomicAdd(&count[zl], 1u);
+        } else {
+            // seed.cpp:616,626: iValue = (int)((fValue - globalMin) * vFactor), f32 arithmetic
+            const float fValue = (float)v[q], gmin = (float)lmin;
+            const int iValue = (int)((fValue - gmin) * vfactor[zl]);
+            const unsigned int slot = atomicAdd(&count[zl], 1u);
+            keys[off[zl] + slot] = (i64)(((unsigned long long)(i64)iValue << 32) | (unsigned int)p);
+        }
     }
 }
 
@@ -193,12 +231,13 @@ struct LayerFinder {
         for (int y = 0; y < h; y++) {
             unsigned char *row = img.data() + (size_t)y * w;
             const unsigned long long *bw = bits + (size_t)y * wpr;
-            for (int k = 0; k < wpr; k++) {
+            for (int k = 0; k < wpr; k++) { // word k = byte position k & 3 of wave tile k >> 2: bit l <-> pixel 256 (k >> 2) + 4 l + (k & 3)
                 unsigned long long m = bw[k];
+                unsigned char *base = row + (k >> 2) * 256 + (k & 3);
                 while (m) {
                     const int bit = __builtin_ctzll(m);
                     m &= m - 1;
-                    row[k * 64 + bit] = *vals++;
+                    base[4 * bit] = *vals++;
                 }
             }
         }
@@ -211,10 +250,11 @@ struct LayerFinder {
             const unsigned long long *bw = bits + (size_t)y * wpr;
             for (int k = 0; k < wpr; k++) {
                 unsigned long long m = bw[k];
+                unsigned char *base = row + (k >> 2) * 256 + (k & 3);
                 while (m) {
                     const int bit = __builtin_ctzll(m);
                     m &= m - 1;
-                    row[k * 64 + bit] = (unsigned char)img_fill;
+                    base[4 * bit] = (unsigned char)img_fill;
                 }
             }
         }
@@ -351,7 +391,7 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     unsigned char *d_vals = nullptr;
     float *d_vf = nullptr;
     i64 *d_off = nullptr, *d_voff = nullptr, *d_keys = nullptr;
-    const int wpr = (w + 63) / 64; // 64-pixel bitmap words per row
+    const int wpr = 4 * ((w + 255) / 256); // bitmap words per row: four per wave tile of 256 pixels
     const size_t nrows = (size_t)nl * h, nwords = nrows * (size_t)wpr;
     int rc = c->scratch_get("seed_min", (size_t)nl, &d_min); // context-owned scratch, sized by the first pass
     if (!rc) rc = c->scratch_get("seed_max", (size_t)nl, &d_max);
@@ -398,7 +438,7 @@ int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1)
     hipLaunchKernelGGL(layer_minmax, dim3(nl * LM_PARTS), dim3(256), 0, c->stream, c->d_J8, wh, (int)z0, d_min, d_max);
     PNR_HIP(hipMemsetAsync(d_cnt, 0, nl * 4, c->stream));
     PNR_HIP(hipMemsetAsync(d_rowcnt, 0, nrows * 4, c->stream));
-    const int tiles_x = (w + 255) / 256;
+    const int tiles_x = (w + 1023) / 1024; // a work-group of four waves covers 1024 pixels of a row
     const unsigned nblk = (unsigned)((i64)tiles_x * h * nl);
     SparseJ8 SP{d_bits, d_rowcnt, d_rowoff, d_voff, nullptr, wpr};
     hipLaunchKernelGGL(layer_maxima<false>, dim3(nblk), dim3(256), 0, c->stream, c->d_J8, w, h, (int)z0, tiles_x, d_min,
