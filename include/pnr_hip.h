@@ -240,6 +240,14 @@ int pnr_sched_playback(const pnr_params *p, int64_t w, int64_t h, int64_t l, con
                        int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used,
                        int64_t *n_iterations_here);
 
+/* The same with the scheduler's tentative replay switched on or off (pnr_sched_playback: on, as in pnr_trace_replay[_sharded]; option
+ * "tentative"): results are identical either way, only the number of iterations run differs. */
+int pnr_sched_playback2(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n, int rank,
+                        int world, pnr_allgather_fn exchange, void *exchange_user, int64_t block_bytes, pnr_trace_fn trace,
+                        void *trace_user, int window, int groups, int poll, int look0, int look_pct, int tentative, pnr_node *nodes,
+                        int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used,
+                        int64_t *n_iterations_here);
+
 /* reconstruct() chain of the plugin (Advantra_plugin.cpp:2096-2181), pure host: link resampling
  * (TRACE_RSMPL) -> mean-shift refinement (SIG2RADIUS, REFINE_ITER, EPSILON2) -> sphere grouping (GROUP_RADIUS) ->
  * BFS trees -> drop trees < TREE_SIZE_MIN -> tree resampling.  Input: the node graph of pnr_trace_replay /
@@ -265,7 +273,9 @@ int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
  *   local_ranks) workers of the seed flood fill and of pnr_reconstruct_ctx | local_ranks (1) processes sharing this host |
  *   trace_timing, seed_timing (0/1) statistics on stderr | trace_log (0/1) keep every trace's end for pnr_get_trace_log | replay_batches (0/1), batch_growth, batch_max: rank batches instead
  *   of the streaming window | no_stash (0/1) persistent driver without the sample stash | exchange_block (0 = 256 KB / world) bytes per rank
- *   and exchange of pnr_trace_replay_sharded | frangi_prune (1) skip the eigen-solver below the first J8 level (pnr_get_frangi).
+ *   and exchange of pnr_trace_replay_sharded | frangi_prune (1) skip the eigen-solver below the first J8 level (pnr_get_frangi) |
+ *   tentative (1) the streaming scheduler pauses traces that a tentative replay of everything recorded so far cuts, and ends them
+ *   itself once that verdict is final (fewer wasted SMC iterations; same graph).
  *   pnr_get_option also knows "host_threads_effective" and "frangi_recomputes" (how often pnr_get_frangi / pnr_quantise_j8 had to
  *   re-run Frangi without the frangi_prune shortcut -- one pnr_frangi worth of GPU time each; also printed with trace_timing /
  *   seed_timing).  The kernel timers (pnr_get_kernel_ms) include those re-runs. */

@@ -22,7 +22,7 @@
 
 namespace {
 
-enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_IT = 3, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_FAST = 12, FL_NCH = 13, FL_N = 16 };
+enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_IT = 3, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_FAST = 12, FL_NCH = 13, FL_PAUSE = 14, FL_N = 16 };
 constexpr int PH_THREADS = 1024; // sampling work-group: 16 waves (<= 128 VGPRs each)
 constexpr int PH_CS = 54; // the sampling kernel holds nothing but the cube in LDS: 54 x 54 rows of 56 bytes = 163 296 B of the 160 KB (53 costs 1.5 %)
 constexpr int PH_PITCH = 56; // row pitch: a multiple of 4, so that every staged dword lands with one aligned ds_write_b32
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     if ((int)blockIdx.x >= P.cnt[lp]) return;
     const int tr = P.list[lp * P.cap + blockIdx.x];
     int *fl = P.flags + (i64)tr * FL_N;
+    if (fl[FL_PAUSE]) return; // paused by the scheduler (stream_sched.h, tentative replay): not stepped, state kept
     const int it = it_arg >= 0 ? it_arg : fl[FL_IT]; // streaming mode: every trace has its own iteration count
     __shared__ int sbox[8];
     extern __shared__ unsigned int dsm[]; // [np] pose hash, [np] representative (the duplicate search at the end)
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(PH_THREADS) PH_SAMPLE_ATTR void ph_sample(Vol V, Ta
     if (slot >= P.cnt[lp]) return;
     const int tr = P.list[lp * P.cap + slot];
     const int *fl = P.flags + (i64)tr * FL_N;
+    if (fl[FL_PAUSE]) return;
     const int it = it_arg >= 0 ? it_arg : fl[FL_IT];
     const float *cur = P.part + (i64)tr * 2 * np * PSTRIDE + (it & 1) * np * PSTRIDE;
     const float *xc_pen = P.xcs + (i64)tr * 16 + ((it & 1) ^ 1) * 8;
@@ -440,6 +442,7 @@ __global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, 
     if (slot >= P.cnt[lp]) return;
     const int tr = P.list[lp * P.cap + slot];
     const int *fl = P.flags + (i64)tr * FL_N;
+    if (fl[FL_PAUSE]) return;
     const int r = blockIdx.x - slot * (S * ng_max);
     const int sI = r / ng_max, g = r - sI * ng_max;
     const int nch = fl[FL_NCH], ngf = nch >> 6, rem = nch & 63;
@@ -490,6 +493,7 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
     if ((int)blockIdx.x >= P.cnt[lp]) return;
     const int tr = P.list[lp * P.cap + blockIdx.x];
     int *fl = P.flags + (i64)tr * FL_N;
+    if (fl[FL_PAUSE]) return; // (not appended to the next step's list: it comes back through ph_control)
     const int it = it_arg >= 0 ? it_arg : fl[FL_IT];
     float *cur = lds;                 // [np][9]
     float *prvw = cur + np * PSTRIDE; // [np] weights of the previous iteration
@@ -669,6 +673,38 @@ __global__ __launch_bounds__(256) void ph_admit(PhState P, float *__restrict__ s
     if (threadIdx.x == 0) P.cnt[lp] = base + m;
 }
 
+// streaming mode, tentative replay: take some traces off the list of this step (they keep slot and state; FL_PAUSE marks them) and
+// put paused ones back on it (one work-group, runs alone in stream order between two steps).  The list is compacted here, so a
+// pause takes effect at once and the slot of a trace the host has ended can be handed to a new trace in the same turn.
+__global__ __launch_bounds__(256) void ph_control(PhState P, const int *__restrict__ pause, int np_, const int *__restrict__ resume, int nr, int lp)
+{
+    __shared__ int kept;
+    const int n = P.cnt[lp];
+    int *list = P.list + (size_t)lp * P.cap, *tmp = P.list + (size_t)(lp ^ 1) * P.cap; // (the other list is only filled by the next ph_update)
+    if (threadIdx.x == 0) kept = 0;
+    for (int j = threadIdx.x; j < np_; j += blockDim.x) P.flags[(i64)pause[j] * FL_N + FL_PAUSE] = 1;
+    __syncthreads();
+    if (np_ > 0) {
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            const int tr = list[j];
+            if (!P.flags[(i64)tr * FL_N + FL_PAUSE]) tmp[atomicAdd(&kept, 1)] = tr;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < kept; j += blockDim.x) list[j] = tmp[j];
+        __syncthreads();
+    } else if (threadIdx.x == 0) {
+        kept = n;
+    }
+    __syncthreads();
+    const int base = kept;
+    for (int j = threadIdx.x; j < nr; j += blockDim.x) {
+        P.flags[(i64)resume[j] * FL_N + FL_PAUSE] = 0;
+        list[base + j] = resume[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) P.cnt[lp] = base + nr;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------
@@ -687,6 +723,7 @@ struct pnr_phased {
     // streaming trace + replay: pinned records written by the kernels / read back at every poll, admission staging
     pnr_xest *h_xc = nullptr; int *h_flags = nullptr; int *h_new = nullptr; float *h_new_s6 = nullptr;
     int *d_new = nullptr; float *d_new_s6 = nullptr;
+    int *h_ctl = nullptr, *d_ctl = nullptr; // pause / resume lists of the tentative replay: [group][2][stream_cap]
     int64_t stream_cap = 0;
     int stream_ni = 0;
     static constexpr int MAXG = 4;
@@ -724,6 +761,8 @@ void pnr_phased_destroy(pnr_phased *h)
     if (h->h_new) hipHostFree(h->h_new);
     if (h->h_new_s6) hipHostFree(h->h_new_s6);
     hipFree(h->d_new); hipFree(h->d_new_s6);
+    if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+    (void)hipFree(h->d_ctl);
     for (int r = 0; r < pnr_phased::RING; r++)
         if (h->ev[r]) (void)hipEventDestroy(h->ev[r]);
     for (int g = 1; g < pnr_phased::MAXG; g++)
@@ -988,6 +1027,9 @@ struct PhasedEngine final : pnr::StreamEngine {
             if (h->h_new) hipHostFree(h->h_new);
             if (h->h_new_s6) hipHostFree(h->h_new_s6);
             hipFree(h->d_new); hipFree(h->d_new_s6);
+            if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+            (void)hipFree(h->d_ctl);
+            h->h_ctl = nullptr; h->d_ctl = nullptr;
             h->h_xc = nullptr; h->h_flags = nullptr; h->h_new = nullptr; h->h_new_s6 = nullptr; h->d_new = nullptr; h->d_new_s6 = nullptr;
             h->stream_cap = 0;
             PE_HIP(hipHostMalloc(&h->h_xc, (size_t)NT * ni * sizeof(pnr_xest)));
@@ -997,6 +1039,8 @@ struct PhasedEngine final : pnr::StreamEngine {
             PE_HIP(hipHostMalloc(&h->h_new_s6, (size_t)NT * 24 * MG));
             PE_HIP(hipMalloc(&h->d_new, (size_t)NT * 4 * MG));
             PE_HIP(hipMalloc(&h->d_new_s6, (size_t)NT * 24 * MG));
+            PE_HIP(hipHostMalloc(&h->h_ctl, (size_t)NT * 4 * 2 * MG));
+            PE_HIP(hipMalloc(&h->d_ctl, (size_t)NT * 4 * 2 * MG));
             h->stream_cap = NT;
             h->stream_ni = ni;
         }
@@ -1076,6 +1120,22 @@ struct PhasedEngine final : pnr::StreamEngine {
         return fl[FL_DONE] != 0;
     }
     const pnr_xest *rows(int slot) const override { return h->h_xc + (size_t)slot * E.ni; }
+    int progress(int g, int slot) const override
+    {
+        // ph_update of iteration `it` writes the estimate of iteration it - 1 (its corr is known one step late) and leaves FL_IT = it + 1
+        return grp[g].h_flags[(size_t)slot * FL_N + FL_IT] - 1;
+    }
+    int control(int g, const int *pause, int np_, const int *resume, int nr) override
+    {
+        Grp &q = grp[g];
+        int *hc = h->h_ctl + (size_t)g * 2 * h->stream_cap, *dc = h->d_ctl + (size_t)g * 2 * h->stream_cap;
+        if (np_ > 0) std::memcpy(hc, pause, (size_t)np_ * 4);      // pinned staging of this group: free, its last steps have been waited for
+        if (nr > 0) std::memcpy(hc + h->stream_cap, resume, (size_t)nr * 4);
+        if (np_ > 0) PE_HIP(hipMemcpyAsync(dc, hc, (size_t)np_ * 4, hipMemcpyHostToDevice, q.st));
+        if (nr > 0) PE_HIP(hipMemcpyAsync(dc + h->stream_cap, hc + h->stream_cap, (size_t)nr * 4, hipMemcpyHostToDevice, q.st));
+        hipLaunchKernelGGL(ph_control, dim3(1), dim3(256), 0, q.st, q.P, (const int *)dc, np_, (const int *)(dc + h->stream_cap), nr, q.lp);
+        return PNR_OK;
+    }
     int density_update(const pnr::Replayer &r, bool concurrent) override
     {
         // its own stream when groups overlap: the kernels of either group may see a voxel before or after the update -- both are
@@ -1102,6 +1162,7 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
     pnr::SchedOptions o;
     o.window = c->opt.window; o.look0 = c->opt.look0; o.look_pct = c->opt.look_pct; o.poll = c->opt.poll; o.groups = c->opt.groups;
     o.timing = c->opt.trace_timing;
+    o.tentative = c->opt.tentative;
     const int64_t own = sh.world > 1 ? (n - sh.rank + sh.world - 1) / sh.world : n; // seeds of this rank
     int64_t window = std::min<int64_t>(std::max(2, o.window), std::max<int64_t>(2, 2 * own));
     window += window & 1;

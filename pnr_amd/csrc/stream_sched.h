@@ -12,6 +12,19 @@
 // reference cuts it, and the replay, which applies the true map, yields exactly the node graph of tracing everything to its
 // map-free end.
 //
+// Tentative replay (option "tentative", default on).  Speculation is what the window costs: a trace beyond the frontier runs without
+// the nodes of the unreplayed seeds in front of it, and nearly half of the SMC iterations run that way are cut away by the replay
+// later.  After every poll the scheduler therefore replays -- on an overlay over the final map, never into it -- ALL records it
+// knows of the unreplayed seeds, in rank order: the finished traces' and what the running traces have written so far.  A cut trace
+// takes its later nodes out of the picture, exactly as in the final replay, so the overlay is what the final map would be if
+// nothing more were recorded.  A running trace that this replay cuts inside its recorded iterations is PAUSED (no longer stepped;
+// it keeps its slot and its state) and resumed if a later pass no longer cuts it (one pause in twenty); as long as every seed in
+// front is complete the pass is not tentative at all -- it IS the final replay's verdict -- and a cut trace is ended on the spot,
+// its record delivered with the iterations it has.  None of this can change the result: the final replay alone builds the
+// graph, from the same records in the same order; a paused trace only stops producing iterations the replay would cut away.
+// Measured on the recorded traces of the bench workload (scripts/sim_tentative.py): 177 k -> 119 k SMC iterations for the same
+// number of steps, nineteen pauses in twenty never resumed.
+//
 // Sharded (world > 1): rank r owns the sorted seeds r, r + world, ...  After every poll the ranks all-gather the records of the
 // traces that finished on them (one fixed-size block per rank and poll; what does not fit is carried to the next poll) and
 // EVERY rank replays the same records in global seed order, so every rank holds the same replayed map -- still only final nodes
@@ -33,6 +46,7 @@ struct SchedOptions {
     int look_pct = -1; // look0 = 0 / look_pct < 0: automatic, max(128, 64 * world) / min(400, 50 * world) (scripts/sim_sharded.py)
     int poll = 4;      // SMC steps between two polls
     int groups = 2;    // trace groups stepping independently (engine permitting)
+    int tentative = 1; // pause traces that a tentative replay of everything recorded so far cuts (see above)
     int timing = 0;    // one line of statistics on stderr
 };
 
@@ -45,6 +59,7 @@ struct ShardSpec {
 
 struct SchedStats {
     int64_t steps = 0, polls = 0, iters = 0, exchanges = 0, carried = 0, launched = 0, skipped = 0;
+    int64_t paused = 0, resumed = 0, ended = 0, tent_nodes = 0, tent_passes = 0; // tentative replay
 };
 
 class StreamEngine {
@@ -61,6 +76,11 @@ public:
     // after wait(g): has the trace in `slot` stopped?  *T = its successful iterations; rows() = its min(T + 1, ni) estimates
     virtual bool finished(int g, int slot, int *T) const = 0;
     virtual const pnr_xest *rows(int slot) const = 0;
+    // after wait(g), for a trace of group g that is still running: the iterations whose estimates can be read in rows(slot)
+    virtual int progress(int g, int slot) const = 0;
+    // queue, in front of group g's next steps and admissions: take the running traces in pause[0..np) off the group's list (they
+    // keep slot and state) and put the paused traces in resume[0..nr) back on it
+    virtual int control(int g, const int *pause, int np, const int *resume, int nr) = 0;
     // push the density of the voxels in r.touched (final values r.den_at) to the engine's map
     virtual int density_update(const Replayer &r, bool concurrent) = 0;
     virtual void drain() = 0;
@@ -95,6 +115,56 @@ inline void abort_exchange(const ShardSpec &sh, int ni)
     (void)sh.exchange(sh.user, send.data(), recv.data(), block);
 }
 
+namespace sched_detail {
+// the tentative replay's density overlay: voxel -> nodes added by the pass (open addressing, emptied by a generation stamp)
+struct Overlay {
+    std::vector<int64_t> key;
+    std::vector<uint32_t> gen;
+    std::vector<uint8_t> cnt;
+    uint32_t cur = 0;
+    size_t used = 0;
+    Overlay() { resize(1 << 14); }
+    void resize(size_t nsz) { key.assign(nsz, 0); gen.assign(nsz, 0); cnt.assign(nsz, 0); }
+    void begin()
+    {
+        used = 0;
+        if (++cur == 0) { std::fill(gen.begin(), gen.end(), 0u); cur = 1; }
+    }
+    static size_t hash(int64_t v) { return (size_t)(((uint64_t)v * 0x9E3779B97F4A7C15ull) >> 20); }
+    int get(int64_t v) const
+    {
+        const size_t mask = key.size() - 1;
+        for (size_t h = hash(v) & mask;; h = (h + 1) & mask) {
+            if (gen[h] != cur) return 0;
+            if (key[h] == v) return cnt[h];
+        }
+    }
+    void add(int64_t v)
+    {
+        if (2 * (used + 1) > key.size()) grow();
+        const size_t mask = key.size() - 1;
+        for (size_t h = hash(v) & mask;; h = (h + 1) & mask) {
+            if (gen[h] != cur) { gen[h] = cur; key[h] = v; cnt[h] = 1; used++; return; }
+            if (key[h] == v) { if (cnt[h] < 255) cnt[h]++; return; }
+        }
+    }
+    void grow()
+    {
+        std::vector<int64_t> k0; std::vector<uint32_t> g0; std::vector<uint8_t> c0;
+        k0.swap(key); g0.swap(gen); c0.swap(cnt);
+        resize(k0.size() * 2);
+        used = 0;
+        const size_t mask = key.size() - 1;
+        for (size_t i = 0; i < k0.size(); i++)
+            if (g0[i] == cur) {
+                size_t h = hash(k0[i]) & mask;
+                while (gen[h] == cur) h = (h + 1) & mask;
+                gen[h] = cur; key[h] = k0[i]; cnt[h] = c0[i]; used++;
+            }
+    }
+};
+} // namespace sched_detail
+
 // Returns 0 or a PNR_E_* code (message in `err`).  `r` ends up holding the node graph; *stats the local counters.
 inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni, SchedOptions o, const ShardSpec &sh, Replayer &r,
                       SchedStats *stats, std::string &err)
@@ -117,17 +187,28 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
 
     struct SeedRec {
         uint8_t have = 0;      // directions whose record has arrived
+        uint8_t got = 0;       // ... which ones (bit = direction)
         bool skipped = false;  // sits on a saturated voxel: never traced (:2669-2670)
         int32_t T[2] = {0, 0};
         std::vector<pnr_xest> xc; // [2][ni], allocated when the first record arrives, dropped after the replay
     };
     std::vector<SeedRec> rec((size_t)n);
-    struct Grp { int active = 0; bool inflight = false; std::vector<int> busy; };
+    struct Grp {
+        int active = 0; bool inflight = false;
+        std::vector<int> busy;    // slots of this group's traces that have not delivered their record (running or paused)
+        int npaused = 0;
+    };
     std::vector<Grp> grp((size_t)G);
     std::vector<int> free_slots;
     for (int k = NT - 1; k >= 0; k--) free_slots.push_back(k);
     std::vector<int64_t> slot_seed((size_t)NT, -1);
-    std::vector<int> slot_dir((size_t)NT, 0);
+    std::vector<int> slot_dir((size_t)NT, 0), slot_group((size_t)NT, -1);
+    std::vector<uint8_t> slot_paused((size_t)NT, 0);
+    std::vector<int32_t> seed_slot((size_t)(2 * n), -1); // slot of trace (seed, direction) while it runs on this rank
+    int64_t max_known = -1;                               // highest seed any record or admission has touched
+    Overlay ov;
+    std::vector<int> pause_list, resume_list;
+    const bool tentative = o.tentative != 0;
     std::vector<int> new_slots;
     std::vector<float> new_s6;
     int64_t next = rank, frontier = 0;
@@ -151,12 +232,14 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             if (dir < 0) {
                 sr.skipped = true;
             } else {
-                if (dir > 1 || sr.have >= 2) return false;
+                if (dir > 1 || sr.have >= 2 || (sr.got >> dir & 1)) return false;
                 if (sr.xc.empty()) sr.xc.resize((size_t)2 * ni);
                 sr.T[dir] = Tn;
                 if (rows > 0) std::memcpy(sr.xc.data() + (size_t)dir * ni, w + k + 4, (size_t)rows * sizeof(pnr_xest));
                 sr.have++;
+                sr.got |= (uint8_t)(1 << dir);
             }
+            if (s > max_known) max_known = s;
             k += 4 + (size_t)rows * 8;
         }
         return true;
@@ -217,7 +300,8 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             for (size_t b = 0; b < q.busy.size(); b++) {
                 const int slot = q.busy[b];
                 int Tn = 0;
-                if (!E.finished(g, slot, &Tn)) { q.busy[keep++] = slot; continue; }
+                if (slot_paused[(size_t)slot] || !E.finished(g, slot, &Tn)) { q.busy[keep++] = slot; continue; }
+                seed_slot[(size_t)(2 * slot_seed[(size_t)slot] + slot_dir[(size_t)slot])] = -1;
                 const int rows = std::min(std::max(Tn, 0) + 1, ni); // + the iteration that failed (its corr is what the reference prints)
                 const size_t at = outbox.size();
                 outbox.resize(at + 4 + (size_t)rows * 8);
@@ -240,22 +324,111 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                 outbox.clear();
             } else {
                 int busy = 0, abort_rank = -1;
-                for (int k = 0; k < G; k++) busy |= (grp[(size_t)k].inflight || grp[(size_t)k].active > 0) ? 1 : 0;
+                for (int k = 0; k < G; k++) busy |= (grp[(size_t)k].inflight || grp[(size_t)k].active > 0 || grp[(size_t)k].npaused > 0) ? 1 : 0;
                 rc = exchange(busy, 0, &busy_all, &abort_rank);
                 if (rc) { aborted = true; return fail(rc); }
                 if (abort_rank >= 0) { aborted = true; err = "rank " + std::to_string(abort_rank) + " aborted the sharded trace"; return fail(PNR_E_STATE); }
             }
             // ---- replay in seed order as far as the finished traces reach, push the new density to the engine
             r.touched.clear();
-            while (frontier < n && !r.stopped) {
-                SeedRec &sr = rec[(size_t)frontier];
-                if (!sr.skipped && sr.have < 2) break;
-                if (!sr.skipped) { // (a skipped seed sits on a saturated voxel: the replay would skip it as well)
-                    r.log_base = frontier;
-                    r.add(&seeds[frontier], 1, sr.T, sr.xc.data());
-                    std::vector<pnr_xest>().swap(sr.xc);
+            auto final_replay = [&]() {
+                while (frontier < n && !r.stopped) {
+                    SeedRec &sr = rec[(size_t)frontier];
+                    if (!sr.skipped && sr.have < 2) break;
+                    if (!sr.skipped) { // (a skipped seed sits on a saturated voxel: the replay would skip it as well)
+                        r.log_base = frontier;
+                        r.add(&seeds[frontier], 1, sr.T, sr.xc.data());
+                        std::vector<pnr_xest>().swap(sr.xc);
+                    }
+                    frontier++;
                 }
-                frontier++;
+            };
+            final_replay();
+            // ---- tentative replay of everything known beyond the frontier (see the head of this file): pause / resume / end the
+            // traces of THIS group (its staging buffers are free: its last steps have just been waited for)
+            if (tentative && !r.stopped && frontier < n) {
+                bool ended_any = false;
+                pause_list.clear(); resume_list.clear(); // what this turn asks of the engine, sent once after the last round
+                auto want_pause = [&](int slot) { // (a resume asked for earlier in this turn is simply taken back: the trace never left the device's list)
+                    auto f = std::find(resume_list.begin(), resume_list.end(), slot);
+                    if (f != resume_list.end()) resume_list.erase(f); else pause_list.push_back(slot);
+                };
+                auto want_resume = [&](int slot) {
+                    auto f = std::find(pause_list.begin(), pause_list.end(), slot);
+                    if (f != pause_list.end()) pause_list.erase(f); else resume_list.push_back(slot);
+                };
+                for (int round = 0; round < 2; round++) { // (records the pass itself produced are applied at once on one rank)
+                    ov.begin();
+                    st.tent_passes++;
+                    bool exact = true; // every seed in front is complete: the overlay is what the final replay will see
+                    const int64_t scan_hi = std::min<int64_t>(n, std::max<int64_t>(max_known + 1, frontier));
+                    ended_any = false;
+                    for (int64_t s = frontier; s < scan_hi; s++) {
+                        SeedRec &sr = rec[(size_t)s];
+                        if (sr.skipped) continue;
+                        const pnr_seed &sd = seeds[s];
+                        const int64_t sv = r.voxel(sd.x, sd.y, sd.z);
+                        const bool seed_sat = r.den_at(sv) + ov.get(sv) >= r.prm.nodepervol; // the replay would not look at its traces
+                        for (int dir = 0; dir < 2; dir++) {
+                            const int slot = seed_slot[(size_t)(2 * s + dir)];
+                            const bool done = (sr.got >> dir & 1) != 0;
+                            const pnr_xest *X = nullptr;
+                            int nr = 0;
+                            if (done) { X = sr.xc.data() + (size_t)dir * ni; nr = std::min(sr.T[dir], ni); }
+                            else if (slot >= 0) { X = E.rows(slot); nr = std::min(std::max(E.progress(slot_group[(size_t)slot], slot), 0), ni); }
+                            else { exact = false; continue; } // running elsewhere, or its record is on its way: nothing known
+                            int cut = seed_sat ? 0 : -1;
+                            for (int i = 0; cut < 0 && i < nr; i++) {
+                                const int64_t crd = r.voxel(X[i].x, X[i].y, X[i].z);
+                                if (r.soma_at(crd) || r.den_at(crd) + ov.get(crd) >= r.prm.nodepervol) { cut = i; break; }
+                                ov.add(crd);
+                                st.tent_nodes++;
+                                if (r.prm.vol > 1) {
+                                    int64_t nb[26];
+                                    const int cnt = density_neighbours(crd, r.W, r.H, r.L, r.prm.vol, nb);
+                                    for (int q2 = 0; q2 < cnt; q2++) ov.add(nb[q2]);
+                                }
+                            }
+                            if (done) continue;
+                            const bool here = slot_group[(size_t)slot] == g; // (another group's staging may still be in use: it acts in its own turn)
+                            if (cut >= 0) {
+                                if (exact && here) { // not tentative: this IS the final replay's verdict -- end the trace, deliver its record
+                                    const size_t at = outbox.size();
+                                    outbox.resize(at + 4 + (size_t)nr * 8);
+                                    outbox[at] = (int32_t)s; outbox[at + 1] = dir; outbox[at + 2] = nr; outbox[at + 3] = nr;
+                                    if (nr > 0) std::memcpy(&outbox[at + 4], X, (size_t)nr * sizeof(pnr_xest));
+                                    st.iters += nr;
+                                    st.ended++;
+                                    if (!slot_paused[(size_t)slot]) want_pause(slot); else q.npaused--;
+                                    slot_paused[(size_t)slot] = 0;
+                                    seed_slot[(size_t)(2 * s + dir)] = -1;
+                                    slot_seed[(size_t)slot] = -1;
+                                    q.busy.erase(std::find(q.busy.begin(), q.busy.end(), slot));
+                                    free_slots.push_back(slot); // (control() takes it off the device's list before this turn's admissions)
+                                    ended_any = true;
+                                } else {
+                                    if (here && !slot_paused[(size_t)slot]) { want_pause(slot); slot_paused[(size_t)slot] = 1; q.npaused++; st.paused++; }
+                                    exact = false;
+                                }
+                            } else {
+                                if (here && slot_paused[(size_t)slot]) { want_resume(slot); slot_paused[(size_t)slot] = 0; q.npaused--; st.resumed++; }
+                                exact = false; // still running: what it will add is not known
+                            }
+                        }
+                    }
+                    if (!(ended_any && world == 1)) break;
+                    if (!apply(outbox.data(), outbox.size())) { err = "malformed trace record"; return fail(PNR_E_STATE); }
+                    outbox.clear();
+                    final_replay();
+                    if (r.stopped || frontier >= n) break;
+                }
+                if (!pause_list.empty() || !resume_list.empty()) {
+                    rc = E.control(g, pause_list.data(), (int)pause_list.size(), resume_list.data(), (int)resume_list.size());
+                    if (rc) { err = E.error(); return fail(rc); }
+                    q.active += (int)resume_list.size() - (int)pause_list.size(); // (what control() leaves on the device's list)
+                    if (q.active < 0) q.active = 0;
+                    idle_turns = 0;
+                }
             }
             if (!r.touched.empty()) {
                 rc = E.density_update(r, G > 1);
@@ -288,7 +461,8 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             for (int dir = 0; dir < 2; dir++) {
                 const int slot = free_slots.back();
                 free_slots.pop_back();
-                slot_seed[(size_t)slot] = next; slot_dir[(size_t)slot] = dir;
+                slot_seed[(size_t)slot] = next; slot_dir[(size_t)slot] = dir; slot_group[(size_t)slot] = g; slot_paused[(size_t)slot] = 0;
+                seed_slot[(size_t)(2 * next + dir)] = slot;
                 q.busy.push_back(slot);
                 new_slots.push_back(slot);
                 const float sg = dir ? -1.f : 1.f; // trackNeg starts from the negated seed direction (tracker.cpp:819-823)
@@ -297,6 +471,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                 m++;
             }
             st.launched++;
+            if (next > max_known) max_known = next;
             next += world;
         }
         if (m > 0) {
@@ -318,6 +493,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
         } else {
             any = any || m > 0 || !outbox.empty();
             for (int k = 0; k < G; k++) any = any || grp[(size_t)k].inflight;
+            // (paused traces are no progress by themselves: the pass resumes or ends the ones at the frontier within a rotation)
         }
         idle_turns = any ? 0 : idle_turns + 1;
         if (idle_turns > STALL_TURNS) {
@@ -329,8 +505,10 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     E.drain(); // what is still running is never looked at again, but it writes into buffers that outlive this call
     if (o.timing)
         fprintf(stderr, "[pnr trace] rank %d/%d: %lld seeds, window %d slots, lookahead max(%d, %d%%), %lld steps, %lld polls, %lld iterations here, "
-                        "%lld exchanges (%lld carried), %zu nodes\n", rank, world, (long long)n, NT, o.look0, o.look_pct, (long long)st.steps,
-                (long long)st.polls, (long long)st.iters, (long long)st.exchanges, (long long)st.carried, r.nodes.size());
+                        "%lld exchanges (%lld carried), %zu nodes; tentative replay: %lld passes, %lld nodes, %lld pauses, %lld resumed, %lld ended by the host\n",
+                rank, world, (long long)n, NT, o.look0, o.look_pct, (long long)st.steps,
+                (long long)st.polls, (long long)st.iters, (long long)st.exchanges, (long long)st.carried, r.nodes.size(), (long long)st.tent_passes,
+                (long long)st.tent_nodes, (long long)st.paused, (long long)st.resumed, (long long)st.ended);
     if (stats) *stats = st;
     return PNR_OK;
 }

@@ -104,6 +104,8 @@ def load():
                                            C.POINTER(i64), C.POINTER(i64)]
     L.pnr_sched_playback.argtypes = [C.POINTER(Params), i64, i64, i64, vp, i64, i32, i32, ALLGATHER_FN, vp, i64, TRACE_FN, vp, i32, i32, i32, i32, i32,
                                      vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    L.pnr_sched_playback2.argtypes = [C.POINTER(Params), i64, i64, i64, vp, i64, i32, i32, ALLGATHER_FN, vp, i64, TRACE_FN, vp, i32, i32, i32, i32, i32, i32,
+                                      vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.pnr_get_trace_log.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.pnr_shm_exchange_open.argtypes = [C.c_char_p, i32, i32, i64, C.POINTER(vp)]
     L.pnr_shm_allgather.argtypes = [vp, vp, vp, i64]
@@ -122,7 +124,7 @@ EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", 
            "pnr_set_volume", "pnr_set_volume_device", "pnr_frangi", "pnr_get_frangi", "pnr_gaussian", "pnr_hessian",
            "pnr_set_j8_v", "pnr_extract_seeds", "pnr_extract_seeds_range", "pnr_zncc_batch",
            "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_replay_traces_ctx", "pnr_frangi_slab", "pnr_quantise_j8", "pnr_soma", "pnr_get_soma", "pnr_trace_replay", "pnr_reconstruct", "pnr_get_table", "pnr_set_profiling", "pnr_set_smc_driver",
-           "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch", "pnr_get_graph", "pnr_trace_replay_sharded", "pnr_sched_playback",
+           "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch", "pnr_get_graph", "pnr_trace_replay_sharded", "pnr_sched_playback", "pnr_sched_playback2",
            "pnr_set_option", "pnr_get_option", "pnr_score_filter_seeds", "pnr_sort_seeds", "pnr_get_trace_log",
            "pnr_shm_exchange_open", "pnr_shm_allgather", "pnr_shm_exchange_close"]
 
@@ -462,7 +464,7 @@ class ShmExchange:
             self.handle = None
 
 
-def sched_playback(params, shape, seeds, trace_fn, rank=0, world=1, exchange=None, block_bytes=0, window=768, groups=1, poll=4, look0=0, look_pct=-1):
+def sched_playback(params, shape, seeds, trace_fn, rank=0, world=1, exchange=None, block_bytes=0, window=768, groups=1, poll=4, look0=0, look_pct=-1, tentative=True):
     """The streaming scheduler over a host engine that plays back map-free traces (pnr_sched_playback; no GPU): `trace_fn(pos_dir6)`
     -> (T, xc[ni][8]).  Returns nodes, links, traces used, iterations on this rank."""
     L = load()
@@ -492,8 +494,8 @@ def sched_playback(params, shape, seeds, trace_fn, rank=0, world=1, exchange=Non
     cap = 2 * len(s) * ni + 2
     nodes = np.zeros(cap, NODE_DT)
     links = np.zeros((2 * cap + 2, 2), np.int32)
-    check(L.pnr_sched_playback(C.byref(params), w, h, l, s.ctypes.data, len(s), rank, world, xcb, xuser, block_bytes, tcb, None, window, groups, poll, look0, look_pct,
-                               nodes.ctypes.data, cap, C.byref(nn), links.ctypes.data, len(links), C.byref(nl), C.byref(nt), C.byref(it)))
+    check(L.pnr_sched_playback2(C.byref(params), w, h, l, s.ctypes.data, len(s), rank, world, xcb, xuser, block_bytes, tcb, None, window, groups, poll, look0, look_pct,
+                                int(bool(tentative)), nodes.ctypes.data, cap, C.byref(nn), links.ctypes.data, len(links), C.byref(nl), C.byref(nt), C.byref(it)))
     return nodes[:nn.value].copy(), links[:nl.value].copy(), nt.value, it.value
 
 

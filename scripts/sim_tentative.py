@@ -1,0 +1,183 @@
+"""Offline study (recorded map-free traces of the bench workload, scripts/dump_traces.py): pausing on a TENTATIVE REPLAY.
+
+The streaming scheduler speculates: seeds beyond the replay frontier are traced without the nodes of the unreplayed seeds in front
+of them, and 45 % of the SMC iterations it runs are cut away by the replay later.  Pausing a trace when the nodes recorded so far
+by lower-ranked seeds (finished or running) saturate its voxel was modelled in sim_pause.py and does not pay: four pauses in five
+are lifted again, because most of those nodes are speculation themselves and get cut.
+
+Here the prediction is a full tentative replay at every poll: all records of the admitted, unreplayed seeds are replayed in rank
+order on top of the final map, exactly as the final replay would if nothing more were recorded -- so a trace that is cut takes its
+own later nodes out of the picture.  A running trace whose tentative cut lies inside what it has recorded is paused (it costs no
+step time but keeps its slot); it resumes when a later tentative replay no longer cuts it; seeds on tentatively saturated voxels
+wait.  The final result is untouched (the final replay decides).
+
+  python scripts/sim_tentative.py [gpurun_out/traces_1024_s2000.npz]
+"""
+import sys
+
+import numpy as np
+
+d = np.load(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/traces_1024_s2000.npz")
+T, pos, seeds = d["T"], d["pos"], d["seeds"]
+n = len(seeds)
+S = 1024
+NPV = 4
+r = lambda a: np.floor(a + 0.5).astype(np.int64)
+vox = ((r(pos[..., 2]) * S + r(pos[..., 1])) * S + r(pos[..., 0]))
+svox = ((r(seeds[:, 2]) * S + r(seeds[:, 1])) * S + r(seeds[:, 0])).tolist()
+voxl = [row.tolist() for row in vox]
+Tl = T.tolist()
+A_MS, C_MS = 0.30, 0.0075
+INF = 1 << 30
+
+
+def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=1, a_ms=A_MS, c_ms=C_MS, margin=0, hold_seeds=True):
+    den = {}
+    it = [0] * (2 * n)
+    state = [0] * (2 * n)  # 0 not admitted, 1 running, 2 stopped, 3 paused, 4 skipped
+    frontier = nxt = 0
+    steps = iters = nodes = polls = 0
+    ms = 0.0
+    active = []
+    paused = set()
+    held = set()          # seeds not admitted because their voxel is tentatively saturated
+    npause = nresume = 0
+    tent_work = 0
+    while frontier < n:
+        lim = frontier + max(look0, frontier * look_pct // 100)
+        # admission: rank order, seeds on tentatively saturated voxels wait (they are looked at again at every poll)
+        s = nxt
+        while s < n and s < lim and len(active) + len(paused) + 2 <= window:
+            if state[2 * s] == 0 and s not in held:
+                if den.get(svox[s], 0) >= NPV:
+                    state[2 * s] = state[2 * s + 1] = 4
+                else:
+                    for g in (2 * s, 2 * s + 1):
+                        state[g] = 1
+                        active.append(g)
+            s += 1
+        nxt = max(nxt, s)
+        for _ in range(poll):
+            if not active:
+                break
+            steps += 1
+            ms += a_ms + c_ms * len(active)
+            iters += len(active)
+            keep = []
+            for g in active:
+                i = it[g]
+                it[g] = i + 1
+                if i >= Tl[g] or den.get(voxl[g][i], 0) >= NPV:
+                    state[g] = 2
+                    continue
+                keep.append(g)
+            active = keep
+        if not active and not paused and not held and nxt >= n and all(state[2 * q] != 1 for q in range(frontier, n)):
+            pass
+        polls += 1
+        # ---- final replay, seed-granular as in stream_sched.h
+        while frontier < n:
+            a = 2 * frontier
+            if frontier in held:
+                break  # (a held seed at the frontier is released below)
+            if state[a] == 0:
+                break
+            if state[a] == 4:
+                frontier += 1
+                continue
+            if state[a] in (1, 3) or state[a + 1] in (1, 3):
+                # a paused trace at the frontier: its tentative cut is now final knowledge -- check it against the final map
+                stuck = False
+                for g in (a, a + 1):
+                    if state[g] == 1:
+                        stuck = True
+                    elif state[g] == 3:
+                        cut = False
+                        if den.get(svox[frontier], 0) >= NPV:
+                            cut = True
+                        else:
+                            dd = {}
+                            for g2 in ((a,) if g == a else (a, a + 1)):
+                                for i in range(min(it[g2], Tl[g2])):
+                                    v = voxl[g2][i]
+                                    if den.get(v, 0) + dd.get(v, 0) >= NPV:
+                                        if g2 == g:
+                                            cut = True
+                                        break
+                                    dd[v] = dd.get(v, 0) + 1
+                        if cut:
+                            state[g] = 2
+                            paused.discard(g)
+                        else:
+                            state[g] = 1
+                            paused.discard(g)
+                            active.append(g)
+                            nresume += 1
+                            stuck = True
+                if stuck or state[a] in (1, 3) or state[a + 1] in (1, 3):
+                    break
+            if den.get(svox[frontier], 0) < NPV:
+                for g in (a, a + 1):
+                    for i in range(min(it[g], Tl[g])):
+                        v = voxl[g][i]
+                        if den.get(v, 0) >= NPV:
+                            break
+                        den[v] = den.get(v, 0) + 1
+                        nodes += 1
+            frontier += 1
+        # a held seed that became the frontier: the final map decides
+        while frontier < n and frontier in held:
+            held.discard(frontier)
+            if den.get(svox[frontier], 0) >= NPV:
+                state[2 * frontier] = state[2 * frontier + 1] = 4
+                frontier += 1
+            else:
+                for g in (2 * frontier, 2 * frontier + 1):
+                    state[g] = 1
+                    active.append(g)
+                break
+        if not tentative or polls % every:
+            continue
+        # ---- tentative replay of everything admitted and unreplayed, in rank order, on top of the final map
+        tden = {}
+        for s in range(frontier, nxt):
+            a = 2 * s
+            if state[a] == 4:
+                continue
+            if state[a] == 0:  # held or not yet admitted
+                if hold_seeds and s < lim:
+                    if den.get(svox[s], 0) + tden.get(svox[s], 0) >= NPV:
+                        held.add(s)
+                    elif s in held:
+                        held.discard(s)
+                continue
+            sat = den.get(svox[s], 0) + tden.get(svox[s], 0) >= NPV
+            for g in (a, a + 1):
+                cut = 0 if sat else INF
+                if not sat:
+                    row = voxl[g]
+                    for i in range(min(it[g], Tl[g])):
+                        v = row[i]
+                        if den.get(v, 0) + tden.get(v, 0) >= NPV:
+                            cut = i
+                            break
+                        tden[v] = tden.get(v, 0) + 1
+                        tent_work += 1
+                if state[g] == 1 and cut + margin < it[g]:
+                    state[g] = 3
+                    paused.add(g)
+                    npause += 1
+                elif state[g] == 3 and cut == INF:
+                    state[g] = 1
+                    paused.discard(g)
+                    active.append(g)
+                    nresume += 1
+        active = [g for g in active if state[g] == 1]
+    return dict(steps=steps, iters=iters, ms=round(ms), nodes=nodes, pauses=npause, resumes=nresume, tentative_nodes_per_poll=tent_work // max(polls, 1))
+
+
+if __name__ == "__main__":
+    print("base", simulate())
+    for look0, pct, win in ((128, 50, 768), (256, 100, 1536), (512, 200, 1536), (1024, 400, 3072), (2048, 1000, 4096)):
+        for every in (1, 4):
+            print("tentative look max(%d, %d%%) window %d every %d:" % (look0, pct, win, every), simulate(window=win, look0=look0, look_pct=pct, tentative=True, every=every), flush=True)

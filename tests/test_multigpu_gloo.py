@@ -113,9 +113,10 @@ def workload():
     return _workload(n_seeds=14)
 
 
+@pytest.mark.parametrize("tentative", [True, False])
 @pytest.mark.parametrize("world,window,poll,block,groups", [(1, 768, 4, 0, 1), (1, 4, 1, 0, 1), (1, 8, 2, 0, 2), (2, 6, 2, 1024, 1), (3, 4, 3, 700, 1),
-                                                            (4, 768, 4, 0, 1), (2, 8, 1, 4096, 2)])
-def test_playback_logical_ranks(workload, world, window, poll, block, groups):
+                                                            (4, 768, 4, 0, 1), (2, 8, 1, 4096, 2), (1, 768, 1, 0, 2), (2, 768, 2, 0, 3)])
+def test_playback_logical_ranks(workload, world, window, poll, block, groups, tentative):
     from pnr_amd import lib, multigpu
     W = workload
     lookup = lambda q6: W["traces"][np.asarray(q6, np.float32).tobytes()]
@@ -125,7 +126,7 @@ def test_playback_logical_ranks(workload, world, window, poll, block, groups):
     def run(r):
         try:
             out[r] = lib.sched_playback(W["p"], W["img"].shape, W["seeds"], lookup, r, world, X.callback(r) if world > 1 else None,
-                                        block_bytes=block, window=window, poll=poll, groups=groups)
+                                        block_bytes=block, window=window, poll=poll, groups=groups, tentative=tentative)
         except Exception as e:  # noqa: BLE001
             out[r] = e
             X.barrier.abort()
