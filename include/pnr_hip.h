@@ -267,7 +267,7 @@ int pnr_get_table(pnr_ctx *ctx, const char *name, void *out, int64_t cap, int64_
 int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
 
 /* Scheduling and host-side knobs of a context; none of them changes a result (the library reads no environment variable).
- *   window (768) trace slots kept busy | look0, look_pct (0 / -1 = automatic) admission lookahead max(look0, frontier*look_pct/100)
+ *   window (0 = automatic: 1536 on one GPU, 768 sharded or without the tentative replay) trace slots kept busy | look0, look_pct (0 / -1 = automatic) admission lookahead max(look0, frontier*look_pct/100)
  *   poll (4) SMC steps between polls | groups (2; 1..4) trace groups on separate streams | split_x10 (0 = automatic), max_split (24) sampling
  *   work-groups per CU x 10 / per trace | stash_mb (65536) sample-stash budget | host_threads (0 = CPUs of this process /
  *   local_ranks) workers of the seed flood fill and of pnr_reconstruct_ctx | local_ranks (1) processes sharing this host |

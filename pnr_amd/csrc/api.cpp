@@ -806,7 +806,7 @@ int pnr_sched_playback2(const pnr_params *p, int64_t w, int64_t h, int64_t l, co
 namespace {
 struct OptEntry { const char *key; int pnr::Options::*i32; int64_t pnr::Options::*i64; int64_t lo, hi; };
 const OptEntry OPTS[] = {
-    {"window", &pnr::Options::window, nullptr, 2, 1 << 20},      {"look0", &pnr::Options::look0, nullptr, 0, 1 << 24},
+    {"window", &pnr::Options::window, nullptr, 0, 1 << 20},      {"look0", &pnr::Options::look0, nullptr, 0, 1 << 24},
     {"look_pct", &pnr::Options::look_pct, nullptr, -1, 100000},   {"poll", &pnr::Options::poll, nullptr, 1, 1024},
     {"groups", &pnr::Options::groups, nullptr, 1, 4},            {"split_x10", &pnr::Options::split_x10, nullptr, 0, 10000},
     {"max_split", &pnr::Options::max_split, nullptr, 1, 4096},   {"stash_mb", nullptr, &pnr::Options::stash_mb, 1, 1 << 20},

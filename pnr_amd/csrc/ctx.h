@@ -57,7 +57,7 @@ int gaussian_taps(float sig, std::vector<float> &g); // returns radius L
 
 // scheduler / host-side knobs of one context (pnr_set_option); none of them changes a result
 struct Options {
-    int window = 768;         // trace slots the streaming tracer keeps busy
+    int window = 0;           // trace slots the streaming tracer keeps busy (0: automatic -- 1536 on one GPU with the tentative replay, 768 otherwise)
     int look0 = 0, look_pct = -1; // admission lookahead max(look0, frontier * look_pct / 100); 0 / -1 = automatic (stream_sched.h)
     int poll = 4;             // SMC steps between two polls
     int groups = 2;           // trace groups on separate streams (2: one group's ordered sums overlap the other's sampling)

@@ -59,16 +59,18 @@ static bool shm_barrier(pnr_shm_exchange *x)
         h->phase.store(gen + 1, std::memory_order_release);
         return true;
     }
-    // a short spin (an exchange between ranks in step takes microseconds), then sleep in growing slices: a rank that waits for a
-    // slower one must not burn the core its own host threads were counted on (host_threads = CPUs / local_ranks)
+    // Spin for about a quarter of a millisecond (ranks in step meet within microseconds, and an exchange happens every millisecond
+    // or two: a sleeping rank's wake-up latency would be paid by everybody at the NEXT barrier -- measured: naps that grew to 0.5 ms
+    // doubled the tracing time of 8 emulated ranks), then sleep in short slices: a rank that waits for a much slower one must not
+    // burn the core its own host threads were counted on (host_threads = CPUs / local_ranks).
     const auto t0 = std::chrono::steady_clock::now();
-    int64_t nap_us = 20;
     for (uint64_t spins = 0; h->phase.load(std::memory_order_acquire) == gen; spins++) {
         if (h->failed.load(std::memory_order_relaxed)) return false;
-        if (spins < 4096) continue;
-        std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
-        if (nap_us < 500) nap_us += nap_us / 2;
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > x->timeout_s) {
+        if ((spins & 255) != 255) { __builtin_ia32_pause(); continue; }
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited < 250e-6) continue;
+        std::this_thread::sleep_for(std::chrono::microseconds(waited < 5e-3 ? 20 : 200));
+        if (waited > x->timeout_s) {
             h->failed.store(1, std::memory_order_relaxed);
             return false;
         }

@@ -33,6 +33,7 @@
 #pragma once
 #include "replay.h"
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -41,9 +42,10 @@
 namespace pnr {
 
 struct SchedOptions {
-    int window = 768;  // trace slots kept busy on this rank
+    int window = 1536; // trace slots kept busy on this rank
     int look0 = 0;     // seeds admitted at most max(look0, frontier * look_pct / 100) ranks beyond the replay frontier;
-    int look_pct = -1; // look0 = 0 / look_pct < 0: automatic, max(128, 64 * world) / min(400, 50 * world) (scripts/sim_sharded.py)
+    int look_pct = -1; // look0 = 0 / look_pct < 0: automatic -- max(256, 100 %) on one GPU with the tentative replay (measured: the pauses make a
+                       // wider lookahead affordable), max(128, 64 * world) / min(400, 50 * world) otherwise (scripts/sim_sharded.py)
     int poll = 4;      // SMC steps between two polls
     int groups = 2;    // trace groups stepping independently (engine permitting)
     int tentative = 1; // pause traces that a tentative replay of everything recorded so far cuts (see above)
@@ -60,6 +62,7 @@ struct ShardSpec {
 struct SchedStats {
     int64_t steps = 0, polls = 0, iters = 0, exchanges = 0, carried = 0, launched = 0, skipped = 0;
     int64_t paused = 0, resumed = 0, ended = 0, tent_nodes = 0, tent_passes = 0; // tentative replay
+    double tent_ms = 0, wait_ms = 0;                                               // host time in it / blocked in E.wait()
 };
 
 class StreamEngine {
@@ -176,8 +179,8 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     const int world = std::max(1, sh.world), rank = sh.rank;
     if (world > 1 && !sh.exchange) { err = "sharded tracing needs an exchange callback"; return PNR_E_ARG; }
     if (rank < 0 || rank >= world) { err = "rank out of range"; return PNR_E_ARG; }
-    if (o.look0 <= 0) o.look0 = std::max(128, 64 * world);
-    if (o.look_pct < 0) o.look_pct = std::min(400, 50 * world);
+    if (o.look0 <= 0) o.look0 = (world == 1 && o.tentative) ? 256 : std::max(128, 64 * world);
+    if (o.look_pct < 0) o.look_pct = (world == 1 && o.tentative) ? 100 : std::min(400, 50 * world);
     o.poll = std::max(1, o.poll);
     const int NT = E.slots() - (E.slots() & 1);
     if (NT < 2) { err = "no trace slots"; abort_exchange(sh, ni); return PNR_E_STATE; }
@@ -208,7 +211,10 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     int64_t max_known = -1;                               // highest seed any record or admission has touched
     Overlay ov;
     std::vector<int> pause_list, resume_list;
-    const bool tentative = o.tentative != 0;
+    // Sharded, a rank only knows its OWN running traces, so a paused trace waits for the frontier to reach it, one exchange per seed:
+    // measured on 8 emulated ranks, that serialisation costs twice what the pauses save (944 against 468 ms).  Until paused traces
+    // publish their records (what comes next), the tentative replay runs on one GPU only.
+    const bool tentative = o.tentative != 0 && world == 1;
     std::vector<int> new_slots;
     std::vector<float> new_s6;
     int64_t next = rank, frontier = 0;
@@ -292,7 +298,9 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
         Grp &q = grp[(size_t)g];
         // ---- the group's last poll: which of its traces have stopped?
         if (q.inflight) {
+            const auto tw0 = std::chrono::steady_clock::now();
             rc = E.wait(g, &q.active);
+            st.wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
             if (rc) { err = E.error(); return fail(rc); }
             q.inflight = false;
             st.polls++;
@@ -347,6 +355,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             // ---- tentative replay of everything known beyond the frontier (see the head of this file): pause / resume / end the
             // traces of THIS group (its staging buffers are free: its last steps have just been waited for)
             if (tentative && !r.stopped && frontier < n) {
+                const auto tt0 = std::chrono::steady_clock::now();
                 bool ended_any = false;
                 pause_list.clear(); resume_list.clear(); // what this turn asks of the engine, sent once after the last round
                 auto want_pause = [&](int slot) { // (a resume asked for earlier in this turn is simply taken back: the trace never left the device's list)
@@ -429,6 +438,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                     if (q.active < 0) q.active = 0;
                     idle_turns = 0;
                 }
+                st.tent_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count();
             }
             if (!r.touched.empty()) {
                 rc = E.density_update(r, G > 1);
@@ -505,10 +515,10 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     E.drain(); // what is still running is never looked at again, but it writes into buffers that outlive this call
     if (o.timing)
         fprintf(stderr, "[pnr trace] rank %d/%d: %lld seeds, window %d slots, lookahead max(%d, %d%%), %lld steps, %lld polls, %lld iterations here, "
-                        "%lld exchanges (%lld carried), %zu nodes; tentative replay: %lld passes, %lld nodes, %lld pauses, %lld resumed, %lld ended by the host\n",
+                        "%lld exchanges (%lld carried), %zu nodes; tentative replay: %lld passes, %lld nodes, %lld pauses, %lld resumed, %lld ended by the host, %.1f ms of host time; %.1f ms blocked waiting for the GPU\n",
                 rank, world, (long long)n, NT, o.look0, o.look_pct, (long long)st.steps,
                 (long long)st.polls, (long long)st.iters, (long long)st.exchanges, (long long)st.carried, r.nodes.size(), (long long)st.tent_passes,
-                (long long)st.tent_nodes, (long long)st.paused, (long long)st.resumed, (long long)st.ended);
+                (long long)st.tent_nodes, (long long)st.paused, (long long)st.resumed, (long long)st.ended, st.tent_ms, st.wait_ms);
     if (stats) *stats = st;
     return PNR_OK;
 }
