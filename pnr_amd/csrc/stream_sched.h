@@ -191,6 +191,8 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     struct SeedRec {
         uint8_t have = 0;      // directions whose record has arrived
         uint8_t got = 0;       // ... which ones (bit = direction)
+        uint8_t part = 0;      // directions whose trace is PAUSED on its rank and has published what it recorded (prow rows in xc)
+        int32_t prow[2] = {0, 0};
         bool skipped = false;  // sits on a saturated voxel: never traced (:2669-2670)
         int32_t T[2] = {0, 0};
         std::vector<pnr_xest> xc; // [2][ni], allocated when the first record arrives, dropped after the replay
@@ -211,17 +213,28 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     int64_t max_known = -1;                               // highest seed any record or admission has touched
     Overlay ov;
     std::vector<int> pause_list, resume_list;
-    // Sharded, a rank only knows its OWN running traces, so a paused trace waits for the frontier to reach it, one exchange per seed:
-    // measured on 8 emulated ranks, that serialisation costs twice what the pauses save (944 against 468 ms).  Until paused traces
-    // publish their records (what comes next), the tentative replay runs on one GPU only.
-    const bool tentative = o.tentative != 0 && world == 1;
+    // Sharded, a rank only knows its OWN running traces; a trace it pauses therefore PUBLISHES the rows it has (record codes 2 / 3), so
+    // that every rank's tentative replay runs through it and all of them end it in the same turn once the verdict is final.  (Without
+    // that a paused trace waits for the frontier to reach it, one exchange per seed: measured on 8 emulated ranks, 944 against 468 ms.)
+    const bool tentative = o.tentative != 0;
     std::vector<int> new_slots;
     std::vector<float> new_s6;
     int64_t next = rank, frontier = 0;
 
-    // ---- records: [seed, dir (-1 = skipped), T, rows] + rows x 8 floats, as 32-bit words
+    // ---- records: [seed, code, T, rows] + rows x 8 floats, as 32-bit words.  code: 0 / 1 the final record of that direction, -1 the
+    // seed was skipped, 2 / 3 the trace of direction code - 2 is PAUSED on its rank and these are the rows it has (sharded: every
+    // rank can then follow the tentative replay through it, and end it in the same turn as its owner once the verdict is final),
+    // 4 / 5 that trace runs again (the rows are withdrawn)
     std::vector<int32_t> outbox; // finished on this rank, not yet applied / sent
     size_t out_head = 0;
+    auto publish = [&](int64_t s, int code, const pnr_xest *X, int nr) { // a record for the other ranks (no-op on one GPU)
+        if (world <= 1) return;
+        const size_t at = outbox.size();
+        outbox.resize(at + 4 + (size_t)nr * 8);
+        outbox[at] = (int32_t)s; outbox[at + 1] = code; outbox[at + 2] = nr; outbox[at + 3] = nr;
+        if (nr > 0) std::memcpy(&outbox[at + 4], X, (size_t)nr * sizeof(pnr_xest));
+    };
+
     const int64_t block = exchange_block_bytes(sh.block_bytes, world, ni);
     const size_t block_words = (size_t)block / 4;
     std::vector<int32_t> sendbuf, recvbuf;
@@ -232,18 +245,30 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
         while (k < nw) {
             if (k + 4 > nw) return false;
             const int64_t s = w[k];
-            const int dir = w[k + 1], Tn = w[k + 2], rows = w[k + 3];
-            if (s < 0 || s >= n || rows < 0 || rows > ni || k + 4 + (size_t)rows * 8 > nw) return false;
+            const int code = w[k + 1], Tn = w[k + 2], rows = w[k + 3];
+            if (s < 0 || s >= n || rows < 0 || rows > ni || k + 4 + (size_t)rows * 8 > nw || code < -1 || code > 5) return false;
             SeedRec &sr = rec[(size_t)s];
-            if (dir < 0) {
+            const int dir = code & 1;
+            if (code < 0) {
                 sr.skipped = true;
-            } else {
-                if (dir > 1 || sr.have >= 2 || (sr.got >> dir & 1)) return false;
+            } else if (sr.got >> dir & 1) {
+                // this rank has already concluded the trace from its published rows (the tentative replay's verdict was final): what
+                // its owner sends afterwards says the same
+            } else if (code <= 1) {
+                if (sr.have >= 2) return false;
                 if (sr.xc.empty()) sr.xc.resize((size_t)2 * ni);
                 sr.T[dir] = Tn;
                 if (rows > 0) std::memcpy(sr.xc.data() + (size_t)dir * ni, w + k + 4, (size_t)rows * sizeof(pnr_xest));
                 sr.have++;
                 sr.got |= (uint8_t)(1 << dir);
+                sr.part &= (uint8_t)~(1 << dir);
+            } else if (code <= 3) {
+                if (sr.xc.empty()) sr.xc.resize((size_t)2 * ni);
+                if (rows > 0) std::memcpy(sr.xc.data() + (size_t)dir * ni, w + k + 4, (size_t)rows * sizeof(pnr_xest));
+                sr.prow[dir] = rows;
+                sr.part |= (uint8_t)(1 << dir);
+            } else {
+                sr.part &= (uint8_t)~(1 << dir);
             }
             if (s > max_known) max_known = s;
             k += 4 + (size_t)rows * 8;
@@ -383,8 +408,10 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                             const bool done = (sr.got >> dir & 1) != 0;
                             const pnr_xest *X = nullptr;
                             int nr = 0;
+                            const bool remote_paused = !done && slot < 0 && (sr.part >> dir & 1); // paused on its rank, rows published
                             if (done) { X = sr.xc.data() + (size_t)dir * ni; nr = std::min(sr.T[dir], ni); }
                             else if (slot >= 0) { X = E.rows(slot); nr = std::min(std::max(E.progress(slot_group[(size_t)slot], slot), 0), ni); }
+                            else if (remote_paused) { X = sr.xc.data() + (size_t)dir * ni; nr = std::min(sr.prow[dir], ni); }
                             else { exact = false; continue; } // running elsewhere, or its record is on its way: nothing known
                             int cut = seed_sat ? 0 : -1;
                             for (int i = 0; cut < 0 && i < nr; i++) {
@@ -399,6 +426,13 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                                 }
                             }
                             if (done) continue;
+                            if (remote_paused) {
+                                // every seed in front complete and the published rows cut: the verdict is final for every rank alike -- the
+                                // trace is complete with the rows it has (its owner ends it in its own pass and says so; that record is ignored)
+                                if (exact && cut >= 0) { sr.T[dir] = nr; sr.got |= (uint8_t)(1 << dir); sr.part &= (uint8_t)~(1 << dir); sr.have++; ended_any = true; }
+                                else exact = false;
+                                continue;
+                            }
                             const bool here = slot_group[(size_t)slot] == g; // (another group's staging may still be in use: it acts in its own turn)
                             if (cut >= 0) {
                                 if (exact && here) { // not tentative: this IS the final replay's verdict -- end the trace, deliver its record
@@ -416,18 +450,23 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                                     free_slots.push_back(slot); // (control() takes it off the device's list before this turn's admissions)
                                     ended_any = true;
                                 } else {
-                                    if (here && !slot_paused[(size_t)slot]) { want_pause(slot); slot_paused[(size_t)slot] = 1; q.npaused++; st.paused++; }
+                                    if (here && !slot_paused[(size_t)slot]) {
+                                        want_pause(slot); slot_paused[(size_t)slot] = 1; q.npaused++; st.paused++;
+                                        publish(s, 2 + dir, X, nr);
+                                    }
                                     exact = false;
                                 }
                             } else {
-                                if (here && slot_paused[(size_t)slot]) { want_resume(slot); slot_paused[(size_t)slot] = 0; q.npaused--; st.resumed++; }
+                                if (here && slot_paused[(size_t)slot]) { want_resume(slot); slot_paused[(size_t)slot] = 0; q.npaused--; st.resumed++; publish(s, 4 + dir, nullptr, 0); }
                                 exact = false; // still running: what it will add is not known
                             }
                         }
                     }
-                    if (!(ended_any && world == 1)) break;
-                    if (!apply(outbox.data(), outbox.size())) { err = "malformed trace record"; return fail(PNR_E_STATE); }
-                    outbox.clear();
+                    if (!ended_any) break;
+                    if (world == 1) { // (sharded, what this rank ended itself comes back with the next exchange)
+                        if (!apply(outbox.data(), outbox.size())) { err = "malformed trace record"; return fail(PNR_E_STATE); }
+                        outbox.clear();
+                    }
                     final_replay();
                     if (r.stopped || frontier >= n) break;
                 }
