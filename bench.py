@@ -353,10 +353,16 @@ def main():
             tpath = os.path.join(ROOT, "profiles", cand if a.driver == "phased" else "r01_traffic_1024_s2000.json")
             if S == 1024 and a.seeds == 2000 and a.np == 200 and a.ni == 200 and not a.one_shot and world == 1 and os.path.exists(tpath):
                 tj = json.load(open(tpath))
+                # the profile was taken with one trace group (no two kernels overlap while the counters run): its launches hold more
+                # traces than this run's when the groups differ -- scale by the SMC iterations per launch (bytes per trace-iteration are
+                # what the kernels' traffic is made of)
+                it_prof = tj.get("workload", {}).get("smc_iterations")
+                st_prof = tj.get("workload", {}).get("smc_steps")
+                scale = ((st["iters"] * a.steps / steps_smc) / (it_prof / st_prof)) if (it_prof and st_prof) else 1.0
                 for key in (("ph_predict", "ph_sample", "ph_sums", "ph_update") if a.driver == "phased" else ("smc_trace",)):
                     e = tj.get(key, {})
                     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
-                        traffic_k[key] = e["FETCH_SIZE"]["bytes_per_launch"] + e["WRITE_SIZE"]["bytes_per_launch"]
+                        traffic_k[key] = (e["FETCH_SIZE"]["bytes_per_launch"] + e["WRITE_SIZE"]["bytes_per_launch"]) * scale
                 if ("ph_sample" in traffic_k and "ph_sums" in traffic_k) or "smc_trace" in traffic_k:
                     traffic = sum(traffic_k.values())
                     traffic_src = "profiles/" + os.path.basename(tpath)
@@ -399,9 +405,13 @@ def main():
                 "time_base": (f"wall time of the tracing stage / SMC steps ({groups} trace groups on separate streams: launches overlap, host replay and polls included)"
                               if overlapped else "summed device time of the four launches of a step (HIP events on the launching stream)"),
                 "device_ms_per_stack": smc_all_ms / a.steps, "Mevals_per_s": bytes_total / (8.0 * Mtot) / (step_ms * steps_smc) / 1e3 if step_ms > 0 else None,
+                # speculation: the streaming scheduler runs more SMC iterations than the sequential reference needs for the same graph
+                # (one per node + the stopping iteration of every trace); `frac` prices every iteration that was run
+                "iterations_run": st["iters"], "iterations_needed_sequentially": st["nodes"] + 2 * st["traces_used"],
+                "frac_of_needed_work": achieved / HBM_PEAK_GBS * min(1.0, (st["nodes"] + 2 * st["traces_used"]) / max(st["iters"], 1)),
                 "note": "ALGORITHMIC bytes of the whole particle evaluation (znccBBB, tracker.cpp:1891-1964: gather AND ordered sums): 8*sum(M_sigma)=%d B per "
                         "evaluation x (np+1) evaluations x the trace-iterations of a step, over the duration of the step; `traffic` = real HBM bytes per step (PMC, "
-                        "sum over the kernels) read from the committed profile named in traffic_source, not measured in this run" % (8 * Mtot)},
+                        "sum over the kernels) read from the committed profile named in traffic_source (scaled to this run's trace-iterations per launch), not measured in this run" % (8 * Mtot)},
             "roofline_sample": kernel_block("smc", bytes_total, "the gather half alone: the evaluation's algorithmic gather bytes over the sampling kernel's own launch time (served from the LDS cube: VALU / LDS bound, not HBM)"),
             "roofline_sums": None if a.driver != "phased" else kernel_block("smc_sums", stash_bytes, "ordered sums alone against their REAL stash bytes: every stashed f32 sample is streamed twice (mean, then corr), 2 x 4 x sum(M) x %d B per SMC iteration -- an upper bound, exact duplicate poses are evaluated once" % stash_row_floats(a.np)),
             "roofline_frangi": None if not fr_vox or fr_ms <= 0 else {
