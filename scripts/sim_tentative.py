@@ -31,7 +31,13 @@ A_MS, C_MS = 0.30, 0.0075
 INF = 1 << 30
 
 
-def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=1, a_ms=A_MS, c_ms=C_MS, margin=0, hold_seeds=True):
+BLK = 8
+def block_of(v):
+    x = v % S; y = (v // S) % S; z = v // (S * S)
+    return ((z // BLK) * (S // BLK) + (y // BLK)) * (S // BLK) + (x // BLK)
+
+
+def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=1, a_ms=A_MS, c_ms=C_MS, margin=0, hold_seeds=True, far=0, far_max=0):
     den = {}
     it = [0] * (2 * n)
     state = [0] * (2 * n)  # 0 not admitted, 1 running, 2 stopped, 3 paused, 4 skipped
@@ -43,6 +49,9 @@ def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=
     held = set()          # seeds not admitted because their voxel is tentatively saturated
     npause = nresume = 0
     tent_work = 0
+    blocks = set()       # 8^3 blocks that hold a node of any admitted trace (maintained from the records at every poll)
+    far_started = set()
+    seen = [0] * (2 * n)
     while frontier < n:
         lim = frontier + max(look0, frontier * look_pct // 100)
         # admission: rank order, seeds on tentatively saturated voxels wait (they are looked at again at every poll)
@@ -57,6 +66,23 @@ def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=
                         active.append(g)
             s += 1
         nxt = max(nxt, s)
+        # far admission: seeds beyond the lookahead whose 8^3 block holds no node yet (final, tentative or of a started seed): nobody in
+        # front of them has been there, so their traces are likely to be needed in full -- start them early (at most `far` per poll)
+        if far and tentative:
+            occ = getattr(simulate, "_occ", None)
+            got = 0
+            s2 = nxt
+            while got < far and s2 < min(n, frontier + far_max) and len(active) + len(paused) + 2 <= window:
+                if state[2 * s2] == 0 and s2 not in held:
+                    b = block_of(svox[s2])
+                    if b not in blocks:
+                        for g in (2 * s2, 2 * s2 + 1):
+                            state[g] = 1
+                            active.append(g)
+                        blocks.add(b)
+                        far_started.add(s2)
+                        got += 1
+                s2 += 1
         for _ in range(poll):
             if not active:
                 break
@@ -75,6 +101,13 @@ def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=
         if not active and not paused and not held and nxt >= n and all(state[2 * q] != 1 for q in range(frontier, n)):
             pass
         polls += 1
+        if far:
+            for g in range(2 * frontier, 2 * n):
+                if state[g] in (1, 2, 3) and seen[g] < min(it[g], Tl[g]):
+                    row = voxl[g]
+                    for i in range(seen[g], min(it[g], Tl[g])):
+                        blocks.add(block_of(row[i]))
+                    seen[g] = min(it[g], Tl[g])
         # ---- final replay, seed-granular as in stream_sched.h
         while frontier < n:
             a = 2 * frontier
@@ -140,7 +173,8 @@ def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=
             continue
         # ---- tentative replay of everything admitted and unreplayed, in rank order, on top of the final map
         tden = {}
-        for s in range(frontier, nxt):
+        hi = max(nxt, max(far_started) + 1) if far_started else nxt
+        for s in range(frontier, hi):
             a = 2 * s
             if state[a] == 4:
                 continue
@@ -178,6 +212,8 @@ def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=
 
 if __name__ == "__main__":
     print("base", simulate())
+    for far, fmax in ((4, 2000), (8, 2000), (16, 2000), (8, 800)):
+        print("far", far, fmax, simulate(window=1536, look0=256, look_pct=100, tentative=True, far=far, far_max=fmax), flush=True)
     for look0, pct, win in ((128, 50, 768), (256, 100, 1536), (512, 200, 1536), (1024, 400, 3072), (2048, 1000, 4096)):
         for every in (1, 4):
             print("tentative look max(%d, %d%%) window %d every %d:" % (look0, pct, win, every), simulate(window=win, look0=look0, look_pct=pct, tentative=True, every=every), flush=True)
