@@ -209,6 +209,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     std::vector<int64_t> slot_seed((size_t)NT, -1);
     std::vector<int> slot_dir((size_t)NT, 0), slot_group((size_t)NT, -1);
     std::vector<uint8_t> slot_paused((size_t)NT, 0);
+    std::vector<uint8_t> slot_fresh((size_t)NT, 0); // admitted since its group was last waited for: the engine's view of the slot is still the previous occupant's
     std::vector<int32_t> seed_slot((size_t)(2 * n), -1); // slot of trace (seed, direction) while it runs on this rank
     int64_t max_known = -1;                               // highest seed any record or admission has touched
     Overlay ov;
@@ -329,6 +330,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             if (rc) { err = E.error(); return fail(rc); }
             q.inflight = false;
             st.polls++;
+            for (int slot : q.busy) slot_fresh[(size_t)slot] = 0;
             size_t keep = 0;
             for (size_t b = 0; b < q.busy.size(); b++) {
                 const int slot = q.busy[b];
@@ -410,7 +412,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                             int nr = 0;
                             const bool remote_paused = !done && slot < 0 && (sr.part >> dir & 1); // paused on its rank, rows published
                             if (done) { X = sr.xc.data() + (size_t)dir * ni; nr = std::min(sr.T[dir], ni); }
-                            else if (slot >= 0) { X = E.rows(slot); nr = std::min(std::max(E.progress(slot_group[(size_t)slot], slot), 0), ni); }
+                            else if (slot >= 0) { X = E.rows(slot); nr = slot_fresh[(size_t)slot] ? 0 : std::min(std::max(E.progress(slot_group[(size_t)slot], slot), 0), ni); }
                             else if (remote_paused) { X = sr.xc.data() + (size_t)dir * ni; nr = std::min(sr.prow[dir], ni); }
                             else { exact = false; continue; } // running elsewhere, or its record is on its way: nothing known
                             int cut = seed_sat ? 0 : -1;
@@ -510,7 +512,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             for (int dir = 0; dir < 2; dir++) {
                 const int slot = free_slots.back();
                 free_slots.pop_back();
-                slot_seed[(size_t)slot] = next; slot_dir[(size_t)slot] = dir; slot_group[(size_t)slot] = g; slot_paused[(size_t)slot] = 0;
+                slot_seed[(size_t)slot] = next; slot_dir[(size_t)slot] = dir; slot_group[(size_t)slot] = g; slot_paused[(size_t)slot] = 0; slot_fresh[(size_t)slot] = 1;
                 seed_slot[(size_t)(2 * next + dir)] = slot;
                 q.busy.push_back(slot);
                 new_slots.push_back(slot);
