@@ -291,3 +291,76 @@ def test_sharded_trace_over_the_shared_memory_exchange():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res) and sum(it for _, _, it in res) > 10
+
+
+def _random_workload(rs, n_seeds, ni, shape, npv, vol):
+    """synthetic map-free traces: random walks with ~2-voxel steps in a small volume, so that traces cross, saturate voxels and cut
+    each other all the time -- the scheduler's pause / resume / end paths get exercised far more densely than on a real stack"""
+    import pnr_amd
+    from pnr_amd import lib
+    l, h, w = shape
+    seeds = np.zeros(n_seeds, lib.SEED_DT)
+    seeds["x"] = rs.randint(2, w - 2, n_seeds); seeds["y"] = rs.randint(2, h - 2, n_seeds); seeds["z"] = rs.randint(1, l - 1, n_seeds)
+    d = rs.randn(n_seeds, 3).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    seeds["vx"], seeds["vy"], seeds["vz"] = d[:, 0], d[:, 1], d[:, 2]
+    seeds["corr"] = np.sort(rs.rand(n_seeds).astype(np.float32))[::-1]
+    traces, Ts, xcs = {}, [], []
+    for sd in seeds:
+        for sgn in (1.0, -1.0):
+            q6 = np.array([sd["x"], sd["y"], sd["z"], sgn * sd["vx"], sgn * sd["vy"], sgn * sd["vz"]], np.float32)
+            Tn = int(rs.choice([0, 1, 2, ni // 2, ni, ni, ni]))  # ni = "never failed"
+            pos = np.array([sd["x"], sd["y"], sd["z"]], np.float32)
+            v = q6[3:].copy()
+            xc = np.zeros((ni, 8), np.float32)
+            for i in range(ni):
+                v = v + 0.4 * rs.randn(3).astype(np.float32)
+                v /= np.linalg.norm(v)
+                pos = np.clip(pos + 2.0 * v, 0, [w - 1, h - 1, l - 1]).astype(np.float32)
+                xc[i] = [pos[0], pos[1], pos[2], v[0], v[1], v[2], 2.0, 0.5 + 0.4 * rs.rand()]
+            traces[q6.tobytes()] = (Tn, xc)
+            Ts.append(Tn)
+            xcs.append(xc)
+    p = pnr_amd.make_params(sigmas=[2.0], np_=8, ni=ni, nodepervol=npv, vol=vol)
+    Tf = np.array(Ts, np.int32)
+    xcf = np.stack(xcs).astype(np.float32)
+    n1, l1, _ = lib.replay(p, shape, seeds, Tf, xcf.view(lib.XEST_DT).reshape(len(Tf), ni))
+    return dict(shape=shape, seeds=seeds, traces=traces, p=p, nodes=n1, links=l1, ni=ni, total_free=int(np.minimum(Tf + 1, ni).sum()))
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_scheduler_random_crossing_traces(case):
+    """randomised stress of the streaming scheduler on the host play-back engine: crowded synthetic traces, random window / lookahead /
+    polling period / trace groups / world, the tentative replay on and off -- every rank must end with the node graph of the one-shot
+    replay of the map-free traces, and with no more iterations than they hold"""
+    from pnr_amd import lib, multigpu
+    rs = np.random.RandomState(7000 + case)
+    ni = int(rs.choice([6, 12, 25]))
+    W = _random_workload(rs, n_seeds=int(rs.choice([8, 20, 40])), ni=ni, shape=(int(rs.choice([6, 10])), 16, 20), npv=int(rs.choice([1, 2, 3])), vol=int(rs.choice([1, 5])))
+    lookup = lambda q6: W["traces"][np.asarray(q6, np.float32).tobytes()]
+    world = int(rs.choice([1, 1, 2, 3]))
+    kw = dict(window=int(rs.choice([2, 4, 8, 64, 768])), poll=int(rs.choice([1, 2, 5])), groups=int(rs.choice([1, 2, 3])), look0=int(rs.choice([0, 1, 3, 16])),
+              look_pct=int(rs.choice([-1, 0, 50, 400])), block_bytes=int(rs.choice([0, 900, 4096])))
+    iters = {}
+    for tentative in (True, False):
+        X = multigpu.ThreadExchange(world)
+        out = [None] * world
+
+        def run(r):
+            try:
+                out[r] = lib.sched_playback(W["p"], W["shape"], W["seeds"], lookup, r, world, X.callback(r) if world > 1 else None, tentative=tentative, **kw)
+            except Exception as e:  # noqa: BLE001
+                out[r] = e
+                X.barrier.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+            assert not t.is_alive(), (case, world, kw, tentative)
+        for r in range(world):
+            assert not isinstance(out[r], Exception), (case, world, kw, tentative, out[r])
+            assert _same_graph(out[r][0], out[r][1], W), (case, world, kw, tentative, r)
+        iters[tentative] = sum(o[3] for o in out)
+        assert iters[tentative] <= W["total_free"]
