@@ -214,26 +214,32 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     int64_t max_known = -1;                               // highest seed any record or admission has touched
     Overlay ov;
     std::vector<int> pause_list, resume_list;
-    // Sharded, a rank only knows its OWN running traces; a trace it pauses therefore PUBLISHES the rows it has (record codes 2 / 3), so
-    // that every rank's tentative replay runs through it and all of them end it in the same turn once the verdict is final.  (Without
-    // that a paused trace waits for the frontier to reach it, one exchange per seed: measured on 8 emulated ranks, 944 against 468 ms.)
+    // Sharded, a rank only knows its OWN running traces; every rank therefore PUBLISHES what its unfinished traces have recorded since
+    // the last exchange (record codes 2 / 3: a few KB per rank and exchange), so that every rank's tentative replay sees all traces
+    // and all of them end a trace in the same turn as its owner once the verdict is final.  (Without that a paused trace waits for
+    // the frontier to reach it, one exchange per seed: measured on 8 emulated ranks, 944 against 468 ms.)
     const bool tentative = o.tentative != 0;
     std::vector<int> new_slots;
     std::vector<float> new_s6;
     int64_t next = rank, frontier = 0;
 
     // ---- records: [seed, code, T, rows] + rows x 8 floats, as 32-bit words.  code: 0 / 1 the final record of that direction, -1 the
-    // seed was skipped, 2 / 3 the trace of direction code - 2 is PAUSED on its rank and these are the rows it has (sharded: every
-    // rank can then follow the tentative replay through it, and end it in the same turn as its owner once the verdict is final),
-    // 4 / 5 that trace runs again (the rows are withdrawn)
+    // seed was skipped, 2 / 3 PROGRESS of the unfinished trace of direction code - 2: `rows` further estimates from iteration T on
+    // (sharded: every rank publishes what its running traces have recorded since the last exchange, so that every rank's tentative
+    // replay sees all traces, and all ranks end a trace in the same turn as its owner once the verdict is final), 4 / 5 reserved
     std::vector<int32_t> outbox; // finished on this rank, not yet applied / sent
     size_t out_head = 0;
-    auto publish = [&](int64_t s, int code, const pnr_xest *X, int nr) { // a record for the other ranks (no-op on one GPU)
+    std::vector<int32_t> slot_pub((size_t)NT, 0); // iterations of the slot's trace the other ranks have been told of
+    // sharded: tell the other ranks what the trace in `slot` has recorded since they were last told (no-op on one GPU)
+    auto publish_progress = [&](int slot, const pnr_xest *X, int nr) {
         if (world <= 1) return;
+        const int from = slot_pub[(size_t)slot];
+        if (nr <= from) return;
         const size_t at = outbox.size();
-        outbox.resize(at + 4 + (size_t)nr * 8);
-        outbox[at] = (int32_t)s; outbox[at + 1] = code; outbox[at + 2] = nr; outbox[at + 3] = nr;
-        if (nr > 0) std::memcpy(&outbox[at + 4], X, (size_t)nr * sizeof(pnr_xest));
+        outbox.resize(at + 4 + (size_t)(nr - from) * 8);
+        outbox[at] = (int32_t)slot_seed[(size_t)slot]; outbox[at + 1] = 2 + slot_dir[(size_t)slot]; outbox[at + 2] = from; outbox[at + 3] = nr - from;
+        std::memcpy(&outbox[at + 4], X + from, (size_t)(nr - from) * sizeof(pnr_xest));
+        slot_pub[(size_t)slot] = nr;
     };
 
     const int64_t block = exchange_block_bytes(sh.block_bytes, world, ni);
@@ -264,12 +270,11 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                 sr.got |= (uint8_t)(1 << dir);
                 sr.part &= (uint8_t)~(1 << dir);
             } else if (code <= 3) {
+                if (Tn < 0 || Tn + rows > ni) return false;
                 if (sr.xc.empty()) sr.xc.resize((size_t)2 * ni);
-                if (rows > 0) std::memcpy(sr.xc.data() + (size_t)dir * ni, w + k + 4, (size_t)rows * sizeof(pnr_xest));
-                sr.prow[dir] = rows;
+                if (rows > 0) std::memcpy(sr.xc.data() + (size_t)dir * ni + Tn, w + k + 4, (size_t)rows * sizeof(pnr_xest));
+                sr.prow[dir] = Tn + rows;
                 sr.part |= (uint8_t)(1 << dir);
-            } else {
-                sr.part &= (uint8_t)~(1 << dir);
             }
             if (s > max_known) max_known = s;
             k += 4 + (size_t)rows * 8;
@@ -283,6 +288,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     bool aborted = false;
     // one exchange: what fits of the outbox + this rank's busy / abort flags; *busy_all = ranks with traces in flight or records
     // still to send (the same number on every rank)
+    bool all_done = false; // every rank said, in the same exchange, that its replay has reached the end
     auto exchange = [&](int busy, int abort_flag, int *busy_all, int *abort_rank) -> int {
         size_t nw = 0;
         if (out_head < outbox.size()) busy = 1;
@@ -292,7 +298,10 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                 if (HDR_WORDS + nw + rw > block_words) break;
                 nw += rw;
             }
-        sendbuf[0] = (int32_t)nw; sendbuf[1] = busy; sendbuf[2] = abort_flag; sendbuf[3] = 0;
+        // word 3: this rank's replay is complete.  The ranks leave together, after an exchange in which ALL of them said so: with the
+        // tentative replay a rank can draw a final verdict a turn before the others, so "my frontier is at the end" is no longer
+        // something every rank reaches in the same turn
+        sendbuf[0] = (int32_t)nw; sendbuf[1] = busy; sendbuf[2] = abort_flag; sendbuf[3] = (frontier >= n || r.stopped) ? 1 : 0;
         if (nw) std::memcpy(sendbuf.data() + HDR_WORDS, outbox.data() + out_head, nw * 4);
         out_head += nw;
         if (out_head < outbox.size()) st.carried++;
@@ -301,10 +310,12 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
         st.exchanges++;
         if (xrc) { err = "exchange callback failed (" + std::to_string(xrc) + ")"; return PNR_E_STATE; }
         *busy_all = 0; *abort_rank = -1;
+        all_done = true;
         for (int q = 0; q < world; q++) {
             const int32_t *b = recvbuf.data() + (size_t)q * block_words;
-            if (b[2]) { *abort_rank = q; continue; }
+            if (b[2]) { *abort_rank = q; all_done = false; continue; }
             *busy_all += b[1] ? 1 : 0;
+            all_done = all_done && b[3] != 0;
             if (b[0] < 0 || (size_t)b[0] > block_words - HDR_WORDS || !apply(b + HDR_WORDS, (size_t)b[0])) {
                 err = "malformed trace records from rank " + std::to_string(q);
                 return PNR_E_STATE;
@@ -316,7 +327,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     // everybody (the last exchange has brought the frontier to the end, or MAX_TRACE_COUNT): then nobody exchanges again
     auto fail = [&](int code) -> int {
         E.drain();
-        if (world > 1 && !aborted && frontier < n && !r.stopped) { int b = 0, a = -1; std::string keep = err; (void)exchange(0, 1, &b, &a); err = keep; }
+        if (world > 1 && !aborted && !all_done) { int b = 0, a = -1; std::string keep = err; (void)exchange(0, 1, &b, &a); err = keep; }
         return code;
     };
 
@@ -358,11 +369,17 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                 if (!apply(outbox.data(), outbox.size())) { err = "malformed trace record"; return fail(PNR_E_STATE); }
                 outbox.clear();
             } else {
+                if (tentative)
+                    for (int k = 0; k < G; k++)
+                        for (int slot : grp[(size_t)k].busy)
+                            if (!slot_fresh[(size_t)slot] && !slot_paused[(size_t)slot])
+                                publish_progress(slot, E.rows(slot), std::min(std::max(E.progress(k, slot), 0), ni));
                 int busy = 0, abort_rank = -1;
                 for (int k = 0; k < G; k++) busy |= (grp[(size_t)k].inflight || grp[(size_t)k].active > 0 || grp[(size_t)k].npaused > 0) ? 1 : 0;
                 rc = exchange(busy, 0, &busy_all, &abort_rank);
                 if (rc) { aborted = true; return fail(rc); }
                 if (abort_rank >= 0) { aborted = true; err = "rank " + std::to_string(abort_rank) + " aborted the sharded trace"; return fail(PNR_E_STATE); }
+                if (all_done) break;
             }
             // ---- replay in seed order as far as the finished traces reach, push the new density to the engine
             r.touched.clear();
@@ -410,7 +427,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                             const bool done = (sr.got >> dir & 1) != 0;
                             const pnr_xest *X = nullptr;
                             int nr = 0;
-                            const bool remote_paused = !done && slot < 0 && (sr.part >> dir & 1); // paused on its rank, rows published
+                            const bool remote_paused = !done && slot < 0 && (sr.part >> dir & 1); // unfinished on its rank: the rows it has published
                             if (done) { X = sr.xc.data() + (size_t)dir * ni; nr = std::min(sr.T[dir], ni); }
                             else if (slot >= 0) { X = E.rows(slot); nr = slot_fresh[(size_t)slot] ? 0 : std::min(std::max(E.progress(slot_group[(size_t)slot], slot), 0), ni); }
                             else if (remote_paused) { X = sr.xc.data() + (size_t)dir * ni; nr = std::min(sr.prow[dir], ni); }
@@ -454,12 +471,12 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                                 } else {
                                     if (here && !slot_paused[(size_t)slot]) {
                                         want_pause(slot); slot_paused[(size_t)slot] = 1; q.npaused++; st.paused++;
-                                        publish(s, 2 + dir, X, nr);
+                                        publish_progress(slot, X, nr);
                                     }
                                     exact = false;
                                 }
                             } else {
-                                if (here && slot_paused[(size_t)slot]) { want_resume(slot); slot_paused[(size_t)slot] = 0; q.npaused--; st.resumed++; publish(s, 4 + dir, nullptr, 0); }
+                                if (here && slot_paused[(size_t)slot]) { want_resume(slot); slot_paused[(size_t)slot] = 0; q.npaused--; st.resumed++; }
                                 exact = false; // still running: what it will add is not known
                             }
                         }
@@ -485,8 +502,14 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                 rc = E.density_update(r, G > 1);
                 if (rc) { err = E.error(); return fail(rc); }
             }
-            if (r.stopped) break; // MAX_TRACE_COUNT (:2702): whatever is still running is never looked at
-            if (frontier >= n) break;
+            // MAX_TRACE_COUNT (:2702) or the last seed replayed: whatever is still running is never looked at.  (Sharded, this rank
+            // says so in its next exchange and leaves with the others.)
+            if (world == 1 && (r.stopped || frontier >= n)) break;
+        }
+        if (r.stopped || frontier >= n) { // (sharded, waiting for the others: nothing more to admit or to step)
+            if (world > 1 && !sync_turn) continue;
+            if (world > 1) { idle_turns = busy_all > 0 ? 0 : idle_turns + 1; if (idle_turns > STALL_TURNS) { E.drain(); err = "ranks did not finish together"; return PNR_E_STATE; } }
+            continue;
         }
         // ---- admission into this group: this rank's seeds inside the lookahead
         const int64_t lim = frontier + std::max<int64_t>(look0, frontier * look_pct / 100);
@@ -512,7 +535,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             for (int dir = 0; dir < 2; dir++) {
                 const int slot = free_slots.back();
                 free_slots.pop_back();
-                slot_seed[(size_t)slot] = next; slot_dir[(size_t)slot] = dir; slot_group[(size_t)slot] = g; slot_paused[(size_t)slot] = 0; slot_fresh[(size_t)slot] = 1;
+                slot_seed[(size_t)slot] = next; slot_dir[(size_t)slot] = dir; slot_group[(size_t)slot] = g; slot_paused[(size_t)slot] = 0; slot_fresh[(size_t)slot] = 1; slot_pub[(size_t)slot] = 0;
                 seed_slot[(size_t)(2 * next + dir)] = slot;
                 q.busy.push_back(slot);
                 new_slots.push_back(slot);
