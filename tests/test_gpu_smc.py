@@ -272,6 +272,40 @@ def test_streaming_scheduler_edge_cases(monkeypatch, smc_driver, window, look0, 
         assert nt2 == maxtr + 1  # the loop ends after the trace that exceeds the cap (:2702)
 
 
+@pytest.mark.parametrize("groups,poll", [(1, 4), (2, 4), (2, 1)])
+def test_tentative_replay_saves_iterations_not_results(smc_driver, groups, poll):
+    """stream_sched.h, option `tentative`: traces that a tentative replay of everything recorded so far cuts are paused, and ended by
+    the host once that verdict is final.  Crowded stack (thick tubes, many seeds on each): the graph is the one-shot graph with the
+    option on and off, the option saves SMC iterations, and ends traces itself (the log of trace ends names every replayed trace)."""
+    if smc_driver != "phased":
+        pytest.skip("the streaming scheduler belongs to the phased driver")
+    img = synth.synth(128, 112, 48, seed=8)
+    p = pnr_amd.make_params(sigmas=[2.0, 3.0], np_=64, ni=60, zdist=2.0, nodepervol=3, vol=1)
+    c = pnr_amd.Context(p, 0)
+    c.set_volume(img)
+    c.frangi()
+    seeds = c.score_filter_sort(c.extract_seeds())[:240]
+    assert len(seeds) > 100
+    T, stop, xc, _ = c.trace_batch(seeds)
+    n1, l1, nt1 = c.replay(seeds, T, xc)
+    free_iters = int((T + (T < p.ni)).sum())
+    c.set_option("groups", groups)
+    c.set_option("poll", poll)
+    c.set_option("trace_log", 1)
+    its = {}
+    for tent in (0, 1):
+        c.set_option("tentative", tent)
+        n2, l2, nt2, its[tent] = c.trace_replay(seeds)
+        assert nt1 == nt2 and len(n1) == len(n2) > 500 and np.array_equal(l1, l2), tent
+        for k in n1.dtype.names:
+            assert np.array_equal(n1[k], n2[k], equal_nan=True), (tent, k)
+        log = c.trace_log()
+        assert len(log) == 2 * nt2  # one record per replayed trace, whoever ended it
+    assert its[1] < its[0] <= free_iters, its
+    print(f"iterations: map-free {free_iters}, streamed {its[0]}, with the tentative replay {its[1]}")
+    c.close()
+
+
 def test_large_sigma_templates_outside_the_cube(oracle):
     """sigma = 12: the templates reach 36 voxels sideways, far beyond the LDS cube -- most corner groups take the HBM fallback"""
     img = synth.synth(96, 80, 40, seed=7)
