@@ -749,7 +749,7 @@ struct PlaybackEngine final : pnr::StreamEngine {
         }
         return PNR_OK;
     }
-    int density_update(const pnr::Replayer &r, bool) override
+    int density_update(const pnr::Replayer &r, int) override
     {
         for (int64_t v : r.touched) den[v] = (uint8_t)r.den_at(v);
         return PNR_OK;

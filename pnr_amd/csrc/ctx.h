@@ -283,6 +283,7 @@ void pnr_phased_destroy(pnr_phased *h);
 int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::Replayer &r, const pnr::ShardSpec &sh, int64_t *iters);
 int pnr_density_reset(pnr_ctx *c);                       // zero the device density map (allocating it on first use)
 int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, hipStream_t on = nullptr); // push the voxels touched since Replayer::touched was cleared
+int pnr_density_scatter_async(pnr_ctx *c, const long long *d_idx, const unsigned char *d_val, size_t n, hipStream_t st); // (staging owned by the caller, no wait)
 int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y);
 int pnr_ensure_frangi_buffers(pnr_ctx *c);
 int pnr_frangi_materialise_v(pnr_ctx *c);

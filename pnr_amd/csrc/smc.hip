@@ -800,6 +800,15 @@ int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, hipStream_t on)
     return PNR_OK;
 }
 
+// the scatter alone, on a stream of the caller's, from device staging the caller owns: nothing here waits for anything
+int pnr_density_scatter_async(pnr_ctx *c, const long long *d_idx, const unsigned char *d_val, size_t n, hipStream_t st)
+{
+    if (n == 0) return PNR_OK;
+    hipLaunchKernelGGL(den_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->d_den, (const i64 *)d_idx, d_val, (int)n);
+    PNR_HIP(hipGetLastError());
+    return PNR_OK;
+}
+
 int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y)
 {
     if (n == 0) return PNR_OK;

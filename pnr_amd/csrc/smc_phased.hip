@@ -724,9 +724,15 @@ struct pnr_phased {
     pnr_xest *h_xc = nullptr; int *h_flags = nullptr; int *h_new = nullptr; float *h_new_s6 = nullptr;
     int *d_new = nullptr; float *d_new_s6 = nullptr;
     int *h_ctl = nullptr, *d_ctl = nullptr; // pause / resume lists of the tentative replay: [group][2][stream_cap]
+    // density updates of the streaming tracer: pinned and device staging per trace group (grow-only), so that an update is queued on the
+    // group's own stream and nothing waits for it
+    long long *h_den_idx[4] = {}, *d_den_idx[4] = {};
+    unsigned char *h_den_val[4] = {}, *d_den_val[4] = {};
+    size_t den_cap[4] = {};
     int64_t stream_cap = 0;
     int stream_ni = 0;
     static constexpr int MAXG = 4;
+    static_assert(MAXG == 4, "the density staging above is declared with four entries");
     hipStream_t stg[MAXG] = {}, st_den = nullptr; // [1..]: the further trace groups of the streaming tracer; density uploads
     hipEvent_t ev_start = nullptr;
 };
@@ -763,6 +769,12 @@ void pnr_phased_destroy(pnr_phased *h)
     hipFree(h->d_new); hipFree(h->d_new_s6);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
     (void)hipFree(h->d_ctl);
+    for (int g = 0; g < pnr_phased::MAXG; g++) {
+        if (h->h_den_idx[g]) (void)hipHostFree(h->h_den_idx[g]);
+        if (h->h_den_val[g]) (void)hipHostFree(h->h_den_val[g]);
+        (void)hipFree(h->d_den_idx[g]);
+        (void)hipFree(h->d_den_val[g]);
+    }
     for (int r = 0; r < pnr_phased::RING; r++)
         if (h->ev[r]) (void)hipEventDestroy(h->ev[r]);
     for (int g = 1; g < pnr_phased::MAXG; g++)
@@ -1136,11 +1148,36 @@ struct PhasedEngine final : pnr::StreamEngine {
         hipLaunchKernelGGL(ph_control, dim3(1), dim3(256), 0, q.st, q.P, (const int *)dc, np_, (const int *)(dc + h->stream_cap), nr, q.lp);
         return PNR_OK;
     }
-    int density_update(const pnr::Replayer &r, bool concurrent) override
+    int density_update(const pnr::Replayer &r, int g) override
     {
-        // its own stream when groups overlap: the kernels of either group may see a voxel before or after the update -- both are
-        // under-counts of the reference's map
-        const int rc = pnr_density_update(c, r, concurrent ? h->st_den : c->stream);
+        // Queued on the group's own stream, in front of its next steps, from staging of its own -- and nothing waits for it.  (Until
+        // round 3 the update ran on a stream of its own and the host waited for it: that stream shares a hardware queue with a trace
+        // group's stream, so the wait lasted until the OTHER group's whole poll had drained -- rocprofv3's timeline showed the two
+        // groups taking turns instead of overlapping.)
+        const size_t nt = r.touched.size();
+        if (nt == 0) return PNR_OK;
+        Grp &q = grp[g];
+        if (h->den_cap[g] < nt) {
+            PE_HIP(hipStreamSynchronize(q.st)); // (its last scatter may still read the old staging)
+            if (h->h_den_idx[g]) (void)hipHostFree(h->h_den_idx[g]);
+            if (h->h_den_val[g]) (void)hipHostFree(h->h_den_val[g]);
+            (void)hipFree(h->d_den_idx[g]);
+            (void)hipFree(h->d_den_val[g]);
+            h->h_den_idx[g] = nullptr; h->h_den_val[g] = nullptr; h->d_den_idx[g] = nullptr; h->d_den_val[g] = nullptr; h->den_cap[g] = 0;
+            const size_t cap = std::max<size_t>(2 * nt, 1 << 16);
+            PE_HIP(hipHostMalloc(&h->h_den_idx[g], cap * 8));
+            PE_HIP(hipHostMalloc(&h->h_den_val[g], cap));
+            PE_HIP(hipMalloc(&h->d_den_idx[g], cap * 8));
+            PE_HIP(hipMalloc(&h->d_den_val[g], cap));
+            h->den_cap[g] = cap;
+        }
+        for (size_t i = 0; i < nt; i++) {
+            h->h_den_idx[g][i] = r.touched[i];
+            h->h_den_val[g][i] = (unsigned char)r.den_at(r.touched[i]); // final value: duplicates agree
+        }
+        PE_HIP(hipMemcpyAsync(h->d_den_idx[g], h->h_den_idx[g], nt * 8, hipMemcpyHostToDevice, q.st));
+        PE_HIP(hipMemcpyAsync(h->d_den_val[g], h->h_den_val[g], nt, hipMemcpyHostToDevice, q.st));
+        const int rc = pnr_density_scatter_async(c, h->d_den_idx[g], h->d_den_val[g], nt, q.st);
         if (rc) msg = pnr_last_error();
         return rc;
     }

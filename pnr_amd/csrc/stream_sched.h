@@ -84,8 +84,9 @@ public:
     // queue, in front of group g's next steps and admissions: take the running traces in pause[0..np) off the group's list (they
     // keep slot and state) and put the paused traces in resume[0..nr) back on it
     virtual int control(int g, const int *pause, int np, const int *resume, int nr) = 0;
-    // push the density of the voxels in r.touched (final values r.den_at) to the engine's map
-    virtual int density_update(const Replayer &r, bool concurrent) = 0;
+    // push the density of the voxels in r.touched (final values r.den_at) to the engine's map, in front of group g's next steps
+    // (g's last steps have been waited for; the other groups may see a voxel before or after the update: both are under-counts)
+    virtual int density_update(const Replayer &r, int g) = 0;
     virtual void drain() = 0;
     virtual const char *error() const { return ""; }
 };
@@ -499,7 +500,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                 st.tent_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count();
             }
             if (!r.touched.empty()) {
-                rc = E.density_update(r, G > 1);
+                rc = E.density_update(r, g);
                 if (rc) { err = E.error(); return fail(rc); }
             }
             // MAX_TRACE_COUNT (:2702) or the last seed replayed: whatever is still running is never looked at.  (Sharded, this rank
