@@ -9,7 +9,13 @@ Here the prediction is a full tentative replay at every poll: all records of the
 order on top of the final map, exactly as the final replay would if nothing more were recorded -- so a trace that is cut takes its
 own later nodes out of the picture.  A running trace whose tentative cut lies inside what it has recorded is paused (it costs no
 step time but keeps its slot); it resumes when a later tentative replay no longer cuts it; seeds on tentatively saturated voxels
-wait.  The final result is untouched (the final replay decides).
+wait.  The final result is untouched (the final replay decides).  [Result: 177 k -> 119 k iterations at the old window, 1764 -> 1338 ms in
+the cost model; with a window of 1536 slots and a lookahead of max(256, 100 %) 1255 ms -- built in stream_sched.h, measured on the GPU:
+1544 -> 1179 ms.]
+
+`far` / `far_max`: also start, at most `far` per poll, seeds up to `far_max` ranks beyond the frontier whose 8^3 block no admitted trace
+has touched yet (nobody in front of them has been there, so their traces are probably needed in full): 1255 -> 1223 ms in the model at
+best, not built.
 
   python scripts/sim_tentative.py [gpurun_out/traces_1024_s2000.npz]
 """
@@ -69,7 +75,6 @@ def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=
         # far admission: seeds beyond the lookahead whose 8^3 block holds no node yet (final, tentative or of a started seed): nobody in
         # front of them has been there, so their traces are likely to be needed in full -- start them early (at most `far` per poll)
         if far and tentative:
-            occ = getattr(simulate, "_occ", None)
             got = 0
             s2 = nxt
             while got < far and s2 < min(n, frontier + far_max) and len(active) + len(paused) + 2 <= window:
