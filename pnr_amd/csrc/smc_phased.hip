@@ -24,7 +24,10 @@ namespace {
 
 enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_IT = 3, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_FAST = 12, FL_NCH = 13, FL_PAUSE = 14, FL_N = 16 };
 constexpr int PH_THREADS = 1024; // sampling work-group: 16 waves (<= 128 VGPRs each)
-constexpr int PH_CS = 54; // the sampling kernel holds nothing but the cube in LDS: 54 x 54 rows of 56 bytes = 163 296 B of the 160 KB (53 costs 1.5 %)
+#ifndef PNR_PH_CS
+#define PNR_PH_CS 54
+#endif
+constexpr int PH_CS = PNR_PH_CS; // the sampling kernel holds nothing but the cube in LDS: 54 x 54 rows of 56 bytes = 163 296 B of the 160 KB (53 costs 1.5 %)
 constexpr int PH_PITCH = 56; // row pitch: a multiple of 4, so that every staged dword lands with one aligned ds_write_b32
 // Experiment build -DPNR_PH_W7=1 (make variant NAME=w7 DEFS=-DPNR_PH_W7=1): the rows as 7 overlapping 8-byte windows, corner pairs by
 // ds_read_b64 + v_perm_b32 (smc_device.h, interp_group_w7).  Bit-identical and the LDS bank-conflict cycles halve, but the kernel
