@@ -241,12 +241,13 @@ int pnr_sched_playback(const pnr_params *p, int64_t w, int64_t h, int64_t l, con
                        int64_t *n_iterations_here);
 
 /* The same with the scheduler's tentative replay switched on or off (pnr_sched_playback: on, as in pnr_trace_replay[_sharded]; option
- * "tentative"): results are identical either way, only the number of iterations run differs. */
+ * "tentative") and the number of running traces the admission keeps up (option "target"; -1 = automatic, 0 = off): results are identical
+ * either way, only the number of iterations run differs. */
 int pnr_sched_playback2(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n, int rank,
                         int world, pnr_allgather_fn exchange, void *exchange_user, int64_t block_bytes, pnr_trace_fn trace,
-                        void *trace_user, int window, int groups, int poll, int look0, int look_pct, int tentative, pnr_node *nodes,
-                        int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used,
-                        int64_t *n_iterations_here);
+                        void *trace_user, int window, int groups, int poll, int look0, int look_pct, int tentative, int target,
+                        pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links,
+                        int64_t *n_traces_used, int64_t *n_iterations_here);
 
 /* reconstruct() chain of the plugin (Advantra_plugin.cpp:2096-2181), pure host: link resampling
  * (TRACE_RSMPL) -> mean-shift refinement (SIG2RADIUS, REFINE_ITER, EPSILON2) -> sphere grouping (GROUP_RADIUS) ->
@@ -268,6 +269,7 @@ int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
 
 /* Scheduling and host-side knobs of a context; none of them changes a result (the library reads no environment variable).
  *   window (0 = automatic: 1536 on one GPU, 768 sharded or without the tentative replay) trace slots kept busy | look0, look_pct (0 / -1 = automatic) admission lookahead max(look0, frontier*look_pct/100)
+ *   target (-1 = automatic: 200 on one GPU with the tentative replay, else 0 = off) seeds are admitted only while fewer traces than this are running |
  *   poll (4) SMC steps between polls | groups (2; 1..4) trace groups on separate streams | split_x10 (0 = automatic), max_split (24) sampling
  *   work-groups per CU x 10 / per trace | stash_mb (65536) sample-stash budget | host_threads (0 = CPUs of this process /
  *   local_ranks) workers of the seed flood fill and of pnr_reconstruct_ctx | local_ranks (1) processes sharing this host |

@@ -764,13 +764,13 @@ int pnr_sched_playback(const pnr_params *p, int64_t w, int64_t h, int64_t l, con
                        int64_t *n_links, int64_t *n_traces_used, int64_t *n_iterations)
 {
     return pnr_sched_playback2(p, w, h, l, seeds, n, rank, world, exchange, xuser, block_bytes, trace, tuser, window, groups, poll, look0, look_pct,
-                               /*tentative*/ 1, nodes, cap_nodes, n_nodes, links, cap_links, n_links, n_traces_used, n_iterations);
+                               /*tentative*/ 1, /*target*/ -1, nodes, cap_nodes, n_nodes, links, cap_links, n_links, n_traces_used, n_iterations);
 }
 
 int pnr_sched_playback2(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n, int rank, int world,
                         pnr_allgather_fn exchange, void *xuser, int64_t block_bytes, pnr_trace_fn trace, void *tuser, int window, int groups,
-                        int poll, int look0, int look_pct, int tentative, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links,
-                        int64_t cap_links, int64_t *n_links, int64_t *n_traces_used, int64_t *n_iterations)
+                        int poll, int look0, int look_pct, int tentative, int target, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes,
+                        int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used, int64_t *n_iterations)
 {
     PNR_REQUIRE(p && trace && n_nodes && n_links && (n == 0 || seeds), PNR_E_ARG, "null argument");
     PNR_REQUIRE(w > 0 && h > 0 && l > 0, PNR_E_ARG, "bad dimensions");
@@ -789,6 +789,7 @@ int pnr_sched_playback2(const pnr_params *p, int64_t w, int64_t h, int64_t l, co
     o.window = window; o.groups = std::max(1, groups); o.poll = std::max(1, poll);
     o.look0 = std::max(0, look0); o.look_pct = look_pct;
     o.tentative = tentative != 0;
+    o.target = std::max(-1, target);
     pnr::SchedStats st;
     std::string err;
     const int rc = pnr::run_stream(eng, seeds, n, p->ni, o, sh, r, &st, err);
@@ -816,7 +817,7 @@ const OptEntry OPTS[] = {
     {"replay_batches", &pnr::Options::replay_batches, nullptr, 0, 1}, {"batch_growth", &pnr::Options::batch_growth, nullptr, 100, 100000},
     {"batch_max", &pnr::Options::batch_max, nullptr, 1, 1 << 24}, {"no_stash", &pnr::Options::no_stash, nullptr, 0, 1},
     {"exchange_block", nullptr, &pnr::Options::exchange_block, 0, 1 << 28}, {"frangi_prune", &pnr::Options::frangi_prune, nullptr, 0, 1},
-    {"tentative", &pnr::Options::tentative, nullptr, 0, 1},
+    {"tentative", &pnr::Options::tentative, nullptr, 0, 1},      {"target", &pnr::Options::target, nullptr, -1, 1 << 20},
 };
 } // namespace
 

@@ -59,6 +59,7 @@ int gaussian_taps(float sig, std::vector<float> &g); // returns radius L
 struct Options {
     int window = 0;           // trace slots the streaming tracer keeps busy (0: automatic -- 1536 on one GPU with the tentative replay, 768 otherwise)
     int look0 = 0, look_pct = -1; // admission lookahead max(look0, frontier * look_pct / 100); 0 / -1 = automatic (stream_sched.h)
+    int target = -1;          // running traces the admission keeps up (0: off, -1: automatic -- 200 on one GPU with the tentative replay)
     int poll = 4;             // SMC steps between two polls
     int groups = 2;           // trace groups on separate streams (2: one group's ordered sums overlap the other's sampling)
     int split_x10 = 0;        // sampling work-groups per CU x 10 and launch; 0 = automatic (40 with one trace group, 22 with several)

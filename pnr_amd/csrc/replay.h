@@ -47,9 +47,49 @@ struct Replayer {
     // npervol_map / nidx_map of the reference are dense N-voxel arrays (5 B/voxel, 5 GiB at 1024^3);
     // only voxels that received a node are ever non-zero, so a hash map holds the same state
     struct Cell { uint8_t den = 0; int32_t nidx = 0; };
+    // ... open addressing, voxel indices are >= 0: the scheduler's tentative replay (stream_sched.h) looks up every recorded node of
+    // every unreplayed trace at every poll, millions of finds per stack
+    struct CellMap {
+        std::vector<int64_t> key;
+        std::vector<Cell> val;
+        size_t used = 0;
+        CellMap() { key.assign((size_t)1 << 17, -1); val.assign((size_t)1 << 17, Cell()); }
+        static size_t hash(int64_t v) { return (size_t)(((uint64_t)v * 0x9E3779B97F4A7C15ull) >> 24); }
+        void prefetch(int64_t v) const { __builtin_prefetch(&key[hash(v) & (key.size() - 1)]); }
+        const Cell *find(int64_t v) const
+        {
+            const size_t mask = key.size() - 1;
+            for (size_t h = hash(v) & mask;; h = (h + 1) & mask) {
+                if (key[h] == v) return &val[h];
+                if (key[h] < 0) return nullptr;
+            }
+        }
+        Cell &operator[](int64_t v)
+        {
+            if (2 * (used + 1) > key.size()) grow();
+            const size_t mask = key.size() - 1;
+            for (size_t h = hash(v) & mask;; h = (h + 1) & mask) {
+                if (key[h] == v) return val[h];
+                if (key[h] < 0) { key[h] = v; used++; return val[h]; }
+            }
+        }
+        void grow()
+        {
+            std::vector<int64_t> k0((size_t)2 * key.size(), -1);
+            std::vector<Cell> v0((size_t)2 * key.size(), Cell());
+            k0.swap(key); v0.swap(val);
+            const size_t mask = key.size() - 1;
+            for (size_t i = 0; i < k0.size(); i++)
+                if (k0[i] >= 0) {
+                    size_t h = hash(k0[i]) & mask;
+                    while (key[h] >= 0) h = (h + 1) & mask;
+                    key[h] = k0[i]; val[h] = v0[i];
+                }
+        }
+    };
     pnr_params prm;
     int W, H, L;
-    std::unordered_map<int64_t, Cell> cells;
+    CellMap cells;
     std::vector<pnr_node> nodes;
     std::vector<int32_t> links;    // pairs (a,b): a.nbr.push_back(b); b.nbr.push_back(a)
     std::vector<int64_t> touched;  // voxels whose density changed since clear_touched()
@@ -64,7 +104,6 @@ struct Replayer {
 
     Replayer(const pnr_params &p, int64_t w, int64_t h, int64_t l) : prm(p), W((int)w), H((int)h), L((int)l)
     {
-        cells.reserve(1 << 16);
         pnr_node d; // n0[0]: dummy Node() (node.cpp:43-54; Advantra_plugin.cpp:2416-2419)
         std::memset(&d, 0, sizeof(d));
         d.corr = -FLT_MAX;
@@ -89,8 +128,8 @@ struct Replayer {
     }
     int den_at(int64_t v) const
     {
-        auto it = cells.find(v);
-        return it == cells.end() ? 0 : (int)it->second.den;
+        const Cell *c = cells.find(v);
+        return c ? (int)c->den : 0;
     }
     bool seed_saturated(const pnr_seed &s) const { return !(den_at(voxel(s.x, s.y, s.z)) < prm.nodepervol); }
     void bump(int64_t v, int32_t node)

@@ -44,8 +44,13 @@ namespace pnr {
 struct SchedOptions {
     int window = 1536; // trace slots kept busy on this rank
     int look0 = 0;     // seeds admitted at most max(look0, frontier * look_pct / 100) ranks beyond the replay frontier;
-    int look_pct = -1; // look0 = 0 / look_pct < 0: automatic -- max(256, 100 %) on one GPU with the tentative replay (measured: the pauses make a
-                       // wider lookahead affordable), max(128, 64 * world) / min(400, 50 * world) otherwise (scripts/sim_sharded.py)
+    int look_pct = -1; // look0 = 0 / look_pct < 0: automatic -- max(512, 200 %) on one GPU with the tentative replay (there `target` is what
+                       // binds), max(128, 64 * world) / min(400, 50 * world) otherwise (scripts/sim_sharded.py)
+    int target = -1;   // > 0: seeds are admitted only while fewer than this many traces are RUNNING on this rank (all groups; paused ones do
+                       // not count): late seeds live a few iterations, early ones dozens, so a constant number of running traces wastes
+                       // fewer iterations per step than a rank window (scripts/sim_tentative.py).  0: off.  -1: automatic -- 200 on one GPU
+                       // with the tentative replay (measured 160 / 200 / 240 / 320: 1130 / 1131 / 1131 / 1168 ms against 1172 ms without; flat in
+                       // the polling period, 4 ... 8 steps), off otherwise
     int poll = 4;      // SMC steps between two polls
     int groups = 2;    // trace groups stepping independently (engine permitting)
     int tentative = 1; // pause traces that a tentative replay of everything recorded so far cuts (see above)
@@ -135,11 +140,21 @@ struct Overlay {
         if (++cur == 0) { std::fill(gen.begin(), gen.end(), 0u); cur = 1; }
     }
     static size_t hash(int64_t v) { return (size_t)(((uint64_t)v * 0x9E3779B97F4A7C15ull) >> 20); }
+    void prefetch(int64_t v) const { __builtin_prefetch(&gen[hash(v) & (key.size() - 1)]); }
     int get(int64_t v) const
     {
         const size_t mask = key.size() - 1;
         for (size_t h = hash(v) & mask;; h = (h + 1) & mask) {
             if (gen[h] != cur) return 0;
+            if (key[h] == v) return cnt[h];
+        }
+    }
+    uint8_t &slot(int64_t v) // the voxel's counter, entered with 0 if the pass has not met it (one probe for "read, test, count")
+    {
+        if (2 * (used + 1) > key.size()) grow();
+        const size_t mask = key.size() - 1;
+        for (size_t h = hash(v) & mask;; h = (h + 1) & mask) {
+            if (gen[h] != cur) { gen[h] = cur; key[h] = v; cnt[h] = 0; used++; return cnt[h]; }
             if (key[h] == v) return cnt[h];
         }
     }
@@ -180,8 +195,9 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     const int world = std::max(1, sh.world), rank = sh.rank;
     if (world > 1 && !sh.exchange) { err = "sharded tracing needs an exchange callback"; return PNR_E_ARG; }
     if (rank < 0 || rank >= world) { err = "rank out of range"; return PNR_E_ARG; }
-    if (o.look0 <= 0) o.look0 = (world == 1 && o.tentative) ? 256 : std::max(128, 64 * world);
-    if (o.look_pct < 0) o.look_pct = (world == 1 && o.tentative) ? 100 : std::min(400, 50 * world);
+    if (o.target < 0) o.target = (world == 1 && o.tentative) ? 200 : 0;
+    if (o.look0 <= 0) o.look0 = (world == 1 && o.tentative) ? (o.target > 0 ? 512 : 256) : std::max(128, 64 * world);
+    if (o.look_pct < 0) o.look_pct = (world == 1 && o.tentative) ? (o.target > 0 ? 200 : 100) : std::min(400, 50 * world);
     o.poll = std::max(1, o.poll);
     const int NT = E.slots() - (E.slots() & 1);
     if (NT < 2) { err = "no trace slots"; abort_exchange(sh, ni); return PNR_E_STATE; }
@@ -197,6 +213,8 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
         bool skipped = false;  // sits on a saturated voxel: never traced (:2669-2670)
         int32_t T[2] = {0, 0};
         std::vector<pnr_xest> xc; // [2][ni], allocated when the first record arrives, dropped after the replay
+        std::vector<int64_t> vox; // [2][ni] voxels of the first nvox[dir] recorded estimates: the tentative replay visits them at every poll
+        int32_t nvox[2] = {0, 0};
     };
     std::vector<SeedRec> rec((size_t)n);
     struct Grp {
@@ -392,6 +410,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                         r.log_base = frontier;
                         r.add(&seeds[frontier], 1, sr.T, sr.xc.data());
                         std::vector<pnr_xest>().swap(sr.xc);
+                        std::vector<int64_t>().swap(sr.vox);
                     }
                     frontier++;
                 }
@@ -434,10 +453,19 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                             else if (remote_paused) { X = sr.xc.data() + (size_t)dir * ni; nr = std::min(sr.prow[dir], ni); }
                             else { exact = false; continue; } // running elsewhere, or its record is on its way: nothing known
                             int cut = seed_sat ? 0 : -1;
+                            if (cut < 0 && nr > 0) { // (a trace's recorded estimates never change: their voxels are computed once)
+                                if (sr.vox.empty()) sr.vox.resize((size_t)2 * ni);
+                                int64_t *vc = sr.vox.data() + (size_t)dir * ni;
+                                for (int32_t &k = sr.nvox[dir]; k < nr; k++) vc[k] = r.voxel(X[k].x, X[k].y, X[k].z);
+                            }
+                            const int64_t *vc = sr.vox.empty() ? nullptr : sr.vox.data() + (size_t)dir * ni;
                             for (int i = 0; cut < 0 && i < nr; i++) {
-                                const int64_t crd = r.voxel(X[i].x, X[i].y, X[i].z);
-                                if (r.soma_at(crd) || r.den_at(crd) + ov.get(crd) >= r.prm.nodepervol) { cut = i; break; }
-                                ov.add(crd);
+                                const int64_t crd = vc[i];
+                                if (i + 6 < nr) { r.cells.prefetch(vc[i + 6]); ov.prefetch(vc[i + 6]); }
+                                if (r.soma_at(crd)) { cut = i; break; }
+                                uint8_t &oc = ov.slot(crd);
+                                if (r.den_at(crd) + oc >= r.prm.nodepervol) { cut = i; break; }
+                                if (oc < 255) oc++;
                                 st.tent_nodes++;
                                 if (r.prm.vol > 1) {
                                     int64_t nb[26];
@@ -524,6 +552,10 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             m_max = (int)std::max<int64_t>(0, (total + G - 1) / G - q.active);
             if (q.active <= least) m_max = std::max(m_max, 2); // the smallest group can always take a seed
         }
+        if (o.target > 0) { // ... and only up to this group's share of the running traces asked for (at least one seed when it has none)
+            const int share = std::max(2, (o.target + G - 1) / G);
+            m_max = std::min(m_max, std::max(0, share - q.active));
+        }
         new_slots.clear(); new_s6.clear();
         while (m + 2 <= m_max && next < n && free_slots.size() >= 2 && next < lim) {
             const pnr_seed &sd = seeds[next];
@@ -579,9 +611,9 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     }
     E.drain(); // what is still running is never looked at again, but it writes into buffers that outlive this call
     if (o.timing)
-        fprintf(stderr, "[pnr trace] rank %d/%d: %lld seeds, window %d slots, lookahead max(%d, %d%%), %lld steps, %lld polls, %lld iterations here, "
+        fprintf(stderr, "[pnr trace] rank %d/%d: %lld seeds, window %d slots, lookahead max(%d, %d%%), target %d running, %lld steps, %lld polls, %lld iterations here, "
                         "%lld exchanges (%lld carried), %zu nodes; tentative replay: %lld passes, %lld nodes, %lld pauses, %lld resumed, %lld ended by the host, %.1f ms of host time; %.1f ms blocked waiting for the GPU\n",
-                rank, world, (long long)n, NT, o.look0, o.look_pct, (long long)st.steps,
+                rank, world, (long long)n, NT, o.look0, o.look_pct, o.target, (long long)st.steps,
                 (long long)st.polls, (long long)st.iters, (long long)st.exchanges, (long long)st.carried, r.nodes.size(), (long long)st.tent_passes,
                 (long long)st.tent_nodes, (long long)st.paused, (long long)st.resumed, (long long)st.ended, st.tent_ms, st.wait_ms);
     if (stats) *stats = st;

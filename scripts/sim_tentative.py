@@ -43,7 +43,7 @@ def block_of(v):
     return ((z // BLK) * (S // BLK) + (y // BLK)) * (S // BLK) + (x // BLK)
 
 
-def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=1, a_ms=A_MS, c_ms=C_MS, margin=0, hold_seeds=True, far=0, far_max=0):
+def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=1, a_ms=A_MS, c_ms=C_MS, margin=0, hold_seeds=True, far=0, far_max=0, detail=None, target=0):
     den = {}
     it = [0] * (2 * n)
     state = [0] * (2 * n)  # 0 not admitted, 1 running, 2 stopped, 3 paused, 4 skipped
@@ -62,7 +62,7 @@ def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=
         lim = frontier + max(look0, frontier * look_pct // 100)
         # admission: rank order, seeds on tentatively saturated voxels wait (they are looked at again at every poll)
         s = nxt
-        while s < n and s < lim and len(active) + len(paused) + 2 <= window:
+        while s < n and s < lim and len(active) + len(paused) + 2 <= window and (not target or len(active) + 2 <= target):
             if state[2 * s] == 0 and s not in held:
                 if den.get(svox[s], 0) >= NPV:
                     state[2 * s] = state[2 * s + 1] = 4
@@ -212,6 +212,8 @@ def simulate(window=768, look0=128, look_pct=50, poll=4, tentative=False, every=
                     active.append(g)
                     nresume += 1
         active = [g for g in active if state[g] == 1]
+    if detail is not None:
+        detail['it'] = list(it)
     return dict(steps=steps, iters=iters, ms=round(ms), nodes=nodes, pauses=npause, resumes=nresume, tentative_nodes_per_poll=tent_work // max(polls, 1))
 
 

@@ -331,7 +331,7 @@ def _random_workload(rs, n_seeds, ni, shape, npv, vol):
 @pytest.mark.parametrize("case", range(40))
 def test_scheduler_random_crossing_traces(case):
     """randomised stress of the streaming scheduler on the host play-back engine: crowded synthetic traces, random window / lookahead /
-    polling period / trace groups / world, the tentative replay on and off -- every rank must end with the node graph of the one-shot
+    polling period / running-trace target / trace groups / world, the tentative replay on and off -- every rank must end with the node graph of the one-shot
     replay of the map-free traces, and with no more iterations than they hold"""
     from pnr_amd import lib, multigpu
     rs = np.random.RandomState(7000 + case)
@@ -340,7 +340,7 @@ def test_scheduler_random_crossing_traces(case):
     lookup = lambda q6: W["traces"][np.asarray(q6, np.float32).tobytes()]
     world = int(rs.choice([1, 1, 2, 3]))
     kw = dict(window=int(rs.choice([2, 4, 8, 64, 768])), poll=int(rs.choice([1, 2, 5])), groups=int(rs.choice([1, 2, 3])), look0=int(rs.choice([0, 1, 3, 16])),
-              look_pct=int(rs.choice([-1, 0, 50, 400])), block_bytes=int(rs.choice([0, 900, 4096])))
+              look_pct=int(rs.choice([-1, 0, 50, 400])), block_bytes=int(rs.choice([0, 900, 4096])), target=int(rs.choice([-1, 0, 2, 6, 40])))
     iters = {}
     for tentative in (True, False):
         X = multigpu.ThreadExchange(world)
