@@ -331,7 +331,8 @@ def main():
         # time of the step's four launches with one trace group, and the wall time of the tracing stage per step with several
         # (their launches overlap on separate streams, so summed durations would count shared time twice).
         Mtot = sum(len(ctx.table(f"model_wgt{s}")) for s in range(len(sigs)))
-        groups = ctx.get_option("groups")
+        groups_opt = ctx.get_option("groups")
+        groups = groups_opt if groups_opt > 0 else (1 if world > 1 and a.mode == "shard" else 2)  # 0 = automatic (pnr_hip.h)
         EV = ("smc_predict", "smc", "smc_sums", "smc_update")
         KNAME = {"smc_predict": "ph_predict", "smc": "ph_sample<54, false>", "smc_sums": "ph_sums", "smc_update": "ph_update"} if a.driver == "phased" else {"smc": "smc_trace"}
         smc_n = km["smc"][1]
@@ -435,7 +436,7 @@ def main():
                 t0i = time.perf_counter()
                 _, _, _, it_iso = ctx.trace_replay(s_all)
                 t_iso = 1e3 * (time.perf_counter() - t0i)
-                ctx.set_option("groups", groups)
+                ctx.set_option("groups", groups_opt)
                 ki = {g: ctx.kernel_ms(g) for g in EV}
                 ev_i = it_iso * (a.np + 1)
                 all_i = sum(v[0] for v in ki.values())

@@ -61,7 +61,8 @@ struct Options {
     int look0 = 0, look_pct = -1; // admission lookahead max(look0, frontier * look_pct / 100); 0 / -1 = automatic (stream_sched.h)
     int target = -1;          // running traces the admission keeps up (0: off, -1: automatic -- 200 on one GPU with the tentative replay)
     int poll = 4;             // SMC steps between two polls
-    int groups = 2;           // trace groups on separate streams (2: one group's ordered sums overlap the other's sampling)
+    int groups = 0;           // trace groups on separate streams (0: automatic -- 2 on one GPU: one group's ordered sums overlap the other's sampling;
+                              // 1 sharded: every poll is then an exchange, and small launches gain nothing from sharing the CUs)
     int split_x10 = 0;        // sampling work-groups per CU x 10 and launch; 0 = automatic (40 with one trace group, 22 with several)
     int max_split = 24;       // ... and at most this many per trace
     int64_t stash_mb = 65536; // sample-stash budget

@@ -1204,6 +1204,7 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
     o.timing = c->opt.trace_timing;
     o.tentative = c->opt.tentative;
     o.target = c->opt.target;
+    if (o.groups <= 0) o.groups = sh.world > 1 ? 1 : 2; // measured on 2 / 4 / 8 emulated ranks (scripts/emulate_ranks.py): 825 -> 774, 527 -> 499, 396 -> 353 ms
     const int64_t own = sh.world > 1 ? (n - sh.rank + sh.world - 1) / sh.world : n; // seeds of this rank
     if (o.window <= 0) o.window = (sh.world <= 1 && o.tentative) ? 1536 : 768; // automatic: without the pauses a wider window only buys speculation
     int64_t window = std::min<int64_t>(std::max(2, o.window), std::max<int64_t>(2, 2 * own));

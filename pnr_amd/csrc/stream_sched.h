@@ -50,7 +50,8 @@ struct SchedOptions {
                        // not count): late seeds live a few iterations, early ones dozens, so a constant number of running traces wastes
                        // fewer iterations per step than a rank window (scripts/sim_tentative.py).  0: off.  -1: automatic -- 200 on one GPU
                        // with the tentative replay (measured 160 / 200 / 240 / 320: 1130 / 1131 / 1131 / 1168 ms against 1172 ms without; flat in
-                       // the polling period, 4 ... 8 steps), off otherwise
+                       // the polling period, 4 ... 8 steps), 128 per rank sharded (emulated ranks, one trace group: 4 ranks 507 -> 499 ms, 8 ranks
+                       // 367 -> 353 ms), off without the tentative replay
     int poll = 4;      // SMC steps between two polls
     int groups = 2;    // trace groups stepping independently (engine permitting)
     int tentative = 1; // pause traces that a tentative replay of everything recorded so far cuts (see above)
@@ -195,7 +196,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     const int world = std::max(1, sh.world), rank = sh.rank;
     if (world > 1 && !sh.exchange) { err = "sharded tracing needs an exchange callback"; return PNR_E_ARG; }
     if (rank < 0 || rank >= world) { err = "rank out of range"; return PNR_E_ARG; }
-    if (o.target < 0) o.target = (world == 1 && o.tentative) ? 200 : 0;
+    if (o.target < 0) o.target = o.tentative ? (world == 1 ? 200 : 128) : 0;
     if (o.look0 <= 0) o.look0 = (world == 1 && o.tentative) ? (o.target > 0 ? 512 : 256) : std::max(128, 64 * world);
     if (o.look_pct < 0) o.look_pct = (world == 1 && o.tentative) ? (o.target > 0 ? 200 : 100) : std::min(400, 50 * world);
     o.poll = std::max(1, o.poll);

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def test_options_roundtrip_and_errors():
     c = pnr_amd.Context(pnr_amd.make_params(sigmas=[2.0], np_=20, ni=5), 0)
-    assert c.get_option("groups") == 2 and c.get_option("window") == 0 and c.get_option("look_pct") == -1
+    assert c.get_option("groups") == 0 and c.get_option("window") == 0 and c.get_option("look_pct") == -1
     c.set_option("window", 64)
     assert c.get_option("window") == 64
     assert 1 <= c.get_option("host_threads_effective") <= 32
