@@ -60,6 +60,8 @@ struct Options {
     int window = 0;           // trace slots the streaming tracer keeps busy (0: automatic -- 1536 on one GPU with the tentative replay, 768 otherwise)
     int look0 = 0, look_pct = -1; // admission lookahead max(look0, frontier * look_pct / 100); 0 / -1 = automatic (stream_sched.h)
     int target = -1;          // running traces the admission keeps up (0: off, -1: automatic -- 200 on one GPU with the tentative replay)
+    int concentrate = 1;      // several trace groups: new seeds go to group 0 only while few traces survive a poll (experiment switch)
+    int overfill = 1;         // the target is the mean over a poll, not the count at its start (experiment switch)
     int poll = 4;             // SMC steps between two polls
     int groups = 0;           // trace groups on separate streams (0: automatic -- 2 on one GPU: one group's ordered sums overlap the other's sampling;
                               // 1 sharded: every poll is then an exchange, and small launches gain nothing from sharing the CUs)

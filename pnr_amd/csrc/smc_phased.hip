@@ -1203,7 +1203,7 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
     o.window = c->opt.window; o.look0 = c->opt.look0; o.look_pct = c->opt.look_pct; o.poll = c->opt.poll; o.groups = c->opt.groups;
     o.timing = c->opt.trace_timing;
     o.tentative = c->opt.tentative;
-    o.target = c->opt.target;
+    o.target = c->opt.target; o.overfill = c->opt.overfill; o.concentrate = c->opt.concentrate;
     if (o.groups <= 0) o.groups = sh.world > 1 ? 1 : 2; // measured on 2 / 4 / 8 emulated ranks (scripts/emulate_ranks.py): 825 -> 774, 527 -> 499, 396 -> 353 ms
     const int64_t own = sh.world > 1 ? (n - sh.rank + sh.world - 1) / sh.world : n; // seeds of this rank
     if (o.window <= 0) o.window = (sh.world <= 1 && o.tentative) ? 1536 : 768; // automatic: without the pauses a wider window only buys speculation

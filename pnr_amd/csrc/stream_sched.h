@@ -52,6 +52,8 @@ struct SchedOptions {
                        // with the tentative replay (measured 160 / 200 / 240 / 320: 1130 / 1131 / 1131 / 1168 ms against 1172 ms without; flat in
                        // the polling period, 4 ... 8 steps), 128 per rank sharded (emulated ranks, one trace group: 4 ranks 507 -> 499 ms, 8 ranks
                        // 367 -> 353 ms), off without the tentative replay
+    int overfill = 1;  // ... counted as the mean over a poll (see the admission)
+    int concentrate = 1; // one GPU, several groups: admit into group 0 only while few traces survive a poll (see the admission)
     int poll = 4;      // SMC steps between two polls
     int groups = 2;    // trace groups stepping independently (engine permitting)
     int tentative = 1; // pause traces that a tentative replay of everything recorded so far cuts (see above)
@@ -222,6 +224,8 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
         int active = 0; bool inflight = false;
         std::vector<int> busy;    // slots of this group's traces that have not delivered their record (running or paused)
         int npaused = 0;
+        int last_start = 0;   // traces on the device's list when the last poll's steps were launched
+        double keep = 1.0;    // smoothed share of them still running when the poll was collected
     };
     std::vector<Grp> grp((size_t)G);
     std::vector<int> free_slots;
@@ -303,6 +307,8 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     };
     auto out_record_words = [&](size_t at) { return 4 + (size_t)outbox[at + 3] * 8; };
 
+    long long dbg_end[4] = {0, 0, 0, 0}, dbg_act = 0, dbg_turns = 0, dbg_paused = 0, dbg_free = 0;
+    bool single = false; // admissions go to group 0 only (see the admission)
     int rc = PNR_OK;
     int idle_turns = 0;
     bool aborted = false;
@@ -554,8 +560,19 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             if (q.active <= least) m_max = std::max(m_max, 2); // the smallest group can always take a seed
         }
         if (o.target > 0) { // ... and only up to this group's share of the running traces asked for (at least one seed when it has none)
-            const int share = std::max(2, (o.target + G - 1) / G);
-            m_max = std::min(m_max, std::max(0, share - q.active));
+            // The target is the MEAN over the steps of a poll: where most traces end or are paused within a poll (late seeds live a few
+            // iterations), the poll starts with up to twice the share.
+            if (q.last_start > 0) q.keep = 0.5 * q.keep + 0.5 * std::min(1.0, (double)q.active / q.last_start);
+            // Late seeds live a few iterations: launches shrink to a few dozen traces, where two overlapping groups only share the
+            // per-launch floors.  Then everything new goes to group 0 (the others run out), until most traces survive a poll again.
+            if (G > 1 && world == 1 && o.concentrate && g == 0) {
+                if (!single && q.keep < 0.6) single = true;
+                else if (single && q.keep > 0.85) single = false;
+            }
+            const int share = single ? (g == 0 ? o.target : 0) : std::max(2, (o.target + G - 1) / G);
+            const int goal = o.overfill ? (int)std::min(2.0 * share, share * 2.0 / (1.0 + q.keep) + 0.5) : share;
+            if (single && g == 0) m_max = 2 * NT; // (the groups are not kept the same size)
+            m_max = std::min(m_max, std::max(0, goal - q.active));
         }
         new_slots.clear(); new_s6.clear();
         while (m + 2 <= m_max && next < n && free_slots.size() >= 2 && next < lim) {
@@ -582,12 +599,17 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             if (next > max_known) max_known = next;
             next += world;
         }
+        if (o.timing) { // why the admission of this turn ended
+            if (next >= n) dbg_end[0]++; else if (next >= lim) dbg_end[1]++; else if (free_slots.size() < 2) dbg_end[2]++; else dbg_end[3]++;
+            dbg_act += q.active + m; dbg_turns++; dbg_paused += q.npaused; dbg_free += (long long)free_slots.size();
+        }
         if (m > 0) {
             rc = E.admit(g, new_slots.data(), new_s6.data(), m);
             if (rc) { err = E.error(); return fail(rc); }
             q.active += m;
         }
         if (q.active > 0) {
+            q.last_start = q.active;
             rc = E.launch(g, q.active, o.poll);
             if (rc) { err = E.error(); return fail(rc); }
             st.steps += o.poll;
@@ -617,6 +639,9 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                 rank, world, (long long)n, NT, o.look0, o.look_pct, o.target, (long long)st.steps,
                 (long long)st.polls, (long long)st.iters, (long long)st.exchanges, (long long)st.carried, r.nodes.size(), (long long)st.tent_passes,
                 (long long)st.tent_nodes, (long long)st.paused, (long long)st.resumed, (long long)st.ended, st.tent_ms, st.wait_ms);
+    if (o.timing && dbg_turns)
+        fprintf(stderr, "[pnr trace] admissions ended by: no seeds left %lld, lookahead %lld, no free slot %lld, target / group share %lld; per turn: %.1f launched, %.1f paused in the group, %.1f free slots\n",
+                dbg_end[0], dbg_end[1], dbg_end[2], dbg_end[3], (double)dbg_act / dbg_turns, (double)dbg_paused / dbg_turns, (double)dbg_free / dbg_turns);
     if (stats) *stats = st;
     return PNR_OK;
 }
