@@ -743,6 +743,90 @@ __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash
     return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f; // tracker.cpp:1955
 }
 
+// The same sums with NB chunk buffers that take turns (the loop runs over NB chunks at a time, no buffer is ever copied): chunk
+// c + NB - 1 is requested before chunk c is added up, so a lane waits for loads issued NB - 1 chunks ago instead of for its own
+// (above, the compiler folds `cur` / `nxt` into one buffer).  More registers (NB x CH values), so fewer waves per SIMD: this is the
+// form for launches of a few dozen traces, whose duration is the latency of one chain and not the bandwidth of the stash -- and for
+// launches that have the GPU to themselves.  Same values in the same order: bit-identical.
+template <int STRIDE, int CH, int NB, class F>
+__device__ __forceinline__ void stash_chunks(const float *__restrict__ stash_lane, int nfull, F &&consume)
+{
+    static_assert((NB - 1) * CH <= 48, "vmcnt counts at most 63 loads in flight");
+    float buf[NB][CH];
+#pragma unroll
+    for (int b = 0; b < NB - 1; b++)
+        if (b < nfull) {
+#pragma unroll
+            for (int j = 0; j < CH; j++) buf[b][j] = stash_lane[((i64)b * CH + j) * STRIDE];
+        }
+    int c0 = 0;
+    // steady state: every chunk requested here exists, so the body is free of branches and the compiler's wait before chunk c is
+    // "all but the (NB - 1) x CH newest loads" (behind a branch that may skip loads it has to assume the fewest and waits for more)
+    for (; c0 + 2 * NB - 1 <= nfull; c0 += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int c = c0 + b, cn = c + NB - 1;
+#pragma unroll
+            for (int j = 0; j < CH; j++) buf[(b + NB - 1) % NB][j] = stash_lane[((i64)cn * CH + j) * STRIDE];
+            consume(buf[b], c);
+        }
+    }
+    for (; c0 < nfull; c0 += NB) { // the last one or two rounds
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int c = c0 + b, cn = c + NB - 1; // wave-uniform
+            if (cn < nfull) {
+#pragma unroll
+                for (int j = 0; j < CH; j++) buf[(b + NB - 1) % NB][j] = stash_lane[((i64)cn * CH + j) * STRIDE];
+            }
+            if (c < nfull) consume(buf[b], c);
+        }
+    }
+}
+
+template <int STRIDE = 64, int CH = 16, int NB = 4>
+__device__ __forceinline__ float zncc_from_stash_deep(const float *__restrict__ stash_lane, int M, const float *__restrict__ wd, float corrc)
+{
+    const int nfull = M / CH, tail = M - nfull * CH; // wave-uniform
+    float ag = 0.f;
+    stash_chunks<STRIDE, CH, NB>(stash_lane, nfull, [&](const float (&v)[CH], int) {
+#pragma unroll
+        for (int j = 0; j < CH; j++) ag += v[j];
+    });
+    float t[CH];
+    {
+        const float *tp = stash_lane + (i64)nfull * CH * STRIDE;
+#pragma unroll
+        for (int j = 0; j < CH; j++) t[j] = (j < tail) ? tp[j * STRIDE] : 0.f;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            if (j < tail) ag += t[j];
+    }
+    ag /= (float)M;
+    float corra = 0.f, corrb = 0.f;
+    stash_chunks<STRIDE, CH, NB>(stash_lane, nfull, [&](const float (&v)[CH], int c) {
+        const float *wk = wd + c * CH; // wave-uniform address: scalar loads
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const float di = v[j] - ag;
+            corra += di * wk[j];
+            corrb = (float)__builtin_fma((double)di, (double)di, (double)corrb); // (see zncc_from_stash)
+        }
+    });
+    {
+        const float *wk = wd + nfull * CH;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            if (j < tail) { // (the tail's values are still in t[])
+                const float di = t[j] - ag;
+                corra += di * wk[j];
+                corrb = (float)__builtin_fma((double)di, (double)di, (double)corrb);
+            }
+    }
+    const float prod = corrb * corrc;
+    return (prod > FLT_MIN) ? corra / sqrtf(prod) : 0.f; // tracker.cpp:1955
+}
+
 struct TabX { // extra template tables for the box kernel
     const Grid *grid;   // per sigma
     const float *axes;  // per sigma: vv[nv] | uu[nu] | ww[nw], at axes_off[s]

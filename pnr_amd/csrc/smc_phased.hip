@@ -438,6 +438,8 @@ __global__ __launch_bounds__(PH_THREADS) PH_SAMPLE_ATTR void ph_sample(Vol V, Ta
 
 // one wave per (trace, sigma, chain group): the ordered sums of the chains from the stash
 constexpr int PH_CH = 32; // stash values in flight per lane (64: 256 VGPRs, slower with many traces, no faster with few)
+// DEEP: zncc_from_stash_deep (four chunk buffers in turn) for launches bound by the latency of a chain, not by the stash's bandwidth
+template <bool DEEP>
 __global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, int np_pad, int ni, int it_arg, int lp, int ng_max)
 {
     const int S = T.nsig, lane = threadIdx.x;
@@ -465,16 +467,25 @@ __global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, 
 #ifdef PNR_SMC_STAMPS
         cv = zncc_from_stash<64, PH_CH>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI], &sst1);
 #else
-        cv = zncc_from_stash<64, PH_CH>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI]);
+        if constexpr (DEEP) cv = zncc_from_stash_deep<64>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI]);
+        else cv = zncc_from_stash<64, PH_CH>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI]);
 #endif
     } else { // last group: narrow rows; lanes without a chain re-read a valid column (same 64 B granules)
         valid = lane < rem;
         const int j = valid ? lane : rem - 1;
         const float *col = sbase + (i64)ngf * M * 64 + j;
-        switch (last_group_stride(rem)) {
-        case 16: cv = zncc_from_stash<16, PH_CH>(col, M, wd, T.corrc[sI]); break;
-        case 32: cv = zncc_from_stash<32, PH_CH>(col, M, wd, T.corrc[sI]); break;
-        default: cv = zncc_from_stash<64, PH_CH>(col, M, wd, T.corrc[sI]); break;
+        if constexpr (DEEP) {
+            switch (last_group_stride(rem)) {
+            case 16: cv = zncc_from_stash_deep<16>(col, M, wd, T.corrc[sI]); break;
+            case 32: cv = zncc_from_stash_deep<32>(col, M, wd, T.corrc[sI]); break;
+            default: cv = zncc_from_stash_deep<64>(col, M, wd, T.corrc[sI]); break;
+            }
+        } else {
+            switch (last_group_stride(rem)) {
+            case 16: cv = zncc_from_stash<16, PH_CH>(col, M, wd, T.corrc[sI]); break;
+            case 32: cv = zncc_from_stash<32, PH_CH>(col, M, wd, T.corrc[sI]); break;
+            default: cv = zncc_from_stash<64, PH_CH>(col, M, wd, T.corrc[sI]); break;
+            }
         }
     }
     if (valid) P.corr[((i64)tr * S + sI) * np_pad + g * 64 + lane] = cv; // indexed by chain
@@ -790,6 +801,14 @@ void pnr_phased_destroy(pnr_phased *h)
 // Work-groups per trace for the sampling launch.  One work-group per CU is resident (the cube fills the LDS); all
 // work-groups of a trace pull items from its counter, so what matters is that there are a few times more work-groups
 // than CUs (the dispatcher keeps every CU busy until the items run out) without paying the cube staging too often.
+// Which form of the ordered sums a launch of `active` traces takes (option "sums_deep": -1 automatic, 0 / 1 forced; the results
+// are the same): the four-buffer form when the launch has the GPU to itself, or is so small that a chain's latency is all it costs
+static bool sums_deep(const pnr_ctx *c, int active, int ngroups)
+{
+    if (c->opt.sums_deep >= 0) return c->opt.sums_deep != 0;
+    return ngroups <= 1 || active <= c->opt.sums_deep_max;
+}
+
 static int pick_nsplit(int active, int ncu, int max_split, int x10 /* work-groups per CU x 10 */)
 {
     if (x10 <= 0) x10 = 40;
@@ -967,7 +986,10 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
                 hipLaunchKernelGGL((ph_sample<CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), cube_bytes, st, V, T, X, P, np, ni, it, it & 1, active);
             c->toc("smc", 1, st);
             c->tic(st);
-            hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it, it & 1, ng);
+            if (sums_deep(c, active, 1))
+                hipLaunchKernelGGL(ph_sums<true>, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it, it & 1, ng);
+            else
+                hipLaunchKernelGGL(ph_sums<false>, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, T, X, P, np, np_pad, ni, it, it & 1, ng);
             c->toc("smc_sums", 1, st);
             c->tic(st);
             hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), upd_lds, st, V, T, P, np, np_pad, ni, it, it & 1, c->prm.Kc, c->prm.znccth,
@@ -1016,6 +1038,7 @@ struct PhasedEngine final : pnr::StreamEngine {
     };
     Grp grp[pnr_phased::MAXG];
     std::string msg;
+    int ngroups = 1;    // trace groups the scheduler steps (what a launch shares the GPU with)
     int split_x10 = 40; // with several trace groups a launch shares the CUs with the other groups' launches: fewer, fatter work-groups
 
     explicit PhasedEngine(pnr_ctx *ctx) : c(ctx) {}
@@ -1109,7 +1132,10 @@ struct PhasedEngine final : pnr::StreamEngine {
                 hipLaunchKernelGGL((ph_sample<PH_CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
             c->toc("smc", 1, st);
             c->tic(st, true);
-            hipLaunchKernelGGL(ph_sums, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp, ng);
+            if (sums_deep(c, active, ngroups))
+                hipLaunchKernelGGL(ph_sums<true>, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp, ng);
+            else
+                hipLaunchKernelGGL(ph_sums<false>, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp, ng);
             c->toc("smc_sums", 1, st);
             c->tic(st, true);
             hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), E.upd_lds, st, E.V, E.T, P, np, np_pad, ni, -1, lp, c->prm.Kc, c->prm.znccth,
@@ -1210,6 +1236,7 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
     int64_t window = std::min<int64_t>(std::max(2, o.window), std::max<int64_t>(2, 2 * own));
     window += window & 1;
     PhasedEngine eng(c);
+    eng.ngroups = std::min(std::max(1, o.groups), (int)pnr_phased::MAXG);
     eng.split_x10 = c->opt.split_x10 > 0 ? c->opt.split_x10 : (std::min(std::max(1, o.groups), (int)pnr_phased::MAXG) > 1 ? 22 : 40);
     int rc = eng.init(window);
     if (rc) { // (the other ranks are about to enter their first exchange: tell them)

@@ -476,3 +476,29 @@ def test_empty_inputs_end_to_end():
     assert len(T) == 0 and xc.shape[0] == 0
     one = pnr_amd.advantra.run_pipeline(c, img, one_shot=True)
     assert len(one["nodes"]) == 1
+
+
+@pytest.mark.parametrize("opts", ["sums_deep=0", "sums_deep=1", "target=0,look0=64,look_pct=50", "target=40,overfill=0", "target=24,concentrate=0,groups=2",
+                                  "target=24,concentrate=1,groups=2,poll=2", "groups=1,target=500"])
+def test_scheduler_and_kernel_forms_same_graph(smc_driver, opts):
+    """the admission rules of the streaming scheduler (running-trace target, overfill, concentration on one trace group) and the two
+    forms of the ordered sums (ph_sums<false>: two folded chunk buffers, ph_sums<true>: four buffers in turn) are performance choices:
+    the node graph is the one-shot graph whichever is taken"""
+    if smc_driver != "phased":
+        pytest.skip("the streaming scheduler belongs to the phased driver")
+    img = synth.synth(128, 112, 48, seed=8)
+    p = pnr_amd.make_params(sigmas=[2.0, 3.0], np_=64, ni=60, zdist=2.0, nodepervol=3, vol=1)
+    c = pnr_amd.Context(p, 0)
+    c.set_volume(img)
+    c.frangi()
+    seeds = c.score_filter_sort(c.extract_seeds())[:240]
+    T, stop, xc, _ = c.trace_batch(seeds)
+    n1, l1, nt1 = c.replay(seeds, T, xc)
+    c.set_options(opts)
+    n2, l2, nt2, its = c.trace_replay(seeds)
+    assert nt1 == nt2 and len(n1) == len(n2) > 500 and np.array_equal(l1, l2), opts
+    for k in n1.dtype.names:
+        assert np.array_equal(n1[k], n2[k], equal_nan=True), (opts, k)
+    assert its <= int((T + (T < p.ni)).sum())
+    c.close()
+
