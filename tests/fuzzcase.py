@@ -35,6 +35,9 @@ def run_case(L, case, stats, desc, driver=None, big=False):
         img = synth.add_somas(img, [(int(rs.randint(8, w - 8)), int(rs.randint(8, h - 8)), int(rs.randint(4, max(5, l - 4))), int(rs.randint(rad + 1, rad + 5)))
                                     for _ in range(int(rs.randint(1, 3)))])
     knobs = dict(groups=groups, window=int(rs.choice([8, 32, 768])), look0=int(rs.choice([2, 16, 128])), poll=int(rs.choice([1, 4, 7])))
+    rk = np.random.RandomState(900000 + case)  # (a stream of its own: the cases keep the stacks and parameters they had before these knobs existed)
+    knobs.update(target=int(rk.choice([-1, 0, 4, 16, 64])), overfill=int(rk.randint(2)), concentrate=int(rk.randint(2)), sums_deep=int(rk.choice([-1, 0, 1])))
+    desc.update(knobs=knobs)
     p = pnr_amd.make_params(sigmas=sigs, somaradius=rad, step=step, kappa=kappa, zdist=zdist, np_=np_, ni=ni, tolerance=tol, znccth=znccth, nodepervol=npv, vol=vol)
     c = pnr_amd.Context(p, 0)
     if driver:
