@@ -819,7 +819,7 @@ const OptEntry OPTS[] = {
     {"exchange_block", nullptr, &pnr::Options::exchange_block, 0, 1 << 28}, {"frangi_prune", &pnr::Options::frangi_prune, nullptr, 0, 1},
     {"tentative", &pnr::Options::tentative, nullptr, 0, 1},      {"target", &pnr::Options::target, nullptr, -1, 1 << 20},
     {"sums_deep", &pnr::Options::sums_deep, nullptr, -1, 1},      {"sums_deep_max", &pnr::Options::sums_deep_max, nullptr, 0, 1 << 20},
-    {"overfill", &pnr::Options::overfill, nullptr, 0, 1},        {"concentrate", &pnr::Options::concentrate, nullptr, 0, 1},
+    {"overfill", &pnr::Options::overfill, nullptr, 0, 1},        {"concentrate", &pnr::Options::concentrate, nullptr, 0, 100},
 };
 } // namespace
 

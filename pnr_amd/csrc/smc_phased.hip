@@ -1035,11 +1035,13 @@ struct PhasedEngine final : pnr::StreamEngine {
     struct Grp {
         PhState P; hipStream_t st; int lp = 0;
         int *h_flags, *h_cnt, *h_new, *d_new; float *h_new_s6, *d_new_s6;
+        int running = 0; // traces of the group's last launch still running (0 once its poll has been collected empty)
     };
     Grp grp[pnr_phased::MAXG];
     std::string msg;
     int ngroups = 1;    // trace groups the scheduler steps (what a launch shares the GPU with)
-    int split_x10 = 40; // with several trace groups a launch shares the CUs with the other groups' launches: fewer, fatter work-groups
+    // (with several trace groups a launch shares the CUs with the other groups' launches: fewer, fatter sampling work-groups -- 22
+    // instead of 40 per 10 CUs -- and the form of ph_sums that fits beside them; decided per launch, see launch())
 
     explicit PhasedEngine(pnr_ctx *ctx) : c(ctx) {}
     const char *error() const override { return msg.c_str(); }
@@ -1119,9 +1121,14 @@ struct PhasedEngine final : pnr::StreamEngine {
         hipStream_t st = q.st;
         const PhState &P = q.P;
         const int np = E.np, ni = E.ni, S = E.S, np_pad = E.np_pad, ng = E.ng;
+        // does this launch share the GPU with another group's steps?  (With the scheduler's `concentrate` the other groups run out.)
+        q.running = active;
+        int sharing = 1;
+        for (int k = 0; k < ngroups; k++) sharing += (k != g && grp[k].running > 0) ? 1 : 0;
+        const int x10 = c->opt.split_x10 > 0 ? c->opt.split_x10 : (sharing > 1 ? 22 : 40);
         for (int k = 0; k < poll; k++) { // `poll` SMC steps over the group's active list (every trace at its own iteration)
             const int lp = q.lp;
-            const int nsplit = pick_nsplit(active, E.ncu, E.max_split, split_x10);
+            const int nsplit = pick_nsplit(active, E.ncu, E.max_split, x10);
             c->tic(st, k > 0); // (the first step of a poll follows the admission copies: its own opening event)
             hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS, PH_CSX);
             c->toc("smc_predict", 1, st);
@@ -1132,7 +1139,7 @@ struct PhasedEngine final : pnr::StreamEngine {
                 hipLaunchKernelGGL((ph_sample<PH_CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
             c->toc("smc", 1, st);
             c->tic(st, true);
-            if (sums_deep(c, active, ngroups))
+            if (sums_deep(c, active, sharing))
                 hipLaunchKernelGGL(ph_sums<true>, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp, ng);
             else
                 hipLaunchKernelGGL(ph_sums<false>, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp, ng);
@@ -1147,11 +1154,13 @@ struct PhasedEngine final : pnr::StreamEngine {
         PE_HIP(hipMemcpyAsync(q.h_cnt, P.cnt + q.lp, 4, hipMemcpyDeviceToHost, st));
         return PNR_OK;
     }
+    void idle(int g) override { grp[g].running = 0; }
     int wait(int g, int *active) override
     {
         PE_HIP(hipStreamSynchronize(grp[g].st)); // the stream carries this group's work only
         PE_HIP(hipGetLastError());
         *active = grp[g].h_cnt[0];
+        grp[g].running = *active;
         return PNR_OK;
     }
     bool finished(int g, int slot, int *T) const override
@@ -1237,7 +1246,6 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
     window += window & 1;
     PhasedEngine eng(c);
     eng.ngroups = std::min(std::max(1, o.groups), (int)pnr_phased::MAXG);
-    eng.split_x10 = c->opt.split_x10 > 0 ? c->opt.split_x10 : (std::min(std::max(1, o.groups), (int)pnr_phased::MAXG) > 1 ? 22 : 40);
     int rc = eng.init(window);
     if (rc) { // (the other ranks are about to enter their first exchange: tell them)
         pnr::set_error("%s", eng.error());

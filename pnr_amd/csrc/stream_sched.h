@@ -88,6 +88,7 @@ public:
     virtual bool finished(int g, int slot, int *T) const = 0;
     virtual const pnr_xest *rows(int slot) const = 0;
     // after wait(g), for a trace of group g that is still running: the iterations whose estimates can be read in rows(slot)
+    virtual void idle(int g) { (void)g; } // group g has nothing to step this turn
     virtual int progress(int g, int slot) const = 0;
     // queue, in front of group g's next steps and admissions: take the running traces in pause[0..np) off the group's list (they
     // keep slot and state) and put the paused traces in resume[0..nr) back on it
@@ -566,8 +567,9 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             // Late seeds live a few iterations: launches shrink to a few dozen traces, where two overlapping groups only share the
             // per-launch floors.  Then everything new goes to group 0 (the others run out), until most traces survive a poll again.
             if (G > 1 && world == 1 && o.concentrate && g == 0) {
-                if (!single && q.keep < 0.6) single = true;
-                else if (single && q.keep > 0.85) single = false;
+                const double enter = (o.concentrate == 1 ? 60 : o.concentrate) / 100.0; // (values above 1: the threshold in percent)
+                if (!single && q.keep < enter) single = true;
+                else if (single && q.keep > std::min(0.97, enter + 0.25)) single = false;
             }
             const int share = single ? (g == 0 ? o.target : 0) : std::max(2, (o.target + G - 1) / G);
             const int goal = o.overfill ? (int)std::min(2.0 * share, share * 2.0 / (1.0 + q.keep) + 0.5) : share;
@@ -614,6 +616,8 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             if (rc) { err = E.error(); return fail(rc); }
             st.steps += o.poll;
             q.inflight = true;
+        } else {
+            E.idle(g); // (nothing of this group runs until its next launch: the other groups have the GPU to themselves)
         }
         // ---- nothing running anywhere and nothing admitted: the frontier cannot move any more
         if (world > 1 && !sync_turn) continue; // the idle count only moves in the turns every rank synchronises in
