@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void zncc_sample(Vol V, Tab T, const float *__
     float *out = stash + soff + (i64)g * M * 64 + (i64)c * 64 * 64;
     for (int e = tid; e < 64 * 64; e += 256) {
         const int j = e >> 6, col = e & 63;
-        if (c * 64 + j < M) out[j * 64 + col] = tile[col][j];
+        if (c * 64 + j < M) STASH_ST(&out[j * 64 + col], tile[col][j]);
     }
 }
 
