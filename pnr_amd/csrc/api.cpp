@@ -679,7 +679,8 @@ int pnr_trace_replay_sharded(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int r
 // ---- the scheduler of pnr_trace_replay[_sharded] over a HOST engine that plays map-free traces (no GPU involved) -----------
 namespace {
 struct PlaybackEngine final : pnr::StreamEngine {
-    struct Slot { bool used = false, done = false; int it = 0, T = 0, Tfree = 0; std::vector<pnr_xest> xc; };
+    // (s_*: the state wait() hands to the scheduler -- the one behind the first poll - lag steps of the last launch, as PhasedEngine's)
+    struct Slot { bool used = false, done = false, s_done = false; int it = 0, T = 0, Tfree = 0, s_it = 0, s_T = 0; std::vector<pnr_xest> xc; };
     const pnr_params &prm;
     int64_t W, H;
     int ni, nslots;
@@ -687,6 +688,7 @@ struct PlaybackEngine final : pnr::StreamEngine {
     void *user;
     std::vector<Slot> sl;
     std::vector<std::vector<int>> active; // per group
+    int s_active[4] = {0, 0, 0, 0};
     std::unordered_map<int64_t, uint8_t> den;
     std::string msg;
     int64_t steps = 0;
@@ -710,7 +712,12 @@ struct PlaybackEngine final : pnr::StreamEngine {
         }
         return PNR_OK;
     }
-    int launch(int g, int, int poll) override
+    void snapshot(int g)
+    {
+        s_active[g] = (int)active[(size_t)g].size();
+        for (Slot &s : sl) { s.s_done = s.done; s.s_it = s.it; s.s_T = s.T; } // (all slots: PhasedEngine copies the whole flag array, too)
+    }
+    int launch(int g, int, int poll, int lag) override
     {
         // what ph_update does with a trace, on the recorded map-free result: iteration `it` fails (T = it), or succeeds and its
         // centroid voxel is saturated in the replayed map (DENSITY stop, T = it + 1), or the trace goes on
@@ -728,19 +735,23 @@ struct PlaybackEngine final : pnr::StreamEngine {
             }
             active[(size_t)g].swap(keep);
             steps++;
+            if (k == poll - 1 - lag) snapshot(g);
         }
         return PNR_OK;
     }
-    int wait(int g, int *act) override { *act = (int)active[(size_t)g].size(); return PNR_OK; }
-    bool finished(int, int slot, int *T) const override { *T = sl[(size_t)slot].T; return sl[(size_t)slot].done; }
+    int wait(int g, int *act) override { *act = s_active[g]; return PNR_OK; }
+    bool finished(int, int slot, int *T) const override { *T = sl[(size_t)slot].s_T; return sl[(size_t)slot].s_done; }
     const pnr_xest *rows(int slot) const override { return sl[(size_t)slot].xc.data(); }
-    int progress(int, int slot) const override { return sl[(size_t)slot].it; }
+    int progress(int, int slot) const override { return sl[(size_t)slot].s_it; }
     int control(int g, const int *pause, int np, const int *resume, int nr) override
     {
         std::vector<int> &a = active[(size_t)g];
         for (int j = 0; j < np; j++) {
             auto f = std::find(a.begin(), a.end(), pause[j]);
-            if (f == a.end()) { msg = "pause of a trace that is not stepped"; return PNR_E_STATE; }
+            if (f == a.end()) { // (stopped by itself in the steps that ran behind the state the scheduler decided on)
+                if (!sl[(size_t)pause[j]].done) { msg = "pause of a trace that is not stepped"; return PNR_E_STATE; }
+                continue;
+            }
             a.erase(f);
         }
         for (int j = 0; j < nr; j++) {
@@ -764,12 +775,12 @@ int pnr_sched_playback(const pnr_params *p, int64_t w, int64_t h, int64_t l, con
                        int64_t *n_links, int64_t *n_traces_used, int64_t *n_iterations)
 {
     return pnr_sched_playback2(p, w, h, l, seeds, n, rank, world, exchange, xuser, block_bytes, trace, tuser, window, groups, poll, look0, look_pct,
-                               /*tentative*/ 1, /*target*/ -1, nodes, cap_nodes, n_nodes, links, cap_links, n_links, n_traces_used, n_iterations);
+                               /*tentative*/ 1, /*target*/ -1, /*lag*/ -1, nodes, cap_nodes, n_nodes, links, cap_links, n_links, n_traces_used, n_iterations);
 }
 
 int pnr_sched_playback2(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n, int rank, int world,
                         pnr_allgather_fn exchange, void *xuser, int64_t block_bytes, pnr_trace_fn trace, void *tuser, int window, int groups,
-                        int poll, int look0, int look_pct, int tentative, int target, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes,
+                        int poll, int look0, int look_pct, int tentative, int target, int lag, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes,
                         int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used, int64_t *n_iterations)
 {
     PNR_REQUIRE(p && trace && n_nodes && n_links && (n == 0 || seeds), PNR_E_ARG, "null argument");
@@ -790,6 +801,7 @@ int pnr_sched_playback2(const pnr_params *p, int64_t w, int64_t h, int64_t l, co
     o.look0 = std::max(0, look0); o.look_pct = look_pct;
     o.tentative = tentative != 0;
     o.target = std::max(-1, target);
+    o.lag = std::max(-1, lag);
     pnr::SchedStats st;
     std::string err;
     const int rc = pnr::run_stream(eng, seeds, n, p->ni, o, sh, r, &st, err);
@@ -819,6 +831,7 @@ const OptEntry OPTS[] = {
     {"exchange_block", nullptr, &pnr::Options::exchange_block, 0, 1 << 28}, {"frangi_prune", &pnr::Options::frangi_prune, nullptr, 0, 1},
     {"tentative", &pnr::Options::tentative, nullptr, 0, 1},      {"target", &pnr::Options::target, nullptr, -1, 1 << 20},
     {"sums_deep", &pnr::Options::sums_deep, nullptr, -1, 1},      {"sums_deep_max", &pnr::Options::sums_deep_max, nullptr, 0, 1 << 20},
+    {"lag", &pnr::Options::lag, nullptr, -1, 1023},
     {"overfill", &pnr::Options::overfill, nullptr, 0, 1},        {"concentrate", &pnr::Options::concentrate, nullptr, 0, 100},
 };
 } // namespace

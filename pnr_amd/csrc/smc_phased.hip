@@ -749,6 +749,7 @@ struct pnr_phased {
     static_assert(MAXG == 4, "the density staging above is declared with four entries");
     hipStream_t stg[MAXG] = {}, st_den = nullptr; // [1..]: the further trace groups of the streaming tracer; density uploads
     hipEvent_t ev_start = nullptr;
+    hipEvent_t ev_state[4] = {}; // per trace group: the state copies of its last launch have landed (PhasedEngine::wait)
 };
 
 static void phased_free(pnr_phased *h)
@@ -795,6 +796,7 @@ void pnr_phased_destroy(pnr_phased *h)
         if (h->stg[g]) (void)hipStreamDestroy(h->stg[g]);
     if (h->st_den) (void)hipStreamDestroy(h->st_den);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    for (hipEvent_t &e : h->ev_state) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -848,6 +850,7 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
         for (int g = 1; g < pnr_phased::MAXG; g++) PNR_HIP(hipStreamCreateWithFlags(&h->stg[g], hipStreamNonBlocking));
         PNR_HIP(hipStreamCreateWithFlags(&h->st_den, hipStreamNonBlocking));
         PNR_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
+        for (hipEvent_t &e : h->ev_state) PNR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // stash rows of a trace hold at most np + 1 chains: full groups of 64 + the last group's stride (16 / 32 / 64)
     const int ngf = (np + 1) / 64, rem = (np + 1) - 64 * ngf, R = rem == 0 ? 0 : (rem > 32 ? 64 : (rem > 16 ? 32 : 16)), W = 64 * ngf + R;
@@ -1035,6 +1038,7 @@ struct PhasedEngine final : pnr::StreamEngine {
     struct Grp {
         PhState P; hipStream_t st; int lp = 0;
         int *h_flags, *h_cnt, *h_new, *d_new; float *h_new_s6, *d_new_s6;
+        hipEvent_t ev_state = nullptr; // the copies of flags and count of the last launch have landed
         int running = 0; // traces of the group's last launch still running (0 once its poll has been collected empty)
     };
     Grp grp[pnr_phased::MAXG];
@@ -1097,6 +1101,7 @@ struct PhasedEngine final : pnr::StreamEngine {
             q.P.list = E.P.list + (size_t)g * 2 * E.P.cap;
             q.P.cnt = E.P.cnt + 2 * g;
             q.st = g == 0 ? c->stream : h->stg[g];
+            q.ev_state = h->ev_state[g];
             q.h_flags = h->h_flags + (size_t)g * h->stream_cap * FL_N; q.h_cnt = h->h_cnt + g;
             q.h_new = h->h_new + (size_t)g * h->stream_cap; q.d_new = h->d_new + (size_t)g * h->stream_cap;
             q.h_new_s6 = h->h_new_s6 + (size_t)g * h->stream_cap * 6; q.d_new_s6 = h->d_new_s6 + (size_t)g * h->stream_cap * 6;
@@ -1115,7 +1120,7 @@ struct PhasedEngine final : pnr::StreamEngine {
         hipLaunchKernelGGL(ph_admit, dim3(1), dim3(256), 0, q.st, q.P, h->d_s6, (const int *)q.d_new, (const float *)q.d_new_s6, m, q.lp, E.ni);
         return PNR_OK;
     }
-    int launch(int g, int active, int poll) override
+    int launch(int g, int active, int poll, int lag) override
     {
         Grp &q = grp[g];
         hipStream_t st = q.st;
@@ -1149,15 +1154,18 @@ struct PhasedEngine final : pnr::StreamEngine {
                                c->prm.neff_ratio, c->d_den, c->prm.nodepervol, O);
             c->toc("smc_update", 1, st);
             q.lp ^= 1;
+            if (k == poll - 1 - lag) { // what wait() hands to the host: the state behind this step (the last `lag` steps run on meanwhile)
+                PE_HIP(hipMemcpyAsync(q.h_flags, P.flags, (size_t)NT * FL_N * 4, hipMemcpyDeviceToHost, st));
+                PE_HIP(hipMemcpyAsync(q.h_cnt, P.cnt + q.lp, 4, hipMemcpyDeviceToHost, st));
+                PE_HIP(hipEventRecord(q.ev_state, st));
+            }
         }
-        PE_HIP(hipMemcpyAsync(q.h_flags, P.flags, (size_t)NT * FL_N * 4, hipMemcpyDeviceToHost, st));
-        PE_HIP(hipMemcpyAsync(q.h_cnt, P.cnt + q.lp, 4, hipMemcpyDeviceToHost, st));
         return PNR_OK;
     }
     void idle(int g) override { grp[g].running = 0; }
     int wait(int g, int *active) override
     {
-        PE_HIP(hipStreamSynchronize(grp[g].st)); // the stream carries this group's work only
+        PE_HIP(hipEventSynchronize(grp[g].ev_state)); // (the steps queued behind the state copy may still be running)
         PE_HIP(hipGetLastError());
         *active = grp[g].h_cnt[0];
         grp[g].running = *active;
@@ -1238,7 +1246,7 @@ int pnr_trace_replay_stream(pnr_ctx *c, const pnr_seed *seeds, int64_t n, pnr::R
     o.window = c->opt.window; o.look0 = c->opt.look0; o.look_pct = c->opt.look_pct; o.poll = c->opt.poll; o.groups = c->opt.groups;
     o.timing = c->opt.trace_timing;
     o.tentative = c->opt.tentative;
-    o.target = c->opt.target; o.overfill = c->opt.overfill; o.concentrate = c->opt.concentrate;
+    o.target = c->opt.target; o.overfill = c->opt.overfill; o.concentrate = c->opt.concentrate; o.lag = c->opt.lag;
     if (o.groups <= 0) o.groups = sh.world > 1 ? 1 : 2; // measured on 2 / 4 / 8 emulated ranks (scripts/emulate_ranks.py): 825 -> 774, 527 -> 499, 396 -> 353 ms
     const int64_t own = sh.world > 1 ? (n - sh.rank + sh.world - 1) / sh.world : n; // seeds of this rank
     if (o.window <= 0) o.window = (sh.world <= 1 && o.tentative) ? 1536 : 768; // automatic: without the pauses a wider window only buys speculation

@@ -53,6 +53,10 @@ struct SchedOptions {
                        // the polling period, 4 ... 8 steps), 128 per rank sharded (emulated ranks, one trace group: 4 ranks 507 -> 499 ms, 8 ranks
                        // 367 -> 353 ms), off without the tentative replay
     int overfill = 1;  // ... counted as the mean over a poll (see the admission)
+    int lag = -1;      // steps of a poll that run while the host works on the state in front of them (see StreamEngine::launch): hides the host's
+                       // share of a poll (tentative pass, exchange) where no other trace group covers it, at the price of `lag` more
+                       // iterations for every trace about to be paused or ended.  -1: automatic -- half a poll when the group is the only
+                       // one running (one trace group, or `concentrate` at work), 0 otherwise
     int concentrate = 1; // one GPU, several groups: admit into group 0 only while few traces survive a poll (see the admission)
     int poll = 4;      // SMC steps between two polls
     int groups = 2;    // trace groups stepping independently (engine permitting)
@@ -81,7 +85,9 @@ public:
     // queue: hand `m` slots to new traces of group g (s6 = m x (x, y, z, vx, vy, vz))
     virtual int admit(int g, const int *slots, const float *s6, int m) = 0;
     // queue: `poll` SMC steps over the active traces of group g (at most `active`), then the read-back of the slot states
-    virtual int launch(int g, int active, int poll) = 0;
+    // `poll` steps of group g; the state wait() hands back is the one after the first poll - lag of them (lag > 0: the host works on it
+    // while the last `lag` steps still run, and what it then asks for -- pauses, ends, admissions -- takes effect behind them)
+    virtual int launch(int g, int active, int poll, int lag) = 0;
     // block until the last launch of group g has landed; *active = traces of the group still running
     virtual int wait(int g, int *active) = 0;
     // after wait(g): has the trace in `slot` stopped?  *T = its successful iterations; rows() = its min(T + 1, ni) estimates
@@ -225,6 +231,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
         int active = 0; bool inflight = false;
         std::vector<int> busy;    // slots of this group's traces that have not delivered their record (running or paused)
         int npaused = 0;
+        int lag = 0;          // steps of the poll in flight that follow the state wait() will hand back
         int last_start = 0;   // traces on the device's list when the last poll's steps were launched
         double keep = 1.0;    // smoothed share of them still running when the poll was collected
     };
@@ -373,7 +380,8 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             for (size_t b = 0; b < q.busy.size(); b++) {
                 const int slot = q.busy[b];
                 int Tn = 0;
-                if (slot_paused[(size_t)slot] || !E.finished(g, slot, &Tn)) { q.busy[keep++] = slot; continue; }
+                if (!E.finished(g, slot, &Tn)) { q.busy[keep++] = slot; continue; }
+                if (slot_paused[(size_t)slot]) { slot_paused[(size_t)slot] = 0; q.npaused--; } // (stopped in the steps that were queued in front of its pause: lag)
                 seed_slot[(size_t)(2 * slot_seed[(size_t)slot] + slot_dir[(size_t)slot])] = -1;
                 const int rows = std::min(std::max(Tn, 0) + 1, ni); // + the iteration that failed (its corr is what the reference prints)
                 const size_t at = outbox.size();
@@ -496,7 +504,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                                     outbox.resize(at + 4 + (size_t)nr * 8);
                                     outbox[at] = (int32_t)s; outbox[at + 1] = dir; outbox[at + 2] = nr; outbox[at + 3] = nr;
                                     if (nr > 0) std::memcpy(&outbox[at + 4], X, (size_t)nr * sizeof(pnr_xest));
-                                    st.iters += nr;
+                                    st.iters += nr; // (the iterations whose records were collected; with a lag the device steps a running trace up to `lag` times more before the pause lands)
                                     st.ended++;
                                     if (!slot_paused[(size_t)slot]) want_pause(slot); else q.npaused--;
                                     slot_paused[(size_t)slot] = 0;
@@ -612,7 +620,11 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
         }
         if (q.active > 0) {
             q.last_start = q.active;
-            rc = E.launch(g, q.active, o.poll);
+            // the host's share of the next poll is covered by another group's steps, or by the last steps of this one
+            bool alone = true;
+            for (int k = 0; k < G; k++) alone = alone && (k == g || (grp[(size_t)k].active == 0 && !grp[(size_t)k].inflight));
+            q.lag = o.lag >= 0 ? std::min(o.lag, o.poll - 1) : (alone ? o.poll / 2 : 0);
+            rc = E.launch(g, q.active, o.poll, q.lag);
             if (rc) { err = E.error(); return fail(rc); }
             st.steps += o.poll;
             q.inflight = true;

@@ -104,7 +104,7 @@ def load():
                                            C.POINTER(i64), C.POINTER(i64)]
     L.pnr_sched_playback.argtypes = [C.POINTER(Params), i64, i64, i64, vp, i64, i32, i32, ALLGATHER_FN, vp, i64, TRACE_FN, vp, i32, i32, i32, i32, i32,
                                      vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
-    L.pnr_sched_playback2.argtypes = [C.POINTER(Params), i64, i64, i64, vp, i64, i32, i32, ALLGATHER_FN, vp, i64, TRACE_FN, vp, i32, i32, i32, i32, i32, i32, i32,
+    L.pnr_sched_playback2.argtypes = [C.POINTER(Params), i64, i64, i64, vp, i64, i32, i32, ALLGATHER_FN, vp, i64, TRACE_FN, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                                       vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.pnr_get_trace_log.argtypes = [vp, vp, i64, C.POINTER(i64)]
     L.pnr_shm_exchange_open.argtypes = [C.c_char_p, i32, i32, i64, C.POINTER(vp)]
@@ -464,7 +464,7 @@ class ShmExchange:
             self.handle = None
 
 
-def sched_playback(params, shape, seeds, trace_fn, rank=0, world=1, exchange=None, block_bytes=0, window=768, groups=1, poll=4, look0=0, look_pct=-1, tentative=True, target=-1):
+def sched_playback(params, shape, seeds, trace_fn, rank=0, world=1, exchange=None, block_bytes=0, window=768, groups=1, poll=4, look0=0, look_pct=-1, tentative=True, target=-1, lag=-1):
     """The streaming scheduler over a host engine that plays back map-free traces (pnr_sched_playback; no GPU): `trace_fn(pos_dir6)`
     -> (T, xc[ni][8]).  Returns nodes, links, traces used, iterations on this rank."""
     L = load()
@@ -495,7 +495,7 @@ def sched_playback(params, shape, seeds, trace_fn, rank=0, world=1, exchange=Non
     nodes = np.zeros(cap, NODE_DT)
     links = np.zeros((2 * cap + 2, 2), np.int32)
     check(L.pnr_sched_playback2(C.byref(params), w, h, l, s.ctypes.data, len(s), rank, world, xcb, xuser, block_bytes, tcb, None, window, groups, poll, look0, look_pct,
-                                int(bool(tentative)), int(target), nodes.ctypes.data, cap, C.byref(nn), links.ctypes.data, len(links), C.byref(nl), C.byref(nt), C.byref(it)))
+                                int(bool(tentative)), int(target), int(lag), nodes.ctypes.data, cap, C.byref(nn), links.ctypes.data, len(links), C.byref(nl), C.byref(nt), C.byref(it)))
     return nodes[:nn.value].copy(), links[:nl.value].copy(), nt.value, it.value
 
 

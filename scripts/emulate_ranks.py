@@ -71,8 +71,8 @@ def main():
         for spec in (a.opts.split(";") if a.opts else [""]):
             kv = dict(x.split("=") for x in spec.split(",") if x)
             kv = {k: int(v) for k, v in kv.items()}
-            for k in ("look0", "look_pct", "groups", "window", "poll", "tentative", "target"):
-                ctx.set_option(k, kv.get(k, {"look0": 0, "look_pct": -1, "groups": 0, "window": 0, "poll": 4, "tentative": 1, "target": -1}[k]))
+            for k in ("look0", "look_pct", "groups", "window", "poll", "tentative", "target", "lag"):
+                ctx.set_option(k, kv.get(k, {"look0": 0, "look_pct": -1, "groups": 0, "window": 0, "poll": 4, "tentative": 1, "target": -1, "lag": -1}[k]))
             best = None
             for rep in range(a.reps):
                 name = f"pnr_emu_{os.getpid()}_{world}_{rep}_{abs(hash(spec)) % 100000}"
@@ -90,7 +90,7 @@ def main():
                             out[0] = (res, 1e3 * (time.perf_counter() - t0))
                         else:
                             out[r] = (lib.sched_playback(p, shape, seeds, lookup, r, world, X[r], window=kv.get("window", 768), groups=kv.get("groups", 0) or (1 if world > 1 else 2),
-                                                         poll=kv.get("poll", 4), look0=kv.get("look0", 0), look_pct=kv.get("look_pct", -1), tentative=bool(kv.get("tentative", 1)), target=kv.get("target", -1)), 0.0)
+                                                         poll=kv.get("poll", 4), look0=kv.get("look0", 0), look_pct=kv.get("look_pct", -1), tentative=bool(kv.get("tentative", 1)), target=kv.get("target", -1), lag=kv.get("lag", -1)), 0.0)
                     except Exception as e:  # noqa: BLE001
                         out[r] = e
 

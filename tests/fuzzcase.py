@@ -36,7 +36,7 @@ def run_case(L, case, stats, desc, driver=None, big=False):
                                     for _ in range(int(rs.randint(1, 3)))])
     knobs = dict(groups=groups, window=int(rs.choice([8, 32, 768])), look0=int(rs.choice([2, 16, 128])), poll=int(rs.choice([1, 4, 7])))
     rk = np.random.RandomState(900000 + case)  # (a stream of its own: the cases keep the stacks and parameters they had before these knobs existed)
-    knobs.update(target=int(rk.choice([-1, 0, 4, 16, 64])), overfill=int(rk.randint(2)), concentrate=int(rk.randint(2)), sums_deep=int(rk.choice([-1, 0, 1])))
+    knobs.update(target=int(rk.choice([-1, 0, 4, 16, 64])), overfill=int(rk.randint(2)), concentrate=int(rk.randint(2)), sums_deep=int(rk.choice([-1, 0, 1])), lag=int(rk.choice([-1, 0, 1, 2])))
     desc.update(knobs=knobs)
     p = pnr_amd.make_params(sigmas=sigs, somaradius=rad, step=step, kappa=kappa, zdist=zdist, np_=np_, ni=ni, tolerance=tol, znccth=znccth, nodepervol=npv, vol=vol)
     c = pnr_amd.Context(p, 0)

@@ -340,7 +340,7 @@ def test_scheduler_random_crossing_traces(case):
     lookup = lambda q6: W["traces"][np.asarray(q6, np.float32).tobytes()]
     world = int(rs.choice([1, 1, 2, 3]))
     kw = dict(window=int(rs.choice([2, 4, 8, 64, 768])), poll=int(rs.choice([1, 2, 5])), groups=int(rs.choice([1, 2, 3])), look0=int(rs.choice([0, 1, 3, 16])),
-              look_pct=int(rs.choice([-1, 0, 50, 400])), block_bytes=int(rs.choice([0, 900, 4096])), target=int(rs.choice([-1, 0, 2, 6, 40])))
+              look_pct=int(rs.choice([-1, 0, 50, 400])), block_bytes=int(rs.choice([0, 900, 4096])), target=int(rs.choice([-1, 0, 2, 6, 40])), lag=int(rs.choice([-1, 0, 1, 3])))
     iters = {}
     for tentative in (True, False):
         X = multigpu.ThreadExchange(world)
