@@ -270,7 +270,7 @@ int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
 /* Scheduling and host-side knobs of a context; none of them changes a result (the library reads no environment variable).
  *   window (0 = automatic: 1536 on one GPU, 768 sharded or without the tentative replay) trace slots kept busy | look0, look_pct (0 / -1 = automatic) admission lookahead max(look0, frontier*look_pct/100)
  *   target (-1 = automatic: 200 on one GPU, 128 per rank sharded, 0 = off without the tentative replay) seeds are admitted only while fewer traces than this are running |
- *   lag (-1 = automatic: half a poll when no other trace group covers the host's share of a poll, else 0) steps of a poll that run on while the host works on the state in front of them |
+ *   lag (-1 = automatic: half a poll when no other trace group covers the host's share of a poll, else one step) steps of a poll that run on while the host works on the state in front of them |
  *   overfill (1) the target is the mean over a poll | concentrate (1) with several trace groups new seeds go to one group while few traces survive a poll |
  *   sums_deep (-1 = automatic: launches of at most sums_deep_max (64) traces, or one trace group; 0 / 1) form of the ordered sums (four chunk buffers in turn) |
  *   poll (4) SMC steps between polls | groups (0 = automatic: 2 on one GPU, 1 sharded; 1..4) trace groups on separate streams | split_x10 (0 = automatic), max_split (24) sampling

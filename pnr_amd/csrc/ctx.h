@@ -62,7 +62,7 @@ struct Options {
     int target = -1;          // running traces the admission keeps up (0: off, -1: automatic -- 200 on one GPU with the tentative replay)
     int sums_deep = -1;       // form of the ordered sums: -1 automatic (smc_phased.hip sums_deep()), 0 two buffers folded, 1 four buffers in turn
     int sums_deep_max = 64;   // ... automatic with several trace groups: the four-buffer form for launches of at most this many traces
-    int lag = -1;             // steps of a poll that run while the host works on the state in front of them (-1 automatic, stream_sched.h)
+    int lag = -1;             // steps of a poll that run while the host works on the state in front of them (-1 automatic: stream_sched.h)
     int concentrate = 1;      // several trace groups: new seeds go to group 0 only while few traces survive a poll (experiment switch)
     int overfill = 1;         // the target is the mean over a poll, not the count at its start (experiment switch)
     int poll = 4;             // SMC steps between two polls

@@ -56,7 +56,8 @@ struct SchedOptions {
     int lag = -1;      // steps of a poll that run while the host works on the state in front of them (see StreamEngine::launch): hides the host's
                        // share of a poll (tentative pass, exchange) where no other trace group covers it, at the price of `lag` more
                        // iterations for every trace about to be paused or ended.  -1: automatic -- half a poll when the group is the only
-                       // one running (one trace group, or `concentrate` at work), 0 otherwise
+                       // one running (one trace group, or `concentrate` at work), one step otherwise (measured with two groups on one GPU,
+                       // lag 0 / 1 / 2 / 3: tracing 988 / 929 / 945 / 968 ms; 8 emulated ranks, one group each: 391 / 316 / 308 / 304 ms)
     int concentrate = 1; // one GPU, several groups: admit into group 0 only while few traces survive a poll (see the admission)
     int poll = 4;      // SMC steps between two polls
     int groups = 2;    // trace groups stepping independently (engine permitting)
@@ -623,7 +624,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             // the host's share of the next poll is covered by another group's steps, or by the last steps of this one
             bool alone = true;
             for (int k = 0; k < G; k++) alone = alone && (k == g || (grp[(size_t)k].active == 0 && !grp[(size_t)k].inflight));
-            q.lag = o.lag >= 0 ? std::min(o.lag, o.poll - 1) : (alone ? o.poll / 2 : 0);
+            q.lag = o.lag >= 0 ? std::min(o.lag, o.poll - 1) : (alone ? o.poll / 2 : std::min(1, o.poll - 1));
             rc = E.launch(g, q.active, o.poll, q.lag);
             if (rc) { err = E.error(); return fail(rc); }
             st.steps += o.poll;
