@@ -479,9 +479,11 @@ def test_empty_inputs_end_to_end():
 
 
 @pytest.mark.parametrize("opts", ["sums_deep=0", "sums_deep=1", "target=0,look0=64,look_pct=50", "target=40,overfill=0", "target=24,concentrate=0,groups=2",
-                                  "target=24,concentrate=1,groups=2,poll=2", "groups=1,target=500"])
+                                  "target=24,concentrate=1,groups=2,poll=2", "groups=1,target=500", "lag=0", "lag=3,poll=4,groups=2", "groups=1,lag=2,poll=3",
+                                  "groups=1,lag=5,poll=6,target=30"])
 def test_scheduler_and_kernel_forms_same_graph(smc_driver, opts):
-    """the admission rules of the streaming scheduler (running-trace target, overfill, concentration on one trace group) and the two
+    """the admission rules of the streaming scheduler (running-trace target, overfill, concentration on one trace group), the lag of
+    the host's view behind the device's steps and the two
     forms of the ordered sums (ph_sums<false>: two folded chunk buffers, ph_sums<true>: four buffers in turn) are performance choices:
     the node graph is the one-shot graph whichever is taken"""
     if smc_driver != "phased":
