@@ -13,6 +13,12 @@ wait.  The final result is untouched (the final replay decides).  [Result: 177 k
 the cost model; with a window of 1536 slots and a lookahead of max(256, 100 %) 1255 ms -- built in stream_sched.h, measured on the GPU:
 1544 -> 1179 ms.]
 
+`target`: admit while fewer than `target` traces are RUNNING instead of by a lookahead in ranks (late seeds need 8 iterations per trace,
+early ones 67: a rank window starts too many traces at the beginning and too few later).  [Result: 1255 -> 1165 ms in the model at 200
+running traces (160 ... 256: within 1 %), with the rank lookahead max(512, 200 %) as a bound that no longer binds; a target that ramps up
+with the frontier is worse (1172 - 1217 ms); built in stream_sched.h (option `target`), measured on the GPU: 1172 -> 1131 ms.]  `detail`:
+a dict that receives the iterations run per trace (waste by rank: 11.8 k of the 35 k wasted iterations belong to the first 200 seeds).
+
 `far` / `far_max`: also start, at most `far` per poll, seeds up to `far_max` ranks beyond the frontier whose 8^3 block no admitted trace
 has touched yet (nobody in front of them has been there, so their traces are probably needed in full): 1255 -> 1223 ms in the model at
 best, not built.
