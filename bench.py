@@ -176,6 +176,7 @@ def main():
         a.cpu_baseline = "off"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))  # before torch / HIP are even imported
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (a rank started by someone else's torch.distributed.run: before HIP initialises)
     import numpy as np
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
