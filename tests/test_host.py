@@ -101,6 +101,40 @@ def test_replay_matches_oracle(oracle, vol, nodepervol):
     assert (nodes["type"][1:] == 6).sum() >= 1  # END markers present
 
 
+def test_replay_many_voxels_matches_oracle(oracle):
+    """the replay's voxel table (Replayer::CellMap, open addressing, grows by doubling from 2^17 slots) against the oracle's dense
+    arrays on synthetic random-walk traces that put > 80 000 nodes (each with its four in-plane neighbours: several hundred thousand voxels) and cross each other (DENSITY links, vol = 5 neighbours)"""
+    rs = np.random.RandomState(11)
+    shape = (96, 160, 192)  # l, h, w
+    l, h, w = shape
+    ni, nseed = 200, 700
+    s = np.zeros((nseed, 8), np.float32)
+    s[:, 0] = rs.uniform(4, w - 5, nseed); s[:, 1] = rs.uniform(4, h - 5, nseed); s[:, 2] = rs.uniform(4, l - 5, nseed)
+    s[:, 3:6] = rs.randn(nseed, 3); s[:, 6] = 0.9; s[:, 7] = 2.0
+    T = rs.randint(60, ni + 1, 2 * nseed).astype(np.int32)
+    xc = np.zeros((2 * nseed, ni, 8), np.float32)
+    for t in range(2 * nseed):
+        d = rs.randn(3); d /= np.linalg.norm(d)
+        steps = 1.1 * d + 0.5 * rs.randn(ni, 3)
+        pos = s[t // 2, :3] + np.cumsum(steps, 0)
+        pos[:, 0] = np.clip(pos[:, 0], 0, w - 1.01); pos[:, 1] = np.clip(pos[:, 1], 0, h - 1.01); pos[:, 2] = np.clip(pos[:, 2], 0, l - 1.01)
+        xc[t, :, 0:3] = pos
+        xc[t, :, 3:6] = d
+        xc[t, :, 6] = 2.0
+        xc[t, :, 7] = rs.uniform(0.4, 0.9, ni)
+    for npv, vol, least in ((4, 5, 80000), (1, 1, 15000)):
+        nodes_o, links_o, nt_o = orc.replay(oracle, s, T, xc, ni, shape, npv, vol)
+        p = pnr_amd.make_params(sigmas=[2.0], np_=24, ni=ni, nodepervol=npv, vol=vol)
+        seeds = np.zeros(nseed, lib.SEED_DT)
+        for i, k in enumerate(lib.SEED_DT.names):
+            seeds[k] = s[:, i]
+        nodes, links, nt = lib.replay(p, shape, seeds, T, xc.view(lib.XEST_DT).reshape(len(T), ni))
+        assert nt == nt_o and len(nodes) == len(nodes_o) > least, (len(nodes), len(nodes_o))
+        for k in nodes.dtype.names:
+            assert np.array_equal(nodes[k], nodes_o[k]), k
+        assert np.array_equal(links, links_o)
+
+
 @pytest.mark.parametrize("vol,tree_min", [(5, 10), (1, 3)])
 def test_reconstruct_matches_oracle(oracle, vol, tree_min):
     """reconstruct() chain (Advantra_plugin.cpp:2096-2181): the grid-accelerated host implementation visits
