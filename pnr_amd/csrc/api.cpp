@@ -688,18 +688,25 @@ struct PlaybackEngine final : pnr::StreamEngine {
     void *user;
     std::vector<Slot> sl;
     std::vector<std::vector<int>> active; // per group
+    // stream order, modelled: a control() is queued on its group's stream and has only run for sure once that group has been waited
+    // for (or settled); until then no OTHER group may be handed a slot it names (the HIP engine would race: advisor finding, round 3)
+    std::vector<int> ctl_pending; // per slot: the group whose control() names it and may not have run yet, or -1
     int s_active[4] = {0, 0, 0, 0};
     std::unordered_map<int64_t, uint8_t> den;
     std::string msg;
     int64_t steps = 0;
     PlaybackEngine(const pnr_params &p, int64_t w, int64_t h, int window, pnr_trace_fn f, void *u)
-        : prm(p), W(w), H(h), ni(p.ni), nslots(window), fn(f), user(u), sl((size_t)window), active(4) {}
+        : prm(p), W(w), H(h), ni(p.ni), nslots(window), fn(f), user(u), sl((size_t)window), active(4), ctl_pending((size_t)window, -1) {}
     const char *error() const override { return msg.c_str(); }
     int slots() const override { return nslots; }
     int max_groups() const override { return 4; }
     int admit(int g, const int *slots, const float *s6, int m) override
     {
         for (int j = 0; j < m; j++) {
+            if (ctl_pending[(size_t)slots[j]] >= 0 && ctl_pending[(size_t)slots[j]] != g) {
+                msg = "slot handed to another trace group before the control() that frees it has run";
+                return PNR_E_STATE;
+            }
             Slot &s = sl[(size_t)slots[j]];
             s = Slot();
             s.used = true;
@@ -739,7 +746,17 @@ struct PlaybackEngine final : pnr::StreamEngine {
         }
         return PNR_OK;
     }
-    int wait(int g, int *act) override { *act = s_active[g]; return PNR_OK; }
+    int wait(int g, int *act) override
+    {
+        *act = s_active[g];
+        for (int &p : ctl_pending) if (p == g) p = -1;
+        return PNR_OK;
+    }
+    int settle(int g) override
+    {
+        for (int &p : ctl_pending) if (p == g) p = -1;
+        return PNR_OK;
+    }
     bool finished(int, int slot, int *T) const override { *T = sl[(size_t)slot].s_T; return sl[(size_t)slot].s_done; }
     const pnr_xest *rows(int slot) const override { return sl[(size_t)slot].xc.data(); }
     int progress(int, int slot) const override { return sl[(size_t)slot].s_it; }
@@ -747,6 +764,7 @@ struct PlaybackEngine final : pnr::StreamEngine {
     {
         std::vector<int> &a = active[(size_t)g];
         for (int j = 0; j < np; j++) {
+            ctl_pending[(size_t)pause[j]] = g;
             auto f = std::find(a.begin(), a.end(), pause[j]);
             if (f == a.end()) { // (stopped by itself in the steps that ran behind the state the scheduler decided on)
                 if (!sl[(size_t)pause[j]].done) { msg = "pause of a trace that is not stepped"; return PNR_E_STATE; }
@@ -774,6 +792,7 @@ int pnr_sched_playback(const pnr_params *p, int64_t w, int64_t h, int64_t l, con
                        int poll, int look0, int look_pct, pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links,
                        int64_t *n_links, int64_t *n_traces_used, int64_t *n_iterations)
 {
+    if (window < 2) window = 2; // (this entry point has always clamped; only pnr_sched_playback2 treats a window below 2 as a set-up failure)
     return pnr_sched_playback2(p, w, h, l, seeds, n, rank, world, exchange, xuser, block_bytes, trace, tuser, window, groups, poll, look0, look_pct,
                                /*tentative*/ 1, /*target*/ -1, /*lag*/ -1, nodes, cap_nodes, n_nodes, links, cap_links, n_links, n_traces_used, n_iterations);
 }

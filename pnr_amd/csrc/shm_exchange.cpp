@@ -20,6 +20,7 @@
 #include <sys/stat.h>
 #include <thread>
 #include <time.h>
+#include <signal.h>
 #include <unistd.h>
 
 namespace pnr { void set_error(const char *fmt, ...); }
@@ -33,10 +34,20 @@ struct ShmHeader {
     std::atomic<uint32_t> phase;   // barrier: generation
     std::atomic<uint32_t> attached, failed; // attached: ranks that mapped the segment (reported when the attach barrier times out)
     uint64_t stamp;                // CLOCK_REALTIME ns at creation (diagnostics)
+    uint32_t owner_pid;            // the creator's process id: a later job's rank 0 only declares a segment stale when that process is gone
 };
 constexpr uint32_t SHM_MAGIC = 0x504e5258u; // "PNRX"
 constexpr uint32_t SHM_DEAD = 0x44454144u;  // "DEAD"
 constexpr size_t HDR = 256;
+
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
 } // namespace
 
 struct pnr_shm_exchange {
@@ -66,7 +77,7 @@ static bool shm_barrier(pnr_shm_exchange *x)
     const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spins = 0; h->phase.load(std::memory_order_acquire) == gen; spins++) {
         if (h->failed.load(std::memory_order_relaxed)) return false;
-        if ((spins & 255) != 255) { __builtin_ia32_pause(); continue; }
+        if ((spins & 255) != 255) { cpu_relax(); continue; }
         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (waited < 250e-6) continue;
         std::this_thread::sleep_for(std::chrono::microseconds(waited < 5e-3 ? 20 : 200));
@@ -95,7 +106,9 @@ int pnr_shm_exchange_open(const char *name, int rank, int world, int64_t capacit
     const auto t0 = std::chrono::steady_clock::now();
     if (rank == 0) {
         // A stale segment of a crashed run under the same name: a rank of THIS job may have opened it already (it was there before
-        // we were) -- mark it dead first, so that whoever waits on it gives up and opens the name again, then remove the name.
+        // we were) -- mark it dead first, so that whoever waits on it gives up and opens the name again, then remove the name.  Only
+        // a segment whose creator is gone is stale: one whose creator still runs belongs to a live job that is attaching right now
+        // (the name is removed once everybody is attached) -- its name is taken over, as ever, but its ranks are left alone.
         {
             const int ofd = shm_open(x->name.c_str(), O_RDWR, 0600);
             struct stat sb;
@@ -103,8 +116,13 @@ int pnr_shm_exchange_open(const char *name, int rank, int world, int64_t capacit
                 void *m = mmap(nullptr, HDR, PROT_READ | PROT_WRITE, MAP_SHARED, ofd, 0);
                 if (m != MAP_FAILED) {
                     ShmHeader *old = (ShmHeader *)m;
-                    old->magic.store(SHM_DEAD, std::memory_order_release);
-                    old->failed.store(1, std::memory_order_release);
+                    const uint32_t opid = old->owner_pid;
+                    const bool initialised = old->magic.load(std::memory_order_acquire) == SHM_MAGIC;
+                    const bool owner_gone = !initialised || opid == 0 || (kill((pid_t)opid, 0) != 0 && errno == ESRCH);
+                    if (owner_gone) {
+                        old->magic.store(SHM_DEAD, std::memory_order_release);
+                        old->failed.store(1, std::memory_order_release);
+                    }
                     munmap(m, HDR);
                 }
             }
@@ -157,6 +175,7 @@ int pnr_shm_exchange_open(const char *name, int rank, int world, int64_t capacit
             x->h->world = (uint32_t)world;
             x->h->capacity = cap;
             x->h->stamp = (uint64_t)now.tv_sec * 1000000000ull + (uint64_t)now.tv_nsec;
+            x->h->owner_pid = (uint32_t)getpid();
             x->h->arrived.store(0); x->h->phase.store(0); x->h->attached.store(0); x->h->failed.store(0);
             x->h->magic.store(SHM_MAGIC, std::memory_order_release);
         } else {
@@ -180,7 +199,20 @@ int pnr_shm_exchange_open(const char *name, int rank, int world, int64_t capacit
         }
         x->h->attached.fetch_add(1);
         if (!shm_barrier(x)) { // everybody is attached: the name can go (the mappings stay)
-            if (rank != 0 && x->h->magic.load(std::memory_order_acquire) == SHM_DEAD && !late(120.0)) { unmap(); continue; } // it was a stale one after all
+            // it was a stale one after all?  Rank 0 of this job may be a moment away from saying so (a crashed job's segment can carry
+            // `failed` already): look again for a while -- at the magic word, and at whether the name leads to another segment by now
+            bool stale = false;
+            for (int tries = 0; rank != 0 && !stale && tries < 400 && !late(120.0); tries++) {
+                if (x->h->magic.load(std::memory_order_acquire) == SHM_DEAD) { stale = true; break; }
+                struct stat mine, named;
+                const int nfd = shm_open(x->name.c_str(), O_RDWR, 0600);
+                if (nfd >= 0) {
+                    if (fstat(x->fd, &mine) == 0 && fstat(nfd, &named) == 0 && (mine.st_ino != named.st_ino || mine.st_dev != named.st_dev)) stale = true;
+                    close(nfd);
+                }
+                if (!stale) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            }
+            if (stale) { unmap(); continue; }
             pnr::set_error("ranks did not all attach to %s (%u of %d did)", x->name.c_str(), x->h->attached.load(), world);
             unmap();
             if (x->owner) shm_unlink(x->name.c_str());

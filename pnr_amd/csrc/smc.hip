@@ -736,10 +736,23 @@ int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T_out, 
 }
 
 namespace {
+// Monotone: a voxel's density only ever grows (the replay adds nodes; a soma voxel is saturated from the start), and updates of
+// different trace groups arrive on different streams in no particular order -- so a value is only written over a smaller one (a
+// compare-and-swap on the byte's dword), and a late older update can never lower what a newer one wrote.
 __global__ void den_scatter(unsigned char *den, const i64 *idx, const unsigned char *val, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) den[idx[i]] = val[i];
+    if (i >= n) return;
+    const i64 at = idx[i];
+    unsigned *w = (unsigned *)(den + (at & ~(i64)3)); // (the map is allocated in whole dwords)
+    const int sh = (int)(at & 3) * 8;
+    const unsigned v = val[i];
+    unsigned old = __atomic_load_n(w, __ATOMIC_RELAXED);
+    while (((old >> sh) & 0xffu) < v) {
+        const unsigned got = atomicCAS(w, old, (old & ~(0xffu << sh)) | (v << sh));
+        if (got == old) break;
+        old = got;
+    }
 }
 } // namespace
 
@@ -749,10 +762,10 @@ int pnr_density_reset(pnr_ctx *c)
         hipFree(c->d_den);
         c->d_den = nullptr;
         c->den_cap = 0;
-        PNR_HIP(hipMalloc(&c->d_den, (size_t)c->N));
+        PNR_HIP(hipMalloc(&c->d_den, ((size_t)c->N + 3) / 4 * 4)); // whole dwords: den_scatter updates a byte through its dword
         c->den_cap = c->N;
     }
-    PNR_HIP(hipMemsetAsync(c->d_den, 0, (size_t)c->N, c->stream));
+    PNR_HIP(hipMemsetAsync(c->d_den, 0, ((size_t)c->N + 3) / 4 * 4, c->stream));
     PNR_HIP(hipStreamSynchronize(c->stream)); // trace jobs run on their own streams
     if (!c->soma_vox.empty()) {
         // a trace that reaches a soma voxel stops there in the replay (tracker.cpp:858-869): for the kernels' early stop

@@ -750,6 +750,9 @@ struct pnr_phased {
     hipStream_t stg[MAXG] = {}, st_den = nullptr; // [1..]: the further trace groups of the streaming tracer; density uploads
     hipEvent_t ev_start = nullptr;
     hipEvent_t ev_state[4] = {}; // per trace group: the state copies of its last launch have landed (PhasedEngine::wait)
+    // per trace group: the last upload from its pinned admission / control / density staging has been consumed.  A group whose traces are
+    // all paused is not launched, so no wait() lies between two of its turns: the staging is only rewritten behind these events.
+    hipEvent_t ev_adm[4] = {}, ev_ctl[4] = {}, ev_den[4] = {};
 };
 
 static void phased_free(pnr_phased *h)
@@ -797,6 +800,9 @@ void pnr_phased_destroy(pnr_phased *h)
     if (h->st_den) (void)hipStreamDestroy(h->st_den);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     for (hipEvent_t &e : h->ev_state) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : h->ev_adm) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : h->ev_ctl) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t &e : h->ev_den) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -851,6 +857,9 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
         PNR_HIP(hipStreamCreateWithFlags(&h->st_den, hipStreamNonBlocking));
         PNR_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
         for (hipEvent_t &e : h->ev_state) PNR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t &e : h->ev_adm) PNR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t &e : h->ev_ctl) PNR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t &e : h->ev_den) PNR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // stash rows of a trace hold at most np + 1 chains: full groups of 64 + the last group's stride (16 / 32 / 64)
     const int ngf = (np + 1) / 64, rem = (np + 1) - 64 * ngf, R = rem == 0 ? 0 : (rem > 32 ? 64 : (rem > 16 ? 32 : 16)), W = 64 * ngf + R;
@@ -1113,11 +1122,13 @@ struct PhasedEngine final : pnr::StreamEngine {
     int admit(int g, const int *slots, const float *s6, int m) override
     {
         Grp &q = grp[g];
-        std::memcpy(q.h_new, slots, (size_t)m * 4);     // pinned staging of this group: its previous admission was consumed before
-        std::memcpy(q.h_new_s6, s6, (size_t)m * 24);    // the wait() that precedes every admission
+        PE_HIP(hipEventSynchronize(h->ev_adm[g]));      // pinned staging of this group: its previous admission has been consumed
+        std::memcpy(q.h_new, slots, (size_t)m * 4);     // (normally long ago: a wait() lies between two admissions unless the group
+        std::memcpy(q.h_new_s6, s6, (size_t)m * 24);    // had nothing to step)
         PE_HIP(hipMemcpyAsync(q.d_new, q.h_new, (size_t)m * 4, hipMemcpyHostToDevice, q.st));
         PE_HIP(hipMemcpyAsync(q.d_new_s6, q.h_new_s6, (size_t)m * 24, hipMemcpyHostToDevice, q.st));
         hipLaunchKernelGGL(ph_admit, dim3(1), dim3(256), 0, q.st, q.P, h->d_s6, (const int *)q.d_new, (const float *)q.d_new_s6, m, q.lp, E.ni);
+        PE_HIP(hipEventRecord(h->ev_adm[g], q.st));
         return PNR_OK;
     }
     int launch(int g, int active, int poll, int lag) override
@@ -1187,11 +1198,18 @@ struct PhasedEngine final : pnr::StreamEngine {
     {
         Grp &q = grp[g];
         int *hc = h->h_ctl + (size_t)g * 2 * h->stream_cap, *dc = h->d_ctl + (size_t)g * 2 * h->stream_cap;
-        if (np_ > 0) std::memcpy(hc, pause, (size_t)np_ * 4);      // pinned staging of this group: free, its last steps have been waited for
+        PE_HIP(hipEventSynchronize(h->ev_ctl[g]));                  // pinned staging of this group: its previous lists have been consumed
+        if (np_ > 0) std::memcpy(hc, pause, (size_t)np_ * 4);
         if (nr > 0) std::memcpy(hc + h->stream_cap, resume, (size_t)nr * 4);
         if (np_ > 0) PE_HIP(hipMemcpyAsync(dc, hc, (size_t)np_ * 4, hipMemcpyHostToDevice, q.st));
         if (nr > 0) PE_HIP(hipMemcpyAsync(dc + h->stream_cap, hc + h->stream_cap, (size_t)nr * 4, hipMemcpyHostToDevice, q.st));
         hipLaunchKernelGGL(ph_control, dim3(1), dim3(256), 0, q.st, q.P, (const int *)dc, np_, (const int *)(dc + h->stream_cap), nr, q.lp);
+        PE_HIP(hipEventRecord(h->ev_ctl[g], q.st));
+        return PNR_OK;
+    }
+    int settle(int g) override
+    {
+        PE_HIP(hipStreamSynchronize(grp[g].st));
         return PNR_OK;
     }
     int density_update(const pnr::Replayer &r, int g) override
@@ -1217,6 +1235,7 @@ struct PhasedEngine final : pnr::StreamEngine {
             PE_HIP(hipMalloc(&h->d_den_val[g], cap));
             h->den_cap[g] = cap;
         }
+        PE_HIP(hipEventSynchronize(h->ev_den[g])); // the previous update's copies have left the pinned staging
         for (size_t i = 0; i < nt; i++) {
             h->h_den_idx[g][i] = r.touched[i];
             h->h_den_val[g][i] = (unsigned char)r.den_at(r.touched[i]); // final value: duplicates agree
@@ -1224,8 +1243,9 @@ struct PhasedEngine final : pnr::StreamEngine {
         PE_HIP(hipMemcpyAsync(h->d_den_idx[g], h->h_den_idx[g], nt * 8, hipMemcpyHostToDevice, q.st));
         PE_HIP(hipMemcpyAsync(h->d_den_val[g], h->h_den_val[g], nt, hipMemcpyHostToDevice, q.st));
         const int rc = pnr_density_scatter_async(c, h->d_den_idx[g], h->d_den_val[g], nt, q.st);
-        if (rc) msg = pnr_last_error();
-        return rc;
+        if (rc) { msg = pnr_last_error(); return rc; }
+        PE_HIP(hipEventRecord(h->ev_den[g], q.st));
+        return PNR_OK;
     }
     void drain() override
     {

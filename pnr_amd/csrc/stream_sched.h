@@ -103,6 +103,8 @@ public:
     // push the density of the voxels in r.touched (final values r.den_at) to the engine's map, in front of group g's next steps
     // (g's last steps have been waited for; the other groups may see a voxel before or after the update: both are under-counts)
     virtual int density_update(const Replayer &r, int g) = 0;
+    // block until everything queued for group g (control, admissions) has executed; only called for a group with nothing in flight
+    virtual int settle(int g) { (void)g; return 0; }
     virtual void drain() = 0;
     virtual const char *error() const { return ""; }
 };
@@ -231,6 +233,11 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     struct Grp {
         int active = 0; bool inflight = false;
         std::vector<int> busy;    // slots of this group's traces that have not delivered their record (running or paused)
+        // Slots of traces the HOST ended on a final verdict.  The device may still be stepping such a trace (the last `lag` steps of the
+        // poll in flight) and the control() that takes it off the group's list is only queued behind them: the group itself may reuse the
+        // slot at once (its admission follows in stream order), another group -- another stream -- only after this group's next wait()
+        // or settle() has shown that the control() has run.
+        std::vector<int> held;
         int npaused = 0;
         int lag = 0;          // steps of the poll in flight that follow the state wait() will hand back
         int last_start = 0;   // traces on the device's list when the last poll's steps were launched
@@ -376,6 +383,8 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             if (rc) { err = E.error(); return fail(rc); }
             q.inflight = false;
             st.polls++;
+            free_slots.insert(free_slots.end(), q.held.begin(), q.held.end()); // (the control() that removed them ran before the state copy)
+            q.held.clear();
             for (int slot : q.busy) slot_fresh[(size_t)slot] = 0;
             size_t keep = 0;
             for (size_t b = 0; b < q.busy.size(); b++) {
@@ -394,6 +403,11 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                 free_slots.push_back(slot);
             }
             q.busy.resize(keep);
+        } else if (!q.held.empty()) { // nothing in flight to wait for: make sure the queued control() has run before other groups may take the slots
+            rc = E.settle(g);
+            if (rc) { err = E.error(); return fail(rc); }
+            free_slots.insert(free_slots.end(), q.held.begin(), q.held.end());
+            q.held.clear();
         }
         // ---- the finished records reach the replay: directly, or through the all-gather of every rank's block -- once per rotation
         // of the trace groups (every rank runs the same number of groups, so all of them exchange in the same turns)
@@ -512,7 +526,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                                     seed_slot[(size_t)(2 * s + dir)] = -1;
                                     slot_seed[(size_t)slot] = -1;
                                     q.busy.erase(std::find(q.busy.begin(), q.busy.end(), slot));
-                                    free_slots.push_back(slot); // (control() takes it off the device's list before this turn's admissions)
+                                    q.held.push_back(slot); // (control() takes it off the device's list before this turn's admissions of THIS group)
                                     ended_any = true;
                                 } else {
                                     if (here && !slot_paused[(size_t)slot]) {
@@ -562,7 +576,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
         int m = 0, m_max = 2 * NT;
         if (G > 1) { // keep the groups the same size: this one is filled up to its share of what the window will hold
             const int64_t ahead = next < lim ? (std::min<int64_t>(lim, n) - next + world - 1) / world : 0;
-            const int64_t room = std::min<int64_t>((int64_t)free_slots.size() / 2, ahead);
+            const int64_t room = std::min<int64_t>((int64_t)(free_slots.size() + q.held.size()) / 2, ahead);
             int64_t total = 2 * std::max<int64_t>(room, 0);
             int least = q.active;
             for (int k = 0; k < G; k++) { total += grp[(size_t)k].active; least = std::min(least, grp[(size_t)k].active); }
@@ -586,7 +600,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             m_max = std::min(m_max, std::max(0, goal - q.active));
         }
         new_slots.clear(); new_s6.clear();
-        while (m + 2 <= m_max && next < n && free_slots.size() >= 2 && next < lim) {
+        while (m + 2 <= m_max && next < n && free_slots.size() + q.held.size() >= 2 && next < lim) {
             const pnr_seed &sd = seeds[next];
             if (r.seed_saturated(sd)) {
                 outbox.insert(outbox.end(), {(int32_t)next, -1, 0, 0});
@@ -595,8 +609,9 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                 continue;
             }
             for (int dir = 0; dir < 2; dir++) {
-                const int slot = free_slots.back();
-                free_slots.pop_back();
+                int slot; // (slots this group's own control() frees first: nobody else may have them yet)
+                if (!q.held.empty()) { slot = q.held.back(); q.held.pop_back(); }
+                else { slot = free_slots.back(); free_slots.pop_back(); }
                 slot_seed[(size_t)slot] = next; slot_dir[(size_t)slot] = dir; slot_group[(size_t)slot] = g; slot_paused[(size_t)slot] = 0; slot_fresh[(size_t)slot] = 1; slot_pub[(size_t)slot] = 0;
                 seed_slot[(size_t)(2 * next + dir)] = slot;
                 q.busy.push_back(slot);

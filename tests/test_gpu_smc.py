@@ -480,7 +480,11 @@ def test_empty_inputs_end_to_end():
 
 @pytest.mark.parametrize("opts", ["sums_deep=0", "sums_deep=1", "target=0,look0=64,look_pct=50", "target=40,overfill=0", "target=24,concentrate=0,groups=2",
                                   "target=24,concentrate=1,groups=2,poll=2", "groups=1,target=500", "lag=0", "lag=3,poll=4,groups=2", "groups=1,lag=2,poll=3",
-                                  "groups=1,lag=5,poll=6,target=30"])
+                                  "groups=1,lag=5,poll=6,target=30",
+                                  # a host-ended trace's slot must not reach the OTHER trace group before its own group's control() has
+                                  # run (advisor finding of round 3): lag = poll - 1 keeps the device stepping it as long as possible,
+                                  # the small target and the concentration hand nearly every freed slot to group 0
+                                  "target=16,concentrate=1,groups=2,poll=4,lag=3,window=48", "target=12,concentrate=0,groups=3,poll=3,lag=2,window=32"])
 def test_scheduler_and_kernel_forms_same_graph(smc_driver, opts):
     """the admission rules of the streaming scheduler (running-trace target, overfill, concentration on one trace group), the lag of
     the host's view behind the device's steps and the two
