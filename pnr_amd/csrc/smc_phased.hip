@@ -24,21 +24,9 @@ namespace {
 
 enum { FL_RES = 0, FL_STOP = 1, FL_T = 2, FL_IT = 3, FL_DONE = 4, FL_OX = 5, FL_OY = 6, FL_OZ = 7, FL_Y0 = 8, FL_Y1 = 9, FL_Z0 = 10, FL_Z1 = 11, FL_FAST = 12, FL_NCH = 13, FL_PAUSE = 14, FL_N = 16 };
 constexpr int PH_THREADS = 1024; // sampling work-group: 16 waves (<= 128 VGPRs each)
-#ifndef PNR_PH_CS
-#define PNR_PH_CS 54
-#endif
-constexpr int PH_CS = PNR_PH_CS; // the sampling kernel holds nothing but the cube in LDS: 54 x 54 rows of 56 bytes = 163 296 B of the 160 KB (53 costs 1.5 %)
+constexpr int PH_CS = 54; // the sampling kernel holds nothing but the cube in LDS: 54 x 54 rows of 56 bytes = 163 296 B of the 160 KB (53 costs 1.5 %)
 constexpr int PH_PITCH = 56; // row pitch: a multiple of 4, so that every staged dword lands with one aligned ds_write_b32
-// Experiment build -DPNR_PH_W7=1 (make variant NAME=w7 DEFS=-DPNR_PH_W7=1): the rows as 7 overlapping 8-byte windows, corner pairs by
-// ds_read_b64 + v_perm_b32 (smc_device.h, interp_group_w7).  Bit-identical and the LDS bank-conflict cycles halve, but the kernel
-// gets SLOWER (dead end (o)): it is bound by VALU issue, and the window arithmetic costs 6 VALU per sample.  Default off.
-#ifndef PNR_PH_W7
-#define PNR_PH_W7 0
-#endif
-constexpr bool PH_W7 = PNR_PH_W7 != 0;
-constexpr int PH_CSX = PH_W7 ? W7_CSX : PH_CS;                                  // extent of the cube in x
-constexpr int PH_PLANE = PH_W7 ? PH_CS * PH_PITCH + 8 : PH_CS * PH_PITCH;       // plane pitch (W7: an odd number of windows)
-constexpr int PH_W7PLANE = PH_W7 ? PH_PLANE : 0;
+constexpr int PH_PLANE = PH_CS * PH_PITCH; // bytes between two planes of the cube
 static_assert((size_t)PH_CS * PH_PLANE <= 160 * 1024, "the cube must fit the LDS of a CU");
 
 struct PhState {
@@ -74,7 +62,7 @@ __device__ __forceinline__ int last_group_stride(int rem) { return rem > 32 ? 64
 
 
 __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, const float *__restrict__ seeds6, Vol V, int np, int ni, int it_arg,
-                                                   int lp, int CS, int CSX)
+                                                   int lp, int CS)
 {
     const int tid = threadIdx.x, B = blockDim.x;
     if (blockIdx.x == 0 && tid == 0) P.cnt[lp ^ 1] = 0; // filled by ph_update of this step
@@ -169,9 +157,8 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
             int hi = sbox[3 + a] > dim[a] - 1 ? dim[a] - 1 : (sbox[3 + a] < lo ? lo : sbox[3 + a]);
             if (lo > dim[a] - 2) lo = dim[a] - 2 < 0 ? 0 : dim[a] - 2;
             if (hi < 1) hi = dim[a] - 1 < 1 ? dim[a] - 1 : 1;
-            const int csa = a == 0 ? CSX : CS; // (the cube is narrower in x: rows of 7-voxel windows)
-            int o = (lo + hi + 1) / 2 - csa / 2;
-            if (o > dim[a] - csa) o = dim[a] - csa;
+            int o = (lo + hi + 1) / 2 - CS / 2;
+            if (o > dim[a] - CS) o = dim[a] - CS;
             if (o < 0) o = 0;
             fl[FL_OX + a] = o;
             if (a > 0) { // rows of the cube that can be sampled at all: only those are staged
@@ -208,7 +195,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
                     // inside the volume: the clamp to [0, dim - 1.001] is the identity; inside the cube: (int)coord - origin <= CS - 2
                     const bool inv = lo >= 0.f && hi <= hi_lim[a]; // (false for NaN poses)
                     fitv = fitv && inv;
-                    fit = fit && inv && floorf(lo) >= (float)sbox[a] && floorf(hi) + 1.f <= (float)(sbox[a] + (a == 0 ? CSX : CS) - 1);
+                    fit = fit && inv && floorf(lo) >= (float)sbox[a] && floorf(hi) + 1.f <= (float)(sbox[a] + CS - 1);
                 }
                 (void)dim;
                 if (!fit) ok &= ~(1u << s);
@@ -277,12 +264,7 @@ __device__ unsigned long long g_ph_stamps[8];
 #endif
 
 template <int CS, bool IS2D>
-#if PNR_PH_W7
-#define PH_SAMPLE_ATTR __attribute__((amdgpu_waves_per_eu(5, 5))) // 96 VGPRs: a ph_sums wave must fit beside four sampling waves on a SIMD
-#else
-#define PH_SAMPLE_ATTR
-#endif
-__global__ __launch_bounds__(PH_THREADS) PH_SAMPLE_ATTR void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it_arg, int lp, int nslots)
+__global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it_arg, int lp, int nslots)
 {
     extern __shared__ unsigned char cube[];
     // part-major: the first nslots work-groups are one per trace, the later ones join whatever is left of their trace
@@ -312,11 +294,11 @@ __global__ __launch_bounds__(PH_THREADS) PH_SAMPLE_ATTR void ph_sample(Vol V, Ta
       // count per load and four byte writes per dword.  The (plane, row) pair now advances incrementally, and the rows are
       // PH_PITCH = 56 bytes apart in LDS so that every dword lands with one aligned ds_write_b32 (the last dword of a row carries
       // two pad bytes).
-        static_assert(PH_PITCH % 4 == 0 && PH_PITCH >= PH_CSX && PH_PITCH <= 64 && (!PH_W7 || PH_PITCH == 8 * W7_NWIN), "one dword per lane, 16 lanes per row");
+        static_assert(PH_PITCH % 4 == 0 && PH_PITCH >= PH_CS && PH_PITCH <= 64, "one dword per lane, 16 lanes per row");
         constexpr int NR = 16;
         typedef unsigned __attribute__((aligned(1))) u32u;
-        // dword d of a row holds the voxels x = 4 d .. 4 d + 3 (W7: half (d & 1) of window d >> 1 = the voxels 7 (d >> 1) + 4 (d & 1) .. + 3)
-        const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6, sub = lane >> 4, l4 = (lane & 15) * 4, sx = PH_W7 ? 7 * ((lane & 15) >> 1) + 4 * (lane & 1) : l4;
+        // dword d of a row holds the voxels x = 4 d .. 4 d + 3
+        const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6, sub = lane >> 4, l4 = (lane & 15) * 4, sx = l4;
         const int y0 = fl[FL_Y0], ny = fl[FL_Y1] - y0, z0 = fl[FL_Z0], nrows = (fl[FL_Z1] - z0) * ny;
         const i64 nvox = V.wh * V.l;
         unsigned *const cube32 = (unsigned *)cube;
@@ -410,18 +392,18 @@ __global__ __launch_bounds__(PH_THREADS) PH_SAMPLE_ATTR void ph_sample(Vol V, Ta
             const float *q = (k >= np) ? xc_pen : cur + k * PSTRIDE; // (the centroid before the first one exists: zeros, discarded)
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
             if (fastmask >> sI & 1)
-                sample_slice<CS, IS2D, true, PH_PITCH, PH_W7PLANE>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
-            else if (!PH_W7 && (volmask >> sI & 1))
-                sample_slice<CS, IS2D, false, PH_PITCH, PH_W7PLANE, true>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+                sample_slice<CS, IS2D, true, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+            else if (volmask >> sI & 1)
+                sample_slice<CS, IS2D, false, PH_PITCH, true>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
             else
-                sample_slice<CS, IS2D, false, PH_PITCH, PH_W7PLANE>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+                sample_slice<CS, IS2D, false, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
         } else {
             const bool act = lane < parts * rem;
             const int pp = act ? lane / rem : 0, j = act ? lane - pp * rem : 0;
             const int k = uidx[ngf * 64 + j];
             const float *q = (k >= np) ? xc_pen : cur + k * PSTRIDE;
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
-            sample_slice_packed<CS, IS2D, false, PH_PITCH, PH_W7PLANE>(V, Bx, f, nv, nu, nw, ax, iv, parts, pp, act, sbase + (i64)ngf * Ms * 64 + j, Rt, r2 * ROWS, r2 * ROWS + ROWS);
+            sample_slice_packed<CS, IS2D, false, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, parts, pp, act, sbase + (i64)ngf * Ms * 64 + j, Rt, r2 * ROWS, r2 * ROWS + ROWS);
         }
     }
 #ifdef PNR_SMC_STAMPS
@@ -989,7 +971,7 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
             }
             const int nsplit = pick_nsplit(active, ncu, max_split, c->opt.split_x10);
             c->tic(st);
-            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, T, X, P, (const float *)h->d_s6, V, np, ni, it, it & 1, CS, PH_CSX);
+            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, T, X, P, (const float *)h->d_s6, V, np, ni, it, it & 1, CS);
             c->toc("smc_predict", 1, st);
             c->tic(st);
             if (V.l == 1)
@@ -1146,7 +1128,7 @@ struct PhasedEngine final : pnr::StreamEngine {
             const int lp = q.lp;
             const int nsplit = pick_nsplit(active, E.ncu, E.max_split, x10);
             c->tic(st, k > 0); // (the first step of a poll follows the admission copies: its own opening event)
-            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS, PH_CSX);
+            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
             c->toc("smc_predict", 1, st);
             c->tic(st, true);
             if (E.V.l == 1)
