@@ -20,6 +20,7 @@
 #include "smc_device.h" // expf_libm: the device expf that equals the host libm value
 #include <cfloat>
 #include <cmath>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -765,11 +766,15 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
     const int o = (ty + 2) * HT_PX + tx + 2;
     float *const qh = DUMP ? nullptr : Q.h + (size_t)region * 6 * HT_REGION;
     unsigned int *const qi = DUMP ? nullptr : Q.idx + (size_t)region * HT_REGION;
-    int s0 = 0; // slot of plane z - 2
     bool zero_here = false;
     const double s2max = s_s2max; // (written before the barrier above)
-#pragma unroll 1
-    for (int z = z0; z < z1; z++) {
+    // One plane of the march.  `s0` = ring slot of plane z - 2.  FAST: no voxel of this plane of the tile is within 2 of a border (the
+    // centred differences everywhere) AND s0 is a compile-time constant: the 19 stencil reads are ds_read_b32 with immediate offsets
+    // from one address register and the slot arithmetic is gone.  Why it matters (PMC, profiles/r04_frangi_pmc_baseline.txt): the
+    // kernel issued 117 scalar instructions per plane and wave against 92 vector ones -- ring-slot selects, 64-bit plane offsets, the
+    // exec-mask bookkeeping of the border rules -- and the scalar unit is shared by the four SIMDs of a CU.
+    auto plane = [&](const int z, const int s0, auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
         float na = 0.f, nc = 0.f;
         const bool more = z + 1 < z1;
         if (more) fetch(z + 3, na, nc); // lands while this plane is computed; stored into the slot nobody reads now
@@ -779,11 +784,10 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
         T.o = o;
         bool surv = false, skipped = false;
         float Dzz = 0, Dyy = 0, Dyz = 0, Dxx = 0, Dxy = 0, Dxz = 0;
-        if (inside) {
+        if (FAST || inside) { // (a tile clear of the borders lies inside the volume)
             // six second derivatives, each x sigma^2 (frangi.cpp:319,339,345,368,374,380)
-            if (interior_xy && z >= 2 && z + 2 < l) {
-                // no voxel of this plane of the tile is within 2 of a border: the centred differences everywhere.  The same
-                // operations as the general path below takes for such a voxel (coordinate 2 of 5 stands for "interior"), but
+            if (FAST || (interior_xy && z >= 2 && z + 2 < l)) {
+                // the same operations as the general path below takes for such a voxel (coordinate 2 of 5 stands for "interior"), but
                 // with the border rules resolved at compile time: 19 LDS reads instead of every variant's
                 Dzz = td2<2, 2>(T, 2, 5, 2, 5) * s2;
                 Dyy = td2<1, 1>(T, 2, 5, 2, 5) * s2;
@@ -813,11 +817,12 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
                 const double nrm = fabs((double)Dxx) + fabs((double)Dyy) + fabs((double)Dzz) + 2.0 * (fabs((double)Dxy) + fabs((double)Dxz) + fabs((double)Dyz));
                 surv = !(tr > 1e-9 * nrm);
                 const double xx = Dxx, yy = Dyy, zz = Dzz, xy = Dxy, xz = Dxz, yz = Dyz;
-                if (surv && s2max > 0.0) { // cannot reach J8 = 1 (see the top of the kernel): skipped, but not a proven zero
-                    const double S2 = (xx * xx + yy * yy + zz * zz) + 2.0 * (xy * xy + xz * xz + yz * yz);
-                    if (S2 < s2max) { surv = false; skipped = true; }
-                }
-                if (surv) {
+                // cannot reach J8 = 1 (see the top of the kernel): skipped, but not a proven zero.  (Evaluated for every lane: nine
+                // f64 operations cost less than the exec-mask bookkeeping of a divergent branch on the shared scalar unit.)
+                const double S2 = (xx * xx + yy * yy + zz * zz) + 2.0 * (xy * xy + xz * xz + yz * yz);
+                skipped = surv && s2max > 0.0 && S2 < s2max;
+                surv = surv && !skipped;
+                if (__builtin_amdgcn_ballot_w64(surv) != 0ull) { // wave-uniform: most waves of a pruned run have no candidate left
                     // Second proof of a zero response: TWO positive eigenvalues.  With all roots real, Descartes' rule on the
                     // characteristic polynomial l^3 - c2 l^2 + c1 l - c0 (c2 = trace <= 0 here) gives exactly two positive roots iff
                     // c1 < 0 and c0 < 0; then (p1 + p2) |n| > -c1 puts the larger positive root above 5e-10 of the norm -- far above
@@ -831,9 +836,9 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
                     // largest-magnitude eigenvalues and the response is 0.
                     const bool two_pos = c1 < -1e-9 * n2 && c0 < -1e-9 * n3;
                     const bool one_pos_big = c0 > 1e-9 * n3 && (tr * c1 - c0) > 1e-9 * n3;
-                    surv = !(two_pos || one_pos_big);
+                    surv = surv && !(two_pos || one_pos_big);
                 }
-                if (!surv && !skipped && z >= zs0 && z < zs1) zero_here = true;
+                zero_here = zero_here || (!surv && !skipped && z >= zs0 && z < zs1);
             }
         }
         if (!DUMP) {
@@ -854,8 +859,24 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
             const int sl = s0 + 5; // plane z + 3 replaces plane z - 3
             put(sl >= HT_RING ? sl - HT_RING : sl, na, nc);
         }
-        s0 = s0 + 1 >= HT_RING ? 0 : s0 + 1;
         __syncthreads();
+    };
+    // the march: runs of HT_RING planes with compile-time ring slots wherever the tile and the planes are clear of every border,
+    // single planes with the general rules otherwise (the first / last two planes of the stack, tiles at an x / y border, the
+    // remainder of a march)
+    int z = z0;
+    int s0 = 0; // slot of plane z - 2 = (z - z0) mod HT_RING
+#pragma unroll 1
+    while (z < z1) {
+        if (interior_xy && s0 == 0 && z >= 2 && z + HT_RING + 2 <= l && z + HT_RING <= z1) {
+#pragma unroll
+            for (int k = 0; k < HT_RING; k++) plane(z + k, k, std::true_type{});
+            z += HT_RING;
+        } else {
+            plane(z, s0, std::false_type{});
+            z++;
+            s0 = s0 + 1 >= HT_RING ? 0 : s0 + 1;
+        }
     }
     if (DUMP) return;
     if (zero_here) s_zero = 1;

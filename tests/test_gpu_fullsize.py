@@ -7,6 +7,13 @@ scripts/parity_production.py, trimmed to what the test box does in well under a 
   * configs[4]: 2048 x 2048 x 512 (2^31 voxels, past the reference's int indexing), scales {2,4,6,8}, zdist 4, np = 500: properties
     that need no oracle -- seeds appear in every quadrant, the streamed schedule gives the one-shot node graph, also for seeds
     whose voxel index lies beyond 2^30 (cube staging, density map and replay in 64-bit arithmetic).
+  * configs[4] AGAINST THE ORACLE, the way SURVEY 8(c) prescribes for a stack the reference's own `int` indexing cannot hold
+    (frangi.cpp:158-163): Frangi / J8 / V of the full-size GPU run against the oracle on two sub-volumes cut with the halo the
+    stencils need (26 voxels in x / y for sigma = 8 + the radius-2 Hessian, 8 planes in z at zdist 4), one of them beyond voxel
+    index 2^30; the seeds of whole layers (MaximumFinder is per layer: a 2048 x 2048 layer is well inside `int`) against the
+    oracle's extractSeeds; the first 40 iterations of the traces of three sorted seeds -- every estimate -- against the oracle's
+    tracker run on the FULL stack (its indices are 64-bit; a cut-out would shift the coordinates and with them the roundings of
+    every sample position), then both node graphs through reconstruct() into SWC files compared by scripts/swc_diff.py.
 """
 import numpy as np
 import pytest
@@ -63,7 +70,7 @@ def test_config0_production_parameters_vs_oracle(oracle, nseeds=5):
     assert np.array_equal(pg, po) and all(np.array_equal(tg[k], to[k], equal_nan=True) for k in to.dtype.names)
 
 
-def test_config4_full_size_properties():
+def _config4_volume():
     import torch
     w, h, l = 2048, 2048, 512
     vol = torch.zeros((l, h, w), dtype=torch.uint8, device="cuda")
@@ -71,6 +78,12 @@ def test_config4_full_size_properties():
     for qi, (z0, y0, x0) in enumerate([(0, 0, 0), (256, 1024, 1024), (0, 1024, 0), (256, 0, 1024)]):
         vol[z0:z0 + 256, y0:y0 + 1024, x0:x0 + 1024] = synth.synth_torch(1024, 1024, 256, seed=5 + qi, zdist=4.0)
     torch.cuda.synchronize()
+    return vol, (w, h, l)
+
+
+def test_config4_full_size_properties():
+    import torch
+    vol, (w, h, l) = _config4_volume()
     p = pnr_amd.make_params(sigmas=(2, 4, 6, 8), np_=500, ni=200, zdist=4)
     c = pnr_amd.Context(p, 0)
     c.set_volume_device(vol.data_ptr(), (l, h, w), keepalive=vol)
@@ -91,5 +104,97 @@ def test_config4_full_size_properties():
             far = (n1["z"][1:].astype(np.float64) * w * h + n1["y"][1:] * w + n1["x"][1:]) > 2 ** 30
             assert far.sum() > 0.9 * len(far)
     c.close()
+    del vol
+    torch.cuda.empty_cache()
+
+
+def test_config4_subvolumes_vs_oracle(oracle, tmp_path):
+    import os
+    import sys
+    import time
+    import torch
+    from pnr_amd import advantra
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import swc_diff
+    L = oracle
+    t_start = time.time()
+    sigs, zdist, np_, ni_cmp = [2.0, 4.0, 6.0, 8.0], 4.0, 500, 40
+    vol, (w, h, l) = _config4_volume()
+    p = pnr_amd.make_params(sigmas=sigs, np_=np_, ni=200, zdist=zdist)
+    c = pnr_amd.Context(p, 0)
+    c.set_volume_device(vol.data_ptr(), (l, h, w), keepalive=vol)
+    jmin, jmax = c.frangi()
+    s0 = c.extract_seeds()
+    s = c.score_filter_sort(s0)
+    g = c.get_frangi(J=True, J8=True, V=True)  # (the exact f32 J of every voxel: one more Frangi pass without the J8 shortcut)
+    img = vol.cpu().numpy()
+    HX, HZ = 26, 8  # ceil(3 * 8) + 2 in x / y; ceil(3 * 8 / zdist) + 2 in z
+    IX, IZ = 96, 24  # interior of a sub-volume
+    # ---- two sub-volumes around strong seeds: one in the first quadrant, one beyond voxel index 2^30 (z >= 256 already is)
+    def pick(mask):
+        for k in np.flatnonzero(mask):
+            x, y, z = int(s["x"][k]), int(s["y"][k]), int(s["z"][k])
+            if IX // 2 + HX <= x < w - IX // 2 - HX and IX // 2 + HX <= y < h - IX // 2 - HX and IZ // 2 + HZ <= z < l - IZ // 2 - HZ:
+                return x, y, z
+        raise AssertionError("no seed far enough from the border")
+    centres = [pick((s["z"] < 200) & (s["x"] < 1000) & (s["y"] < 1000)), pick((s["z"] >= 300) & (s["x"] > 1100) & (s["y"] > 1100))]
+    assert (centres[1][2] * h + centres[1][1]) * w + centres[1][0] > 2 ** 30
+    layers = []
+    for cx, cy, cz in centres:
+        x0, y0, z0 = cx - IX // 2, cy - IX // 2, cz - IZ // 2
+        sub = np.ascontiguousarray(img[z0 - HZ:z0 + IZ + HZ, y0 - HX:y0 + IX + HX, x0 - HX:x0 + IX + HX])
+        Jo, _, _, Vxo, Vyo, Vzo = orc.frangi3d(L, sub, sigs, zdist)
+        J8o = orc.j8(L, Jo, jmin, jmax)  # (the rule with the GLOBAL extremes, Advantra_plugin.cpp:2499-2512)
+        inner = (slice(HZ, HZ + IZ), slice(HX, HX + IX), slice(HX, HX + IX))
+        full = (slice(z0, z0 + IZ), slice(y0, y0 + IX), slice(x0, x0 + IX))
+        Jg = g["J"][full]
+        assert np.allclose(Jg, Jo[inner], rtol=2e-6, atol=0) and (Jg > 0).sum() > 1000, (cx, cy, cz)  # fp64 exp: ocml vs glibc
+        assert np.array_equal(g["J8"][full], J8o[inner]) and (J8o[inner] > 0).sum() > 100, (cx, cy, cz)
+        for k, Vo in (("Vx", Vxo), ("Vy", Vyo), ("Vz", Vzo)):
+            assert np.array_equal(g[k][full], Vo[inner]), (k, cx, cy, cz)
+        layers += [cz - 3, cz + 2]
+    # ---- seeds of whole layers: SeedExtractor::extractSeeds is per layer (seed.cpp:574), so the oracle takes a layer as a one-slice stack
+    for z in layers:
+        so = orc.extract_seeds(L, 5, *[np.ascontiguousarray(g[k][z:z + 1]) for k in ("J8", "Vx", "Vy", "Vz")])
+        sg = s0[s0["z"] == z]
+        assert len(so) == len(sg) > 5, (z, len(so), len(sg))
+        so[:, 2] = z
+        assert np.array_equal(mat(sg)[:, :6], so[:, :6]), z
+    del g
+    # ---- traces: three sorted seeds (one per region + the best of all), 40 iterations, the oracle on the full stack
+    near = lambda cx, cy, cz: np.flatnonzero((abs(s["x"] - cx) < 40) & (abs(s["y"] - cy) < 40) & (abs(s["z"] - cz) < 10))[0]
+    pick3 = sorted({0, int(near(*centres[0])), int(near(*centres[1]))})
+    sel = s[pick3]
+    p2 = pnr_amd.make_params(sigmas=sigs, np_=np_, ni=ni_cmp, zdist=zdist)
+    c2 = pnr_amd.Context(p2, 0)
+    c2.set_volume_device(vol.data_ptr(), (l, h, w), keepalive=vol)
+    Tg, stop, xc, _ = c2.trace_batch(sel)
+    T = orc.Tracker(L, sigs, 2, np_, ni_cmp, 3.0, 0.3, zdist=zdist)
+    corr_o, _ = T.zncc(img, mat(sel)[:, :6])
+    assert np.array_equal(corr_o, sel["corr"])
+    To, xo = [], []
+    for i in range(len(sel)):
+        for d_, sgn in enumerate((1, -1)):
+            q = np.array([sel[k][i] for k in lib.SEED_DT.names[:6]], np.float32)
+            q[3:] *= sgn
+            Tn, st, xco, *_ = T.trace(img, q)
+            j = 2 * i + d_
+            rows = min(Tn + 1, ni_cmp)
+            assert Tg[j] == Tn and stop[j] == st and np.array_equal(mat(xc[j])[:rows], xco[:rows], equal_nan=True), (j, Tg[j], Tn, stop[j], st)
+            To.append(Tn); xo.append(xco)
+    assert sum(To) > 60
+    # ---- both node graphs -> reconstruct() -> SWC -> the numeric SWC diff (BASELINE configs[4]: "SWC diff vs CPU reference")
+    seeds8 = np.stack([sel[k] for k in lib.SEED_DT.names], -1).astype(np.float32)
+    ng, lg, _ = c2.replay(sel, Tg, xc)
+    no, lo, _ = orc.replay(L, seeds8, np.asarray(To, np.int32), np.stack(xo), ni_cmp, (l, h, w), 4, 1)
+    tg, pg = lib.reconstruct(ng, lg, tree_size_min=3)
+    to, po = orc.reconstruct(L, no, lo, tree_size_min=3)
+    a, b = str(tmp_path / "gpu.swc"), str(tmp_path / "oracle.swc")
+    advantra.write_swc_tree(a, tg, pg)
+    advantra.write_swc_tree(b, to, po)
+    ok, msg = swc_diff.diff(a, b, tol=2e-3)
+    assert ok and len(swc_diff.read_swc(a)[0]) > 20, msg
+    assert time.time() - t_start < 200, "this test is meant to stay well inside the GPU test budget"
+    c.close(); c2.close()
     del vol
     torch.cuda.empty_cache()
