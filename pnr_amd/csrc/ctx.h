@@ -115,7 +115,8 @@ struct pnr_ctx {
     int64_t frangi_recomputes = 0;                          // exact re-runs pnr_get_frangi / pnr_quantise_j8 had to make (pnr_get_option "frangi_recomputes")
     int64_t fr_zs0 = 0, fr_zs1 = 0;                         // planes the extremes of the last Frangi run were taken over
     bool have_scale = false, have_v = false; // d_scale + d_F valid / the direction volumes Vx, Vy, Vz are filled
-    float *d_taps = nullptr;          // Gaussian taps of all scales
+    float *d_taps = nullptr;          // Gaussian taps of all scales (frangi.hip: TAPS_SLOT floats per pass, zero-padded)
+    std::vector<float> taps_stage;    // their host staging (asynchronous uploads)
     float *d_qh = nullptr;            // survivor queue of the Hessian stage: [region][6][entries]
     unsigned int *d_qidx = nullptr, *d_qcount = nullptr;
     size_t q_regions = 0;

@@ -33,6 +33,9 @@ typedef long long i64;
 // ----------------------------------------------------------------------------------------
 constexpr int GX_BLOCK = 256;
 constexpr int MAX_L = 64; // ceil(3*sigma) <= 64  (sigma <= 21)
+// the taps of one pass on the device: a +0, the 2L + 1 taps, a +0 (gauss_sums_packed reads the neighbours of a tap pairwise), in a
+// slot of TAPS_SLOT floats; a scale owns two slots (x / y taps, z taps)
+constexpr int TAPS_SLOT = 2 * MAX_L + 4;
 
 __global__ __launch_bounds__(GX_BLOCK) void gauss_x_u8(const uint8_t *__restrict__ img, float *__restrict__ out, int w,
                                                         i64 rows, int tiles_x, const float *__restrict__ taps, int L)
@@ -65,12 +68,98 @@ __device__ __forceinline__ unsigned int xcd_contiguous(unsigned int b, unsigned 
     return x * q + (x < r ? x : r) + idx;
 }
 
+constexpr int GR = 8; // consecutive outputs per thread in the register-tiled Gaussian passes
+typedef float gf32x2 __attribute__((ext_vector_type(2)));
+
+// The GR ascending-tap sums of a register-tiled pass, two outputs per instruction: outputs 2m + 1 and 2m live in the halves (.x,
+// .y) of one 64-bit register pair, input t is broadcast into both halves (op_sel) and meets the tap pair (tap[t - 2m - 1],
+// tap[t - 2m]) -- two neighbours of the tap array, one scalar 64-bit load -- in a v_pk_mul_f32, the products join the sums in a
+// v_pk_add_f32: the two IEEE operations per output and tap of the scalar loop, in its order, each rounded like the scalar one.
+// Where one half has no tap (the first input of an odd output, the last of an even one) the tap array is padded with +0: the sum
+// takes a +0 (0 x a finite input), which leaves it bit for bit what it was.  `taps` points at tap 0 of an array with one zero in
+// front and one behind (upload_taps).
+// Why (round 4, scripts/probes/valu_rate.hip + PMC): the passes with the long radii are VALU-bound -- gauss_axis_t issued 4.29e9
+// wave-instructions in 7.0 ms, exactly four cycles each on the 1024 SIMDs -- and on gfx950 a packed f32 instruction issues in the
+// same four cycles as a plain one (38.7 against 72.6 T lane-operations per second measured).  The instructions are written by hand:
+// left to the compiler the four sums of a thread come out one after the other, every v_pk_add_f32 right behind the v_pk_mul_f32 it
+// depends on with an s_nop in between, and the pass gets slower (2.47 -> 2.99 ms at L = 18; round 3 saw the same and called packed
+// f32 an anti-lever).  Here the multiplies of one input come first, then the adds: no dependent pair is adjacent.
+#define PNR_PK_LO " op_sel:[0,0] op_sel_hi:[0,1]\n"
+#define PNR_PK_HI " op_sel:[1,0] op_sel_hi:[1,1]\n"
+template <int N, bool HI>
+__device__ __forceinline__ void pk_step(gf32x2 *a, const gf32x2 in2, const gf32x2 *t)
+{
+    static_assert(N >= 1 && N <= 4, "");
+    gf32x2 p0, p1, p2, p3;
+    if constexpr (N == 4) {
+        if (HI)
+            asm("v_pk_mul_f32 %0, %8, %9" PNR_PK_HI "v_pk_mul_f32 %1, %8, %10" PNR_PK_HI "v_pk_mul_f32 %2, %8, %11" PNR_PK_HI "v_pk_mul_f32 %3, %8, %12" PNR_PK_HI
+                "v_pk_add_f32 %4, %4, %0\nv_pk_add_f32 %5, %5, %1\nv_pk_add_f32 %6, %6, %2\nv_pk_add_f32 %7, %7, %3"
+                : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
+                : "v"(in2), "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]));
+        else
+            asm("v_pk_mul_f32 %0, %8, %9" PNR_PK_LO "v_pk_mul_f32 %1, %8, %10" PNR_PK_LO "v_pk_mul_f32 %2, %8, %11" PNR_PK_LO "v_pk_mul_f32 %3, %8, %12" PNR_PK_LO
+                "v_pk_add_f32 %4, %4, %0\nv_pk_add_f32 %5, %5, %1\nv_pk_add_f32 %6, %6, %2\nv_pk_add_f32 %7, %7, %3"
+                : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
+                : "v"(in2), "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]));
+    } else if constexpr (N == 3) {
+        if (HI)
+            asm("v_pk_mul_f32 %0, %6, %7" PNR_PK_HI "v_pk_mul_f32 %1, %6, %8" PNR_PK_HI "v_pk_mul_f32 %2, %6, %9" PNR_PK_HI
+                "v_pk_add_f32 %3, %3, %0\nv_pk_add_f32 %4, %4, %1\nv_pk_add_f32 %5, %5, %2"
+                : "=&v"(p0), "=&v"(p1), "=&v"(p2), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "v"(in2), "s"(t[0]), "s"(t[1]), "s"(t[2]));
+        else
+            asm("v_pk_mul_f32 %0, %6, %7" PNR_PK_LO "v_pk_mul_f32 %1, %6, %8" PNR_PK_LO "v_pk_mul_f32 %2, %6, %9" PNR_PK_LO
+                "v_pk_add_f32 %3, %3, %0\nv_pk_add_f32 %4, %4, %1\nv_pk_add_f32 %5, %5, %2"
+                : "=&v"(p0), "=&v"(p1), "=&v"(p2), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "v"(in2), "s"(t[0]), "s"(t[1]), "s"(t[2]));
+    } else if constexpr (N == 2) {
+        if (HI)
+            asm("v_pk_mul_f32 %0, %4, %5" PNR_PK_HI "v_pk_mul_f32 %1, %4, %6" PNR_PK_HI "v_pk_add_f32 %2, %2, %0\nv_pk_add_f32 %3, %3, %1"
+                : "=&v"(p0), "=&v"(p1), "+v"(a[0]), "+v"(a[1]) : "v"(in2), "s"(t[0]), "s"(t[1]));
+        else
+            asm("v_pk_mul_f32 %0, %4, %5" PNR_PK_LO "v_pk_mul_f32 %1, %4, %6" PNR_PK_LO "v_pk_add_f32 %2, %2, %0\nv_pk_add_f32 %3, %3, %1"
+                : "=&v"(p0), "=&v"(p1), "+v"(a[0]), "+v"(a[1]) : "v"(in2), "s"(t[0]), "s"(t[1]));
+    } else { // a lone pair: the add would sit right behind its multiply (one wait state)
+        if (HI) asm("v_pk_mul_f32 %0, %2, %3" PNR_PK_HI "s_nop 0\nv_pk_add_f32 %1, %1, %0" : "=&v"(p0), "+v"(a[0]) : "v"(in2), "s"(t[0]));
+        else asm("v_pk_mul_f32 %0, %2, %3" PNR_PK_LO "s_nop 0\nv_pk_add_f32 %1, %1, %0" : "=&v"(p0), "+v"(a[0]) : "v"(in2), "s"(t[0]));
+    }
+}
+#undef PNR_PK_LO
+#undef PNR_PK_HI
+
+// acc[m] = (output 2m + 1, output 2m); ld2(q) = the inputs (2q, 2q + 1) of this thread's window; taps: see above
+template <int L, class LD2>
+__device__ __forceinline__ void gauss_sums_packed(gf32x2 (&acc)[GR / 2], const float *__restrict__ taps, LD2 &&ld2)
+{
+    static_assert(GR == 8, "four register pairs of sums");
+#pragma unroll
+    for (int q = 0; q < (2 * L + GR) / 2; q++) {
+        const gf32x2 in2 = ld2(q);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int t = 2 * q + half;
+            // pair m takes the taps (k0 - 1, k0) with k0 = t - 2m, for 0 <= k0 <= 2L + 1
+            const int m_hi = t / 2 < GR / 2 - 1 ? t / 2 : GR / 2 - 1;
+            const int m_lo = t - 2 * L - 1 > 0 ? (t - 2 * L - 1 + 1) / 2 : 0;
+            const int n = m_hi - m_lo + 1;
+            gf32x2 tp2[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int k0 = t - 2 * (m_lo + (i < n ? i : 0));
+                __builtin_memcpy(&tp2[i], taps + k0 - 1, 8); // wave-uniform address, static offset: a scalar load
+            }
+            if (n == 4) { if (half) pk_step<4, true>(acc + m_lo, in2, tp2); else pk_step<4, false>(acc + m_lo, in2, tp2); }
+            else if (n == 3) { if (half) pk_step<3, true>(acc + m_lo, in2, tp2); else pk_step<3, false>(acc + m_lo, in2, tp2); }
+            else if (n == 2) { if (half) pk_step<2, true>(acc + m_lo, in2, tp2); else pk_step<2, false>(acc + m_lo, in2, tp2); }
+            else if (n == 1) { if (half) pk_step<1, true>(acc + m_lo, in2, tp2); else pk_step<1, false>(acc + m_lo, in2, tp2); }
+        }
+    }
+}
+
 // The x pass with the radius a compile-time constant (the radii the usual parameters give; gauss_x_u8 otherwise): a work-group
 // converts a tile of 64 rows x (32 + 2L) bytes to f32 in LDS once; lane = row, and every thread computes GR consecutive outputs
 // of its row from 2L + GR LDS reads (row pitch odd: the 64 rows of a wave-read fall into different banks), taps in scalar
 // registers, fully unrolled; the 64 x 32 results go back through LDS so that the stores are whole 128-byte rows.  Same sums as
 // gauss_x_u8: ascending taps, separate multiply and add.
-constexpr int GR = 8; // consecutive outputs per thread in the register-tiled Gaussian passes
 constexpr int GXT_W = 32, GXT_H = 64;
 template <int L>
 __global__ __launch_bounds__(256) void gauss_x_u8_t(const uint8_t *__restrict__ img, float *__restrict__ out, int w, i64 rows, int tiles_x,
@@ -113,26 +202,15 @@ __global__ __launch_bounds__(256) void gauss_x_u8_t(const uint8_t *__restrict__ 
             s_in[r * PITCH + cidx] = (float)img[row * w + x];
         }
     }
-    float tp[2 * L + 1];
-#pragma unroll
-    for (int k = 0; k <= 2 * L; k++) tp[k] = taps[k];
     __syncthreads();
     const int lane = tid & 63, wv = tid >> 6; // row, chunk of GR outputs
-    float acc[GR];
+    gf32x2 acc[GR / 2];
 #pragma unroll
-    for (int j = 0; j < GR; j++) acc[j] = 0.f;
+    for (int m = 0; m < GR / 2; m++) acc[m] = (gf32x2){0.f, 0.f};
     const float *src = s_in + lane * PITCH + wv * GR;
+    gauss_sums_packed<L>(acc, taps, [&](int q) { return (gf32x2){src[2 * q], src[2 * q + 1]}; });
 #pragma unroll
-    for (int t = 0; t < 2 * L + GR; t++) {
-        const float v = src[t];
-#pragma unroll
-        for (int j = 0; j < GR; j++) {
-            const int k = t - j;
-            if (k >= 0 && k <= 2 * L) acc[j] = acc[j] + v * tp[k];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < GR; j++) s_out[lane * (GXT_W + 1) + wv * GR + j] = acc[j];
+    for (int j = 0; j < GR; j++) s_out[lane * (GXT_W + 1) + wv * GR + j] = (j & 1) ? acc[j / 2].x : acc[j / 2].y;
     __syncthreads();
     for (int e = tid; e < GXT_H * GXT_W; e += 256) { // 32 consecutive floats of a row per half wave
         const int r = e / GXT_W, cidx = e - r * GXT_W;
@@ -229,29 +307,18 @@ __global__ __launch_bounds__(64 * GT) void gauss_axis_t(const float *__restrict_
             s_in[r * 64 + lane] = base[(i64)a * axis_stride + x];
         }
     }
-    float tp[2 * L + 1];
-#pragma unroll
-    for (int k = 0; k <= 2 * L; k++) tp[k] = taps[k]; // uniform address, static index: scalar loads
     __syncthreads();
     if (x >= w) return;
-    float acc[GR];
+    gf32x2 acc[GR / 2];
 #pragma unroll
-    for (int j = 0; j < GR; j++) acc[j] = 0.f;
+    for (int m = 0; m < GR / 2; m++) acc[m] = (gf32x2){0.f, 0.f};
     const float *col = s_in + grp * GR * 64 + lane;
-#pragma unroll
-    for (int t = 0; t < 2 * L + GR; t++) { // input row t of this thread's window feeds output j with tap k = t - j
-        const float v = col[t * 64];
-#pragma unroll
-        for (int j = 0; j < GR; j++) {
-            const int k = t - j;
-            if (k >= 0 && k <= 2 * L) acc[j] = acc[j] + v * tp[k];
-        }
-    }
+    gauss_sums_packed<L>(acc, taps, [&](int q) { return (gf32x2){col[2 * q * 64], col[(2 * q + 1) * 64]}; }); // input row t of this thread's window feeds output j with tap k = t - j
     float *dst = out + (i64)o * other_stride;
 #pragma unroll
     for (int j = 0; j < GR; j++) {
         const int a = a0 + grp * GR + j;
-        if (a < n_axis) dst[(i64)a * axis_stride + x] = acc[j];
+        if (a < n_axis) dst[(i64)a * axis_stride + x] = (j & 1) ? acc[j / 2].x : acc[j / 2].y;
     }
 }
 
@@ -301,52 +368,33 @@ __global__ __launch_bounds__(256) void gauss_xy_u8_t(const uint8_t *__restrict__
             s_u8[r * PB + cidx] = plane[(i64)y * w + x];
         }
     }
-    float tp[2 * L + 1];
-#pragma unroll
-    for (int k = 0; k <= 2 * L; k++) tp[k] = taps[k];
     __syncthreads();
     // ---- x pass: task = (row, chunk of GR outputs); consecutive lanes take consecutive rows
     for (int task = tid; task < NR * (64 / GR); task += 256) {
         const int c = task / NR, r = task - c * NR;
         const unsigned char *src = s_u8 + r * PB + mis + c * GR;
-        float acc[GR];
+        gf32x2 acc[GR / 2];
 #pragma unroll
-        for (int j = 0; j < GR; j++) acc[j] = 0.f;
+        for (int m = 0; m < GR / 2; m++) acc[m] = (gf32x2){0.f, 0.f};
+        gauss_sums_packed<L>(acc, taps, [&](int q) { return (gf32x2){(float)src[2 * q], (float)src[2 * q + 1]}; });
 #pragma unroll
-        for (int t = 0; t < 2 * L + GR; t++) {
-            const float v = (float)src[t];
-#pragma unroll
-            for (int j = 0; j < GR; j++) {
-                const int k = t - j;
-                if (k >= 0 && k <= 2 * L) acc[j] = acc[j] + v * tp[k];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < GR; j++) s_x[r * PX + c * GR + j] = acc[j];
+        for (int j = 0; j < GR; j++) s_x[r * PX + c * GR + j] = (j & 1) ? acc[j / 2].x : acc[j / 2].y;
     }
     __syncthreads();
     // ---- y pass: task = (column, group of GR consecutive output rows)
     const int lane = tid & 63;
     const int x = x0 + lane;
     for (int gy = tid >> 6; gy < GXY_TY / GR; gy += 4) {
-        float acc[GR];
+        gf32x2 acc[GR / 2];
 #pragma unroll
-        for (int j = 0; j < GR; j++) acc[j] = 0.f;
+        for (int m = 0; m < GR / 2; m++) acc[m] = (gf32x2){0.f, 0.f};
         const float *col = s_x + gy * GR * PX + lane;
-#pragma unroll
-        for (int t = 0; t < 2 * L + GR; t++) {
-            const float v = col[t * PX];
-#pragma unroll
-            for (int j = 0; j < GR; j++) {
-                const int k = t - j;
-                if (k >= 0 && k <= 2 * L) acc[j] = acc[j] + v * tp[k];
-            }
-        }
+        gauss_sums_packed<L>(acc, taps, [&](int q) { return (gf32x2){col[2 * q * PX], col[(2 * q + 1) * PX]}; });
         if (x < w) {
 #pragma unroll
             for (int j = 0; j < GR; j++) {
                 const int y = y0 + gy * GR + j;
-                if (y < h) out[(z * h + y) * (i64)w + x] = acc[j];
+                if (y < h) out[(z * h + y) * (i64)w + x] = (j & 1) ? acc[j / 2].x : acc[j / 2].y;
             }
         }
     }
@@ -363,7 +411,7 @@ static bool launch_gauss_xy_t(hipStream_t st, const uint8_t *src, float *dst, in
     // against 2.26 + 2.18 (a tie in time, 8.6 GB less HBM traffic), L = 18 8.2 against 2.63 + 2.47 -- the x pass of the 2L halo rows
     // ((64 + 36) / 64 of the arithmetic at L = 18) costs more than the round trip saves.  Fused up to L = 12 only.
     switch (L) {
-        PNR_GXY(6) PNR_GXY(12)
+        PNR_GXY(6) PNR_GXY(12) PNR_GXY(18)
     default: return false;
     }
 #undef PNR_GXY
@@ -660,7 +708,13 @@ __device__ __forceinline__ double vesselness(const double (&d)[3], float two_a2,
 // 32-plane march) instead of once per stencil point.  Each voxel's six second derivatives go through the test that proves the
 // response zero (below); the survivors are appended to the work-group's own region of a queue in HBM (no global atomics) for
 // the eigen-solver kernel, so that kernel runs with full wavefronts whatever the survival rate.
-constexpr int HT_X = 64, HT_Y = 8, HT_Z = 32, HT_PX = HT_X + 4, HT_PY = HT_Y + 4, HT_PLANE = HT_PX * HT_PY, HT_THREADS = HT_X * HT_Y;
+// (HT_VY voxels per thread, rows ty, ty + 8, ... of the tile.  Two per thread -- a 64 x 16 tile, the per-plane scalar work shared by
+// twice the voxels, the x / y halo 1.33 instead of 1.59 x the tile -- was measured in round 4: 93 VGPRs instead of 62, two instead of
+// four work-groups per CU, 16.2 instead of 13.3 ms per stack.  The kernel lives on its occupancy: one voxel per thread.)
+constexpr int HT_X = 64, HT_VY = 1, HT_TY = 8, HT_Y = HT_TY * HT_VY, HT_Z = 32, HT_PX = HT_X + 4, HT_PY = HT_Y + 4, HT_PLANE = HT_PX * HT_PY, HT_THREADS = HT_X * HT_TY;
+constexpr int HT_YBITS = 3, HT_POSBITS = 6 + HT_YBITS; // queue entry: (z - z0) << HT_POSBITS | y in tile << 6 | x in tile
+static_assert(HT_X == 64 && (1 << HT_YBITS) == HT_Y, "the position code of a queue entry");
+constexpr int HT_LD = (HT_PLANE + HT_THREADS - 1) / HT_THREADS; // halo'd plane elements a thread fetches
 constexpr int HT_REGION = HT_X * HT_Y * HT_Z; // queue entries a work-group can produce
 constexpr int HT_RING = 6;
 
@@ -690,7 +744,7 @@ __device__ __forceinline__ float td2(const Tile &T, int ci, int ni, int co, int 
 
 struct HessQueue {
     float *h;            // [region][6][HT_REGION]
-    unsigned int *idx;   // [region][HT_REGION]: (z - z0) << 9 | ty << 6 | tx
+    unsigned int *idx;   // [region][HT_REGION]: (z - z0) << HT_POSBITS | y in tile << 6 | x in tile
     unsigned int *count; // [region]
 };
 
@@ -736,38 +790,50 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
         }
         s_s2max = s2max;
     }
-    // a plane of the ring: HT_PLANE floats, two per thread; out-of-volume halo cells repeat the border (never read: the
+    // a plane of the ring: HT_PLANE floats, HT_LD per thread; out-of-volume halo cells repeat the border (never read: the
     // one-sided border rules of the reference do not look past the border)
-    const int e0 = tid, e1 = tid + HT_THREADS;
-    const int r0 = e0 / HT_PX, c0 = e0 - r0 * HT_PX, r1 = e1 / HT_PX, c1 = e1 - r1 * HT_PX;
     auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
-    const i64 g0 = (i64)clampi(y0 - 2 + r0, h - 1) * w + clampi(x0 - 2 + c0, w - 1);
-    const i64 g1 = (i64)clampi(y0 - 2 + r1, h - 1) * w + clampi(x0 - 2 + c1, w - 1);
-    const bool has1 = e1 < HT_PLANE;
-    auto fetch = [&](int zp, float &a, float &c) {
+    i64 gofs[HT_LD];
+    bool hasv[HT_LD];
+#pragma unroll
+    for (int q = 0; q < HT_LD; q++) {
+        const int e = tid + q * HT_THREADS;
+        hasv[q] = e < HT_PLANE;
+        const int r = (hasv[q] ? e : 0) / HT_PX, cc = (hasv[q] ? e : 0) - r * HT_PX;
+        gofs[q] = (i64)clampi(y0 - 2 + r, h - 1) * w + clampi(x0 - 2 + cc, w - 1);
+    }
+    struct PlaneVals { float v[HT_LD]; };
+    auto fetch = [&](int zp, PlaneVals &pv) {
         const i64 zo = (i64)clampi(zp, l - 1) * wh;
-        a = F[zo + g0];
-        c = has1 ? F[zo + g1] : 0.f;
+#pragma unroll
+        for (int q = 0; q < HT_LD; q++) pv.v[q] = (q + 1 < HT_LD || hasv[q]) ? F[zo + gofs[q]] : 0.f;
     };
-    auto put = [&](int slot, float a, float c) {
-        ring[slot][e0] = a;
-        if (has1) ring[slot][e1] = c;
+    auto put = [&](int slot, const PlaneVals &pv) {
+#pragma unroll
+        for (int q = 0; q < HT_LD; q++)
+            if (q + 1 < HT_LD || hasv[q]) ring[slot][tid + q * HT_THREADS] = pv.v[q];
     };
     // slots: plane zp lives in slot (zp - (z0 - 2)) mod 6
+    // Two planes are in flight per work-group: plane z + 3 was requested during plane z - 1 and is stored behind plane z, plane
+    // z + 4 is requested at the start of plane z.  (With one plane in flight the kernel sat on its memory latency: four work-groups
+    // x 3.3 KB per CU are 3.3 MB in flight on the chip, 1.3 - 1.6 TB/s at 2 - 2.5 us -- what it ran at, with half its VALU slots idle.)
+    PlaneVals pend; // plane z + 3 of the plane z about to be computed
     {
-        float a, c;
+        PlaneVals pv[5];
 #pragma unroll
-        for (int k = 0; k < 5; k++) { fetch(z0 - 2 + k, a, c); put(k, a, c); }
+        for (int k = 0; k < 5; k++) fetch(z0 - 2 + k, pv[k]);
+        if (z0 + 1 < z1) fetch(z0 + 3, pend);
+#pragma unroll
+        for (int k = 0; k < 5; k++) put(k, pv[k]);
     }
     __syncthreads();
-    const int x = x0 + tx, y = y0 + ty;
-    const bool inside = x < w && y < h;
+    const int x = x0 + tx;
     const bool interior_xy = x0 >= 2 && x0 + HT_X + 2 <= w && y0 >= 2 && y0 + HT_Y + 2 <= h; // block-uniform
-    const int o = (ty + 2) * HT_PX + tx + 2;
     float *const qh = DUMP ? nullptr : Q.h + (size_t)region * 6 * HT_REGION;
     unsigned int *const qi = DUMP ? nullptr : Q.idx + (size_t)region * HT_REGION;
     bool zero_here = false;
     const double s2max = s_s2max; // (written before the barrier above)
+    const float s2max_f = (float)(s2max * 0.99999);
     // One plane of the march.  `s0` = ring slot of plane z - 2.  FAST: no voxel of this plane of the tile is within 2 of a border (the
     // centred differences everywhere) AND s0 is a compile-time constant: the 19 stencil reads are ds_read_b32 with immediate offsets
     // from one address register and the slot arithmetic is gone.  Why it matters (PMC, profiles/r04_frangi_pmc_baseline.txt): the
@@ -775,13 +841,17 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
     // exec-mask bookkeeping of the border rules -- and the scalar unit is shared by the four SIMDs of a CU.
     auto plane = [&](const int z, const int s0, auto fast_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
-        float na = 0.f, nc = 0.f;
+        PlaneVals nx;
         const bool more = z + 1 < z1;
-        if (more) fetch(z + 3, na, nc); // lands while this plane is computed; stored into the slot nobody reads now
+        if (z + 2 < z1) fetch(z + 4, nx); // lands while this plane and the next are computed
         Tile T;
 #pragma unroll
         for (int k = 0; k < 5; k++) { const int sl = s0 + k; T.pl[k] = ring[sl >= HT_RING ? sl - HT_RING : sl]; }
-        T.o = o;
+#pragma unroll
+        for (int v = 0; v < HT_VY; v++) {
+        const int yt = ty + v * HT_TY, y = y0 + yt; // row of the tile / of the volume
+        const bool inside = x < w && y < h;
+        T.o = (yt + 2) * HT_PX + tx + 2;
         bool surv = false, skipped = false;
         float Dzz = 0, Dyy = 0, Dyz = 0, Dxx = 0, Dxy = 0, Dxz = 0;
         if (FAST || inside) { // (a tile clear of the borders lies inside the volume)
@@ -813,30 +883,48 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
                 // solver's rounding error (1e-9 of the matrix 1-norm vs ~1e-15) proves the response is exactly 0: at the first
                 // scale J stays the 0 it was cleared to, at later scales the voxel cannot beat J >= 0 -- no eigen-solver either
                 // way.  (NaN compares false: no skip.)
-                const double tr = (double)Dxx + (double)Dyy + (double)Dzz;
-                const double nrm = fabs((double)Dxx) + fabs((double)Dyy) + fabs((double)Dzz) + 2.0 * (fabs((double)Dxy) + fabs((double)Dxz) + fabs((double)Dyz));
-                surv = !(tr > 1e-9 * nrm);
-                const double xx = Dxx, yy = Dyy, zz = Dzz, xy = Dxy, xz = Dxz, yz = Dyz;
-                // cannot reach J8 = 1 (see the top of the kernel): skipped, but not a proven zero.  (Evaluated for every lane: nine
-                // f64 operations cost less than the exec-mask bookkeeping of a divergent branch on the shared scalar unit.)
-                const double S2 = (xx * xx + yy * yy + zz * zz) + 2.0 * (xy * xy + xz * xz + yz * yz);
-                skipped = surv && s2max > 0.0 && S2 < s2max;
-                surv = surv && !skipped;
-                if (__builtin_amdgcn_ballot_w64(surv) != 0ull) { // wave-uniform: most waves of a pruned run have no candidate left
-                    // Second proof of a zero response: TWO positive eigenvalues.  With all roots real, Descartes' rule on the
-                    // characteristic polynomial l^3 - c2 l^2 + c1 l - c0 (c2 = trace <= 0 here) gives exactly two positive roots iff
-                    // c1 < 0 and c0 < 0; then (p1 + p2) |n| > -c1 puts the larger positive root above 5e-10 of the norm -- far above
-                    // the solver's rounding -- and at least one of the two largest-magnitude eigenvalues is that positive one.
-                    const double c1 = (xx * yy - xy * xy) + (xx * zz - xz * xz) + (yy * zz - yz * yz);
-                    const double c0 = xx * (yy * zz - yz * yz) - xy * (xy * zz - yz * xz) + xz * (xy * yz - yy * xz);
-                    const double n2 = nrm * nrm, n3 = n2 * nrm;
-                    // Third: ONE positive eigenvalue p (c0 > 0: n1 <= n2 < 0 < p) that is not the smallest in magnitude.  The
-                    // product of the pairwise sums (n1 + n2)(n1 + p)(n2 + p) = c2 c1 - c0 is positive only if n2 + p > 0 (and
-                    // n1 + p < 0); above the margin that puts p at least 2.5e-10 of the norm beyond |n2|, so p is one of the two
-                    // largest-magnitude eigenvalues and the response is 0.
-                    const bool two_pos = c1 < -1e-9 * n2 && c0 < -1e-9 * n3;
-                    const bool one_pos_big = c0 > 1e-9 * n3 && (tr * c1 - c0) > 1e-9 * n3;
-                    surv = surv && !(two_pos || one_pos_big);
+                // First in f32, conservatively -- most voxels are settled here and the f64 tests below run for the waves that
+                // still hold an unsettled voxel only (in a pruned run, one wave in a few).  (a) The trace: the f32 sum is within
+                // 2 * 2^-24 of the norm of the exact one, so a trace above 1e-5 of the norm proves what the f64 test asks for
+                // (> 1e-9 of the norm).  (b) The J8 bound: six non-negative squares, relative error below 1e-6 in f32, against the
+                // bound lowered by 1e-5.  NaN / inf compare false: such a voxel stays unsettled and takes the f64 path as before.
+                const float nrmf = fabsf(Dxx) + fabsf(Dyy) + fabsf(Dzz) + 2.f * (fabsf(Dxy) + fabsf(Dxz) + fabsf(Dyz));
+                const float trf = (Dxx + Dyy) + Dzz;
+                const float S2f = (Dxx * Dxx + Dyy * Dyy + Dzz * Dzz) + 2.f * (Dxy * Dxy + Dxz * Dxz + Dyz * Dyz);
+                const bool zero_f = nrmf > 1e-30f && trf > 1e-5f * nrmf;
+                skipped = !zero_f && S2f < s2max_f; // (s2max_f = 0 without the shortcut)
+                const bool open = !(zero_f || skipped);
+                if (__builtin_amdgcn_ballot_w64(open) != 0ull) { // wave-uniform
+                    // A response > 0 needs lambda2 <= 0 and lambda3 <= 0 (the two largest-magnitude eigenvalues).  Then
+                    // trace = l1+l2+l3 <= |l2| + l2 + l3 = l3 <= 0.  So a trace that is positive by a margin far above the
+                    // solver's rounding error (1e-9 of the matrix 1-norm vs ~1e-15) proves the response is exactly 0: at the first
+                    // scale J stays the 0 it was cleared to, at later scales the voxel cannot beat J >= 0 -- no eigen-solver either
+                    // way.  (NaN compares false: no skip.)
+                    const double tr = (double)Dxx + (double)Dyy + (double)Dzz;
+                    const double nrm = fabs((double)Dxx) + fabs((double)Dyy) + fabs((double)Dzz) + 2.0 * (fabs((double)Dxy) + fabs((double)Dxz) + fabs((double)Dyz));
+                    surv = open && !(tr > 1e-9 * nrm);
+                    const double xx = Dxx, yy = Dyy, zz = Dzz, xy = Dxy, xz = Dxz, yz = Dyz;
+                    // cannot reach J8 = 1 (see the top of the kernel): skipped, but not a proven zero
+                    const double S2 = (xx * xx + yy * yy + zz * zz) + 2.0 * (xy * xy + xz * xz + yz * yz);
+                    const bool skip_d = surv && s2max > 0.0 && S2 < s2max;
+                    skipped = skipped || skip_d;
+                    surv = surv && !skip_d;
+                    if (__builtin_amdgcn_ballot_w64(surv) != 0ull) {
+                        // Second proof of a zero response: TWO positive eigenvalues.  With all roots real, Descartes' rule on the
+                        // characteristic polynomial l^3 - c2 l^2 + c1 l - c0 (c2 = trace <= 0 here) gives exactly two positive roots iff
+                        // c1 < 0 and c0 < 0; then (p1 + p2) |n| > -c1 puts the larger positive root above 5e-10 of the norm -- far above
+                        // the solver's rounding -- and at least one of the two largest-magnitude eigenvalues is that positive one.
+                        const double c1 = (xx * yy - xy * xy) + (xx * zz - xz * xz) + (yy * zz - yz * yz);
+                        const double c0 = xx * (yy * zz - yz * yz) - xy * (xy * zz - yz * xz) + xz * (xy * yz - yy * xz);
+                        const double n2 = nrm * nrm, n3 = n2 * nrm;
+                        // Third: ONE positive eigenvalue p (c0 > 0: n1 <= n2 < 0 < p) that is not the smallest in magnitude.  The
+                        // product of the pairwise sums (n1 + n2)(n1 + p)(n2 + p) = c2 c1 - c0 is positive only if n2 + p > 0 (and
+                        // n1 + p < 0); above the margin that puts p at least 2.5e-10 of the norm beyond |n2|, so p is one of the two
+                        // largest-magnitude eigenvalues and the response is 0.
+                        const bool two_pos = c1 < -1e-9 * n2 && c0 < -1e-9 * n3;
+                        const bool one_pos_big = c0 > 1e-9 * n3 && (tr * c1 - c0) > 1e-9 * n3;
+                        surv = surv && !(two_pos || one_pos_big);
+                    }
                 }
                 zero_here = zero_here || (!surv && !skipped && z >= zs0 && z < zs1);
             }
@@ -851,14 +939,16 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
                     const unsigned int p = base + (unsigned int)__builtin_popcountll(m & ((1ull << (tid & 63)) - 1ull));
                     qh[0 * HT_REGION + p] = Dxx; qh[1 * HT_REGION + p] = Dxy; qh[2 * HT_REGION + p] = Dxz;
                     qh[3 * HT_REGION + p] = Dyy; qh[4 * HT_REGION + p] = Dyz; qh[5 * HT_REGION + p] = Dzz;
-                    qi[p] = ((unsigned int)(z - z0) << 9) | (unsigned int)tid;
+                    qi[p] = ((unsigned int)(z - z0) << HT_POSBITS) | (unsigned int)(yt << 6) | (unsigned int)tx;
                 }
             }
         }
+        } // v
         if (more) {
-            const int sl = s0 + 5; // plane z + 3 replaces plane z - 3
-            put(sl >= HT_RING ? sl - HT_RING : sl, na, nc);
+            const int sl = s0 + 5; // plane z + 3 replaces plane z - 3, which nobody reads any more
+            put(sl >= HT_RING ? sl - HT_RING : sl, pend);
         }
+        pend = nx;
         __syncthreads();
     };
     // the march: runs of HT_RING planes with compile-time ring slots wherever the tile and the planes are clear of every border,
@@ -917,7 +1007,7 @@ __global__ __launch_bounds__(EQ_BLOCK, 8) void eigen_queue(HessQueue Q, float *_
     unsigned int omin = 0xffffffffu, omax = 0u;
     for (unsigned int e = sub * EQ_BLOCK + threadIdx.x; e < cnt; e += EQ_SUB * EQ_BLOCK) {
         const unsigned int code = qi[e];
-        const int z = zc0 + bz * HT_Z + (int)(code >> 9), y = by * HT_Y + (int)((code >> 6) & 7u), x = bx * HT_X + (int)(code & 63u);
+        const int z = zc0 + bz * HT_Z + (int)(code >> HT_POSBITS), y = by * HT_Y + (int)((code >> 6) & (unsigned)(HT_Y - 1)), x = bx * HT_X + (int)(code & 63u);
         const i64 i = (i64)z * wh + (i64)y * w + x;
         double V[3][3], d[3];
         const float Dxx = qh[0 * HT_REGION + e], Dxy = qh[1 * HT_REGION + e], Dxz = qh[2 * HT_REGION + e];
@@ -1114,7 +1204,10 @@ int pnr_ensure_frangi_buffers(pnr_ctx *c)
 // grow-only scratch: the per-scale Gaussian taps
 static int ensure_taps(pnr_ctx *c)
 {
-    if (!c->d_taps) PNR_HIP(hipMalloc(&c->d_taps, (size_t)PNR_MAX_SIGMAS * (2 * (2 * MAX_L + 1)) * 4));
+    if (!c->d_taps) {
+        PNR_HIP(hipMalloc(&c->d_taps, (size_t)PNR_MAX_SIGMAS * 2 * TAPS_SLOT * 4));
+        c->taps_stage.assign((size_t)PNR_MAX_SIGMAS * 2 * TAPS_SLOT, 0.f);
+    }
     return PNR_OK;
 }
 
@@ -1148,9 +1241,13 @@ static int ensure_queue(pnr_ctx *c, size_t regions)
     return PNR_OK;
 }
 
-static int upload_taps(pnr_ctx *c, const std::vector<float> &g, float *d_dst)
+// `d_slot`: a slot of c->d_taps; the kernels get d_slot + 1 (tap 0).  Staged in the context (the copy is asynchronous)
+static int upload_taps(pnr_ctx *c, const std::vector<float> &g, float *d_slot)
 {
-    PNR_HIP(hipMemcpyAsync(d_dst, g.data(), g.size() * 4, hipMemcpyHostToDevice, c->stream));
+    float *stage = c->taps_stage.data() + (d_slot - c->d_taps);
+    std::fill(stage, stage + TAPS_SLOT, 0.f);
+    std::copy(g.begin(), g.end(), stage + 1);
+    PNR_HIP(hipMemcpyAsync(d_slot, stage, (size_t)TAPS_SLOT * 4, hipMemcpyHostToDevice, c->stream));
     return PNR_OK;
 }
 
@@ -1161,11 +1258,11 @@ static int gaussian3d(pnr_ctx *c, const std::vector<float> &gxy, const std::vect
     const int w = (int)c->w, h = (int)c->h, l = (int)c->l;
     const int Lxy = ((int)gxy.size() - 1) / 2, Lz = ((int)gz.size() - 1) / 2;
     PNR_REQUIRE(Lxy <= MAX_L && Lz <= MAX_L, PNR_E_ARG, "sigma too large: Gaussian radius %d > %d", Lxy, MAX_L);
-    float *d_txy = d_taps, *d_tz = d_taps + 2 * MAX_L + 1;
-    int rc = upload_taps(c, gxy, d_txy);
+    int rc = upload_taps(c, gxy, d_taps);
     if (rc) return rc;
-    rc = upload_taps(c, gz, d_tz);
+    rc = upload_taps(c, gz, d_taps + TAPS_SLOT);
     if (rc) return rc;
+    const float *d_txy = d_taps + 1, *d_tz = d_taps + TAPS_SLOT + 1; // tap 0 of each
     // the three passes alternate buffers so that the last one lands in d_out
     float *bufX = (d_out == c->d_tmpA) ? c->d_tmpA : c->d_tmpB; // x-pass out
     float *bufY = (bufX == c->d_tmpA) ? c->d_tmpB : c->d_tmpA;  // y-pass out
@@ -1344,7 +1441,7 @@ int pnr_frangi_run_range(pnr_ctx *c, int64_t zs0, int64_t zs1, bool finish, floa
             if (rc) return rc;
             Fs = c->d_F[s];
         }
-        rc = gaussian3d(c, c->tab.gxy[s], c->tab.gz[s], c->d_taps + (size_t)s * (2 * (2 * MAX_L + 1)), Fs);
+        rc = gaussian3d(c, c->tab.gxy[s], c->tab.gz[s], c->d_taps + (size_t)s * 2 * TAPS_SLOT, Fs);
         if (rc) return rc;
         if (l == 1) { // P == 1: frangi2d (Advantra_plugin.cpp:2496-2497) with frangi_betaone = .5, frangi_betatwo = 15 (:69-70)
             c->tic();

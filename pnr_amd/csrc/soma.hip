@@ -251,6 +251,11 @@ int pnr_soma_run(pnr_ctx *c, uint8_t *E8_out, int32_t *threshold)
     unsigned long long *d_hist = nullptr;
     int *d_cnt = nullptr;
     i64 *d_off = nullptr, *d_vox = nullptr;
+    { // a +0 in front of the taps and one behind: the register-tiled x pass reads the neighbours of a tap pairwise (gauss_sums_packed)
+        std::vector<float> Gp(G.size() + 2, 0.f);
+        std::copy(G.begin(), G.end(), Gp.begin() + 1);
+        G.swap(Gp);
+    }
     PNR_HIP(hipMalloc(&d_G, G.size() * 4));
     PNR_HIP(hipMalloc(&d_hist, 256 * 8));
     PNR_HIP(hipMalloc(&d_cnt, (size_t)rows * 4));
@@ -264,13 +269,13 @@ int pnr_soma_run(pnr_ctx *c, uint8_t *E8_out, int32_t *threshold)
     c->tic();
     hipLaunchKernelGGL(erode_x, dim3(nb), dim3(SOMA_BLOCK), 0, st, c->d_img, d_K, w, n, Le);
     hipLaunchKernelGGL(erode_y, dim3(nb), dim3(SOMA_BLOCK), 0, st, (const unsigned char *)d_K, d_E, w, h, n, Le);
-    rc = pnr_gauss_x_u8_launch(c, d_E, c->d_tmpA, d_G, Lg); // K[i0] += I[i1] * G[...], taps ascending, clamp-to-edge (frangi.cpp:806-836)
+    rc = pnr_gauss_x_u8_launch(c, d_E, c->d_tmpA, d_G + 1, Lg); // K[i0] += I[i1] * G[...], taps ascending, clamp-to-edge (frangi.cpp:806-836)
     if (rc) { cleanup(); return rc; }
     {
         const int tiles_x = (w + 63) / 64, tiles_y = (h + TYS - 1) / TYS;
         const size_t sm = ((size_t)(TYS + 2 * Lg) * 64 + 2 * Lg + 1) * 4 + 8 * 256 * 4;
         hipLaunchKernelGGL(gauss_y_trunc_hist, dim3((unsigned)((i64)tiles_x * tiles_y * l)), dim3(256), sm, st, (const float *)c->d_tmpA, d_E,
-                           (const float *)d_G, w, h, tiles_x, tiles_y, Lg, d_hist);
+                           (const float *)(d_G + 1), w, h, tiles_x, tiles_y, Lg, d_hist);
     }
     c->toc("soma", 4);
     unsigned long long hist[256];

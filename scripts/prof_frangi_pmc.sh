@@ -19,7 +19,7 @@ import csv, glob, collections, re
 agg = collections.defaultdict(float)
 for f in glob.glob("$OUT/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r'(gauss_\w+?I[Li0-9]+E|gauss_\w+?(?=E)|hessian_tile|eigen_queue|j8_kernel)', r.get('Kernel_Name', ''))
+        m = re.search(r'(gauss_[a-z0-9_]+?_tILi[0-9]+E|gauss_[a-z0-9_]+|hessian_tile|eigen_queue|j8_kernel)', r.get('Kernel_Name', ''))
         if m: agg[(m.group(1), r['Counter_Name'])] += float(r['Counter_Value'])
 with open("$OUT/summary.txt", "w") as o:
     o.write("# bash scripts/prof_frangi_pmc.sh $TAG $SIZE: rocprofv3 --pmc <group> (three groups, separate passes), ONE Frangi pass over one $SIZE^3 stack, scales {2,4,6}; sums over all launches of a kernel\n")
