@@ -244,8 +244,9 @@ def main():
                 exchange = pnr_amd.lib.ShmExchange(f"pnr_bench_{os.getuid()}_{int(ok[1].item())}_{int(ok[2].item())}", rank, world, 1 << 20)
                 exchange_kind = "shared memory (one node)"
         if exchange is None:
-            exchange = multigpu.make_exchange(dist, world, coll_dev)
-            exchange_kind = "RCCL all_gather_into_tensor" if backend == "nccl" else backend
+            # (a rehearsal over gloo that asks for the RCCL exchange gets its shape -- pinned staging, one all_gather_into_tensor -- on host tensors)
+            exchange = multigpu.make_exchange(dist, world, coll_dev, staged=(backend != "nccl" and want == "rccl"))
+            exchange_kind = "RCCL all_gather_into_tensor" if backend == "nccl" else (backend + (" all_gather_into_tensor, pinned staging (the RCCL exchange's shape)" if want == "rccl" else ""))
 
     def step():
         st = {}
@@ -350,16 +351,24 @@ def main():
         # HBM traffic per SMC step: PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, calibrated on a known
         # byte count in the same access pattern: scripts/prof_traffic.sh), collected for THIS workload with one trace group and
         # committed under profiles/ -- read from that file, not measured in this run; null for any other workload
-        traffic, traffic_src, traffic_k = None, None, {}
-        for cand in ("r03_traffic_1024_s2000.json", "r02_traffic_1024_s2000.json"):
-            tpath = os.path.join(ROOT, "profiles", cand if a.driver == "phased" else "r01_traffic_1024_s2000.json")
-            if S == 1024 and a.seeds == 2000 and a.np == 200 and a.ni == 200 and not a.one_shot and world == 1 and os.path.exists(tpath):
+        traffic, traffic_src, traffic_k, traffic_note = None, None, {}, None
+        src_hash = pnr_amd.lib.kernel_source_hash()
+        if S == 1024 and a.seeds == 2000 and a.np == 200 and a.ni == 200 and not a.one_shot and world == 1:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_1024_s2000.json")), reverse=True)
+            stale = []
+            for tpath in cands:
                 tj = json.load(open(tpath))
+                wl = tj.get("workload", {})
+                if wl.get("driver", "phased") != a.driver:
+                    continue
+                if wl.get("kernel_source_hash") != src_hash:  # taken from other kernels than the ones that run here: never quoted
+                    stale.append(os.path.basename(tpath))
+                    continue
                 # the profile was taken with one trace group (no two kernels overlap while the counters run): its launches hold more
                 # traces than this run's when the groups differ -- scale by the SMC iterations per launch (bytes per trace-iteration are
                 # what the kernels' traffic is made of)
-                it_prof = tj.get("workload", {}).get("smc_iterations")
-                st_prof = tj.get("workload", {}).get("smc_steps")
+                it_prof, st_prof = wl.get("smc_iterations"), wl.get("smc_steps")
                 scale = ((st["iters"] * a.steps / steps_smc) / (it_prof / st_prof)) if (it_prof and st_prof) else 1.0
                 for key in (("ph_predict", "ph_sample", "ph_sums", "ph_update") if a.driver == "phased" else ("smc_trace",)):
                     e = tj.get(key, {})
@@ -369,6 +378,9 @@ def main():
                     traffic = sum(traffic_k.values())
                     traffic_src = "profiles/" + os.path.basename(tpath)
                     break
+            if traffic is None:
+                traffic_note = ("no committed PMC profile was taken from these kernel sources (hash %s; found: %s): run scripts/prof_traffic.sh and commit its JSON"
+                                % (src_hash, ", ".join(stale) or "none"))
         if world == 1:
             par = "1 GPU"
         elif shard:
@@ -400,9 +412,11 @@ def main():
                        "trace_groups": groups},
             "roofline": {
                 "kernel": "+".join(KNAME[g] for g in EV if g in KNAME), "dominant_by_device_time": KNAME[dominant],
-                "bound": "hbm", "bound_detail": "priced against the HBM peak as SURVEY 8(d) prescribes; what binds is the LDS gather + VALU of ph_sample and the stash round trip (HBM) + serial f32 chains of ph_sums",
+                "bound": "hbm", "bound_measured": "lds-gather + valu (ph_sample), hbm stash + serial f32 chains (ph_sums)",
+                "bound_detail": "priced against the HBM peak as SURVEY 8(d) prescribes (the contract's bound is the roofline it is priced against); what the kernels wait for is named in bound_measured",
                 "bytes_per_launch": bytes_total / steps_smc, "avg_launch_ms": step_ms, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_per_kernel": traffic_k or None,
+                "frac": achieved / HBM_PEAK_GBS, "frac_time_base": "tracing wall time" if overlapped else "summed device time",
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_per_kernel": traffic_k or None, "traffic_note": traffic_note, "kernel_source_hash": src_hash,
                 "launch": "one SMC step = one launch of each kernel over all active traces of a trace group",
                 "time_base": (f"wall time of the tracing stage / SMC steps ({groups} trace groups on separate streams: launches overlap, host replay and polls included)"
                               if overlapped else "summed device time of the four launches of a step (HIP events on the launching stream)"),
@@ -449,6 +463,7 @@ def main():
                     "sample_frac": 8.0 * Mtot * ev_i / (ki["smc"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "sums_GBs": 2.0 * 4 * Mtot * stash_row_floats(a.np) * it_iso / (ki["smc_sums"][0] * 1e-3) / 1e9,
                     "note": "one trace group, same seeds, after the timed region: the whole evaluation over the summed device time of its four kernels (no overlap)"}
+                out["roofline"]["frac_summed_device_time_one_group"] = out["roofline_isolated"]["frac"]
             if a.seeds > 0:
                 # the same sampling kernel with every CU busy: ONE launch over all traces (outside the timed region)
                 ctx.reset_kernel_ms()

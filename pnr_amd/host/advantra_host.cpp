@@ -288,11 +288,22 @@ bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *>
         return true;
     }
     Stack st;
+    const auto tl0 = std::chrono::steady_clock::now();
     if (!load_stack(infiles[0], raw_dims, st, err)) {
         fprintf(stderr, "%s\n", err.c_str());
         return true;
     }
-    reconstruction_func(st.data.data(), st.w, st.h, st.l, infiles[0], paras, p, device, result);
+    Result local;
+    Result *R = result ? result : &local;
+    const double t_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
+    if (reconstruction_func(st.data.data(), st.w, st.h, st.l, infiles[0], paras, p, device, R) && settings().rank == 0) {
+        // what a user of advantra_func waits for (Advantra_plugin.cpp:2241 load, :2183-2731 reconstruction_func, :2164 the SWC)
+        R->t_load = t_load;
+        R->t_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
+        printf("wall: load %.3f s, context + upload %.3f s, frangi %.3f s, seeds %.3f s, selection %.3f s, tracing %.3f s, reconstruct %.3f s, "
+               "write %.3f s | total %.3f s for %lld voxels\n",
+               R->t_load, R->t_setup, R->t_frangi, R->t_seeds, R->t_select, R->t_trace, R->t_recon, R->t_write, R->t_total, (long long)(st.w * st.h * st.l));
+    }
     return true;
 }
 
@@ -331,6 +342,7 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     p.rng_seed = settings().rng_seed;
     printf("-------------  ADVANTRA  -------------\n");
+    const auto t_begin = clk::now();
     pnr_ctx *ctx = nullptr;
     if (pnr_create(&p, device, &ctx) != PNR_OK) {
         fprintf(stderr, "%s\n", pnr_last_error());
@@ -480,6 +492,7 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
         return true;
     }
     R.t_frangi = secs(t0, t1); R.t_seeds = secs(t1, t2); R.t_select = secs(t2, t3); R.t_trace = secs(t3, t4);
+    R.t_setup = secs(t_begin, t0); // context, upload of the stack, soma path
     printf("\n-----\n%g%% seeds used \n", nseeds ? 100.0 * used / nseeds : 0.0);
     { // reconstruct(n0, ...) :2729 -> :2096-2181 (host): refinement, grouping, trees, final resampling
         int64_t cap = std::max<int64_t>(16, 4 * nn), nt = 0;
@@ -502,6 +515,7 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
     R.swc_path = inimg_file + "_Advantra.swc"; // :2164
     save_treelist(R.tree, R.parent, R.swc_path, -1, 1.f, "Advantra", swc_comment(paras, p));
     if (settings().save_midres) save_nodelist(R.nodes, R.links, inimg_file + "_n0_.swc"); // saveMidres tap (:2099)
+    R.t_write = secs(t5, clk::now());
     printf("%s\n%lld trace nodes, %lld traces, %lld SMC iterations, %zu tree nodes | frangi %.3f s, seeds %.3f s, selection %.3f s, "
            "tracing %.3f s, reconstruct %.3f s\n",
            R.swc_path.c_str(), (long long)nn - 1, (long long)used, (long long)iters, R.tree.size() - 1, R.t_frangi, R.t_seeds, R.t_select,

@@ -27,6 +27,7 @@ struct Result {
     std::vector<int32_t> parent;   // parent index per tree node, -1 = root
     std::string swc_path;
     double t_frangi = 0, t_seeds = 0, t_select = 0, t_trace = 0, t_recon = 0;
+    double t_load = 0, t_setup = 0, t_write = 0, t_total = 0; // stack file -> memory; context + upload (+ soma); SWC file; advantra_func as a whole
 };
 
 // switches of the head-less driver (advantra_cli flags; the plugin's compile-time TRACING_VERBOSE / saveMidres taps)

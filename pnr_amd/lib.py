@@ -514,3 +514,16 @@ def reconstruct(nodes, links, trace_rsmpl=0.0, sig2radius=0.0, refine_iter=0, ep
         if n.value <= cap:
             return out[:n.value].copy(), par[:n.value].copy()
         cap = int(n.value)
+
+
+def kernel_source_hash(names=("smc_phased.hip", "smc_device.h", "smc.hip", "stream_sched.h", "frangi.hip", "seeds.hip")):
+    """sha256 (first 16 hex digits) over the kernel sources the library was built from: the committed PMC traffic profiles carry it,
+    and bench.py only quotes a profile whose hash equals the hash of the sources it runs (a changed kernel is never priced with the
+    bytes of an older one)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for n in names:
+        with open(os.path.join(d, n), "rb") as f:
+            h.update(n.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]

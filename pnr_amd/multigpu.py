@@ -35,10 +35,12 @@ def _all_gather(dist, t, world):
     return out
 
 
-def make_exchange(dist, world, device=None):
+def make_exchange(dist, world, device=None, staged=False):
     """pnr_allgather_fn over torch.distributed: `bytes` bytes per rank -> world x bytes in rank order.  With a CUDA `device` (backend
-    nccl = RCCL) the block goes through pinned staging buffers and the GPU; otherwise (gloo) it stays in host memory.  Keep the
-    returned object alive while the C call runs."""
+    nccl = RCCL) the block goes through pinned staging buffers and the GPU into ONE all_gather_into_tensor; otherwise (gloo) it stays
+    in host memory.  `staged` gives the host form the shape of the RCCL one -- pinned staging buffers and a single
+    all_gather_into_tensor -- so that a rehearsal of N ranks on fewer GPUs (gloo cannot gather device tensors) walks the same code.
+    Keep the returned object alive while the C call runs."""
     cuda = device is not None and torch.device(device).type == "cuda"
     st = {"nb": -1}
 
@@ -49,8 +51,9 @@ def make_exchange(dist, world, device=None):
                 st["nb"] = nb
                 st["inp"] = torch.empty(nb, dtype=torch.uint8)
                 st["out"] = torch.empty(world * nb, dtype=torch.uint8)
-                if cuda:
+                if cuda or (staged and torch.cuda.is_available()):
                     st["inp"], st["out"] = st["inp"].pin_memory(), st["out"].pin_memory()
+                if cuda:
                     st["ginp"] = torch.empty(nb, dtype=torch.uint8, device=device)
                     st["gout"] = torch.empty(world * nb, dtype=torch.uint8, device=device)
             C.memmove(st["inp"].data_ptr(), send, nb)
@@ -58,6 +61,8 @@ def make_exchange(dist, world, device=None):
                 st["ginp"].copy_(st["inp"], non_blocking=True)
                 dist.all_gather_into_tensor(st["gout"], st["ginp"])
                 st["out"].copy_(st["gout"])  # blocking: the block is on the host when this returns
+            elif staged:
+                dist.all_gather_into_tensor(st["out"], st["inp"])
             else:
                 dist.all_gather(list(st["out"].view(world, nb).unbind(0)), st["inp"])
             C.memmove(recv, st["out"].data_ptr(), world * nb)

@@ -1,6 +1,10 @@
 #!/bin/bash
 # HBM traffic of the SMC and Frangi kernels from PMC counters (separate passes: FETCH_SIZE takes 3 TCC slots,
 # WRITE_SIZE 2), calibrated on a known byte count in the same access pattern (MI355X_MICROARCH.md, HBM).
+#   PNR_BENCH_OPTS=groups=1 bash scripts/prof_traffic.sh [bench.py arguments]   -> gpurun_out/traffic/traffic.json
+# (one trace group: no two kernels overlap while the counters run).  The JSON carries the workload it was taken on and the hash of the
+# kernel sources (pnr_amd.lib.kernel_source_hash): copy it to profiles/rNN_traffic_1024_s2000.json -- bench.py quotes it only while
+# the sources it runs have that hash.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
@@ -38,5 +42,18 @@ for ctr, f in (('FETCH_SIZE', f_rd), ('WRITE_SIZE', f_wr)):
         b = v * 1024 * (f or 1.0)
         print('%-42s %-11s launches %4d  bytes(calibrated) %.4g  per launch %.4g' % (k, c, n, b, b / n))
         out.setdefault(k.strip(), {})[c] = {'launches': n, 'bytes': b, 'bytes_per_launch': b / n}
+import os, sys
+sys.path.insert(0, "$ROOT")
+from pnr_amd import lib as pl
+bj = None
+for ln in open("$OUT/bench_FETCH_SIZE.json"):
+    if ln.startswith("{"):
+        bj = json.loads(ln)
+out["workload"] = {"command": "PNR_BENCH_OPTS=%s python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra " % os.environ.get("PNR_BENCH_OPTS", "") + "$*",
+                   "kernel_source_hash": pl.kernel_source_hash(), "driver": "phased",
+                   "config": (bj or {}).get("config"), "smc_iterations": (bj or {}).get("counts", {}).get("iters"),
+                   "smc_steps": (bj or {}).get("smc_launches_per_step"), "nodes": (bj or {}).get("counts", {}).get("nodes"),
+                   "note": "counters collected under rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate passes), one bench step each"}
 json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
+print(json.dumps(out["workload"]))
 PY

@@ -247,6 +247,19 @@ def test_bench_gpus_2_starts_two_ranks_and_matches_one_gpu():
     assert one["roofline"]["kernel"] == "ph_predict+ph_sample<54, false>+ph_sums+ph_update" and one["roofline"]["dominant_by_device_time"] in one["roofline"]["kernel"]
 
 
+def test_bench_gpus_2_with_the_rccl_shaped_exchange():
+    """the per-poll exchange of trace records in the form it takes across nodes -- pinned staging buffers and ONE all_gather_into_tensor
+    per exchange (pnr_amd/multigpu.py make_exchange) -- with a world of TWO: rehearsed on one GPU over gloo (which cannot gather device
+    tensors: the device hop of the RCCL form is covered with a world of one below), against the shared-memory default"""
+    common = ["--size", "160", "--seeds", "150", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra", "--gpus", "2"]
+    shm = _bench(common, {"PNR_BENCH_BACKEND": "gloo"})
+    rc = _bench(common, {"PNR_BENCH_BACKEND": "gloo", "PNR_BENCH_EXCHANGE": "rccl"})
+    assert "shared memory" in shm["config"]["record_exchange"] and "all_gather_into_tensor" in rc["config"]["record_exchange"]
+    for k in ("nodes", "n_seeds", "n_seeds_init", "traces_used"):
+        assert rc["counts"][k] == shm["counts"][k], k
+    assert rc["counts"]["nodes"] > 50 and rc["n_gpus"] == 2
+
+
 def test_exchange_callback_over_rccl_one_rank():
     """the RCCL form of the exchange callback (pinned staging -> device -> all_gather_into_tensor -> host) with a world of one, the
     only RCCL world a one-GPU box can form: the block comes back unchanged, twice, also after the block size changes"""

@@ -73,6 +73,10 @@ def _worker(rank, world, port, q):
     # block of 1 KiB: a record of 20 rows is 656 B, so finished traces queue up and are carried over several polls
     nodes, links, nt, iters = lib.sched_playback(p, img.shape, seeds, lookup, rank, world, ex, block_bytes=1024, window=6, poll=2)
     ok = _same_graph(nodes, links, W)
+    # the same through the exchange in the shape it has over RCCL: staging buffers and ONE all_gather_into_tensor per exchange
+    ex2 = multigpu.make_exchange(dist, world, torch.device("cpu"), staged=True)
+    nodes2, links2, _, _ = lib.sched_playback(p, img.shape, seeds, lookup, rank, world, ex2, block_bytes=2048, window=6, poll=2)
+    ok = ok and _same_graph(nodes2, links2, W)
     it = torch.tensor([iters], dtype=torch.int64)
     dist.all_reduce(it)
     graphs = multigpu.gather_graphs(nodes, links, dist, rank, world, torch.device("cpu"))
