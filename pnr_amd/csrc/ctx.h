@@ -61,7 +61,7 @@ struct Options {
     int look0 = 0, look_pct = -1; // admission lookahead max(look0, frontier * look_pct / 100); 0 / -1 = automatic (stream_sched.h)
     int target = -1;          // running traces the admission keeps up (0: off, -1: automatic -- 200 on one GPU with the tentative replay)
     int sums_deep = -1;       // form of the ordered sums: -1 automatic (smc_phased.hip sums_deep()), 0 two buffers folded, 1 four buffers in turn
-    int sums_deep_max = 64;   // ... automatic with several trace groups: the four-buffer form for launches of at most this many traces
+    int sums_deep_max = 96;   // ... automatic with several trace groups: the four-buffer form for launches of at most this many traces (round 4: 64 -> 96, -1 % on both bench workloads)
     int lag = -1;             // steps of a poll that run while the host works on the state in front of them (-1 automatic: stream_sched.h)
     int concentrate = 1;      // several trace groups: new seeds go to group 0 only while few traces survive a poll (experiment switch)
     int overfill = 1;         // the target is the mean over a poll, not the count at its start (experiment switch)
@@ -69,7 +69,7 @@ struct Options {
     int groups = 0;           // trace groups on separate streams (0: automatic -- 2 on one GPU: one group's ordered sums overlap the other's sampling;
                               // 1 sharded: every poll is then an exchange, and small launches gain nothing from sharing the CUs)
     int split_x10 = 0;        // sampling work-groups per CU x 10 and launch; 0 = automatic (40 with one trace group, 22 with several)
-    int max_split = 24;       // ... and at most this many per trace
+    int max_split = 96;       // ... and at most this many per trace (round 4: 24 -> 96: the last few traces of a late poll are spread over the whole chip)
     int64_t stash_mb = 65536; // sample-stash budget
     int host_threads = 0;     // host worker threads of the seed flood fill / reconstruct(); 0 = hardware threads / local_ranks
     int local_ranks = 1;      // processes that share this host (one per GPU)

@@ -209,7 +209,9 @@ __device__ __forceinline__ int cdf_search(const float *__restrict__ cws, int n, 
 // carry the non-temporal hint (global_store_dword ... nt), so that they do not push the cube rows, the template tables and the other
 // trace group's lines out of L2.  Measured on the bench step: tracing 1033 -> 978 ms; the same hint on the loads changes nothing
 // (EXPERIMENTS.md, round 3).
+#ifndef STASH_ST // (an experiment build may have chosen its own: scripts/probes/experiments/ph_sample_hooks.h)
 #define STASH_ST(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#endif
 #define STASH_LD(ptr) (*(ptr))
 typedef __attribute__((address_space(3))) const unsigned char lds_cu8; // LDS-qualified: ds_read_u8, never flat_load
 struct Box {

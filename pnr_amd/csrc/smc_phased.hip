@@ -16,6 +16,11 @@
 #include "ctx.h"
 #include "replay.h"
 #include "stream_sched.h"
+#ifdef PNR_EXPERIMENT_HOOKS // variant libraries only (make variant): scripts/probes/experiments/ph_sample_hooks.h
+#include "../../scripts/probes/experiments/ph_sample_hooks.h"
+#else
+#define PNR_HOOK_AFTER_FULL_ITEM(seg_lane, cnt)
+#endif
 #include "smc_device.h"
 #include <algorithm>
 #include <cstdlib>
@@ -397,6 +402,7 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
                 sample_slice<CS, IS2D, false, PH_PITCH, true>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
             else
                 sample_slice<CS, IS2D, false, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+            PNR_HOOK_AFTER_FULL_ITEM(sbase + (i64)g * Ms * 64 + lane + ((i64)iv * nu + ch * ROWS) * nw * 64, (min(ch * ROWS + ROWS, nu) - ch * ROWS) * nw);
         } else {
             const bool act = lane < parts * rem;
             const int pp = act ? lane / rem : 0, j = act ? lane - pp * rem : 0;
