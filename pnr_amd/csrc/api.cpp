@@ -348,6 +348,7 @@ int pnr_gaussian(pnr_ctx *c, float sig, float *F)
     PNR_REQUIRE(c && c->d_img && F, PNR_E_STATE, "pnr_gaussian: no volume set");
     PNR_REQUIRE(sig > 0, PNR_E_ARG, "sigma must be positive");
     int rc = pnr_ensure_frangi_buffers(c);
+    if (!rc) rc = pnr_ensure_tmpA(c);
     if (rc) return rc;
     rc = pnr_gaussian_run(c, sig, c->d_tmpA);
     if (rc) return rc;
@@ -383,6 +384,7 @@ int pnr_set_j8_v(pnr_ctx *c, const uint8_t *J8, const uint8_t *Vx, const uint8_t
     PNR_REQUIRE(c && c->N > 0, PNR_E_STATE, "pnr_set_j8_v: set a volume first (for the dimensions)");
     PNR_REQUIRE(J8 && Vx && Vy && Vz, PNR_E_ARG, "null argument");
     int rc = pnr_ensure_frangi_buffers(c);
+    if (!rc) rc = pnr_ensure_v(c);
     if (rc) return rc;
     const size_t n = (size_t)c->N;
     PNR_HIP(hipMemcpyAsync(c->d_J8, J8, n, hipMemcpyHostToDevice, c->stream));

@@ -274,6 +274,8 @@ int pnr_hessian_run(pnr_ctx *c, float sig, float *const d_out[6]);
 int pnr_seeds_run(pnr_ctx *c, int64_t z0, int64_t z1);
 int pnr_soma_run(pnr_ctx *c, uint8_t *E8_out, int32_t *threshold);
 int pnr_gauss_x_u8_launch(pnr_ctx *c, const uint8_t *src, float *dst, const float *d_taps, int L);
+int pnr_ensure_tmpA(pnr_ctx *c); // the second Gaussian scratch volume / the direction volumes: allocated where they are used (frangi.hip)
+int pnr_ensure_v(pnr_ctx *c);
 int pnr_zncc_run(pnr_ctx *c, const float *h_pos_dir, int64_t n, float *h_corr, float *h_sig);
 int pnr_trace_run(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *T, int32_t *stop, pnr_xest *xc,
                   int dbg_iters, float *xfilt, int32_t *idxres, float *neff, int use_density);

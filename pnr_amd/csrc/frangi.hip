@@ -1188,16 +1188,33 @@ int pnr_ensure_frangi_buffers(pnr_ctx *c)
     for (int s = 0; s < PNR_MAX_SIGMAS; s++) { hipFree(c->d_F[s]); c->d_F[s] = nullptr; }
     c->frangi_cap = 0;
     c->have_v = c->have_scale = false;
+    // tmpA and the three direction volumes (7.5 GB at 1024^3) are only allocated where they are used -- pnr_ensure_tmpA / pnr_ensure_v:
+    // the default pipeline never touches them, and a first hipMalloc of tens of GB costs a one-shot process about 25 ms per GB
+    // (scripts/probes/malloc_probe.py)
     const size_t n = (size_t)c->N;
-    PNR_HIP(hipMalloc(&c->d_tmpA, n * 4));
     PNR_HIP(hipMalloc(&c->d_tmpB, n * 4));
     PNR_HIP(hipMalloc(&c->d_J, n * 4));
-    PNR_HIP(hipMalloc(&c->d_Vx, n));
-    PNR_HIP(hipMalloc(&c->d_Vy, n));
-    PNR_HIP(hipMalloc(&c->d_Vz, n));
     PNR_HIP(hipMalloc(&c->d_J8, n));
     PNR_HIP(hipMalloc(&c->d_scale, n));
     c->frangi_cap = c->N;
+    return PNR_OK;
+}
+
+int pnr_ensure_tmpA(pnr_ctx *c)
+{
+    if (c->d_tmpA) return PNR_OK;
+    PNR_REQUIRE(c->frangi_cap >= c->N, PNR_E_STATE, "the Frangi buffers are not allocated");
+    PNR_HIP(hipMalloc(&c->d_tmpA, (size_t)c->frangi_cap * 4));
+    return PNR_OK;
+}
+
+int pnr_ensure_v(pnr_ctx *c)
+{
+    if (c->d_Vx && c->d_Vy && c->d_Vz) return PNR_OK;
+    PNR_REQUIRE(c->frangi_cap >= c->N, PNR_E_STATE, "the Frangi buffers are not allocated");
+    if (!c->d_Vx) PNR_HIP(hipMalloc(&c->d_Vx, (size_t)c->frangi_cap));
+    if (!c->d_Vy) PNR_HIP(hipMalloc(&c->d_Vy, (size_t)c->frangi_cap));
+    if (!c->d_Vz) PNR_HIP(hipMalloc(&c->d_Vz, (size_t)c->frangi_cap));
     return PNR_OK;
 }
 
@@ -1263,13 +1280,15 @@ static int gaussian3d(pnr_ctx *c, const std::vector<float> &gxy, const std::vect
     rc = upload_taps(c, gz, d_taps + TAPS_SLOT);
     if (rc) return rc;
     const float *d_txy = d_taps + 1, *d_tz = d_taps + TAPS_SLOT + 1; // tap 0 of each
-    // the three passes alternate buffers so that the last one lands in d_out
-    float *bufX = (d_out == c->d_tmpA) ? c->d_tmpA : c->d_tmpB; // x-pass out
-    float *bufY = (bufX == c->d_tmpA) ? c->d_tmpB : c->d_tmpA;  // y-pass out
+    // The passes alternate buffers so that the last one lands in d_out: the (fused x-) y pass writes a scratch volume Y != d_out, the
+    // z pass reads it into d_out; pass by pass, the x result may sit in d_out itself (it is consumed before d_out is written).  A
+    // single-slice stack has no z pass: y writes d_out, x a scratch volume.  The scratch is tmpB (tmpA only when d_out is tmpB).
+    const bool two_d = (l == 1); // the 2-D imgaussian (frangi.cpp:576-645)
+    if (d_out == c->d_tmpB) { rc = pnr_ensure_tmpA(c); if (rc) return rc; }
+    float *const scratch = d_out == c->d_tmpB ? c->d_tmpA : c->d_tmpB;
+    float *bufY = two_d ? d_out : scratch;
+    float *bufX = two_d ? scratch : d_out;
     float *bufZ = d_out;
-    if (bufZ == bufY) { float *t = bufX; bufX = bufY; bufY = t; }
-    const bool two_d = (l == 1); // single-slice stack: the 2-D imgaussian has no z pass (frangi.cpp:576-645)
-    if (two_d) { bufY = d_out; bufX = (d_out == c->d_tmpA) ? c->d_tmpB : c->d_tmpA; }
     c->tic();
     int nlaunch = two_d ? 1 : 2;
     if (!launch_gauss_xy_t(c->stream, c->d_img, bufY, w, h, l, d_txy, Lxy)) { // x and y in one kernel for the usual radii; else pass by pass
@@ -1332,7 +1351,8 @@ static void tile_grid(const pnr_ctx *c, int zc0, int zc1, int &tiles_x, int &til
 
 int pnr_hessian_run(pnr_ctx *c, float sig, float *const d_out[6])
 {
-    int rc = pnr_gaussian_run(c, sig, c->d_tmpA);
+    int rc = pnr_ensure_tmpA(c);
+    if (!rc) rc = pnr_gaussian_run(c, sig, c->d_tmpA);
     if (rc) return rc;
     const int w = (int)c->w, h = (int)c->h, l = (int)c->l;
     HessOut dump{d_out[0], d_out[1], d_out[2], d_out[3], d_out[4], d_out[5]};
@@ -1352,6 +1372,7 @@ int pnr_frangi_materialise_v(pnr_ctx *c)
 {
     if (c->have_v) return PNR_OK;
     PNR_REQUIRE(c->have_scale, PNR_E_STATE, "no Frangi response: the direction volumes cannot be produced");
+    { const int rcv = pnr_ensure_v(c); if (rcv) return rcv; }
     ScaleVols SV{};
     for (int s = 0; s < c->prm.nsig; s++) { SV.F[s] = c->d_F[s]; SV.s2[s] = c->prm.sig[s] * c->prm.sig[s]; }
     hipLaunchKernelGGL(vdir_points, dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream, SV, (const unsigned char *)c->d_scale, (const i64 *)nullptr,
@@ -1435,7 +1456,13 @@ int pnr_frangi_run_range(pnr_ctx *c, int64_t zs0, int64_t zs1, bool finish, floa
         PNR_HIP(hipMemsetAsync(c->d_scale, 0, (size_t)c->N, c->stream));
     }
     for (int s = 0; s < P.nsig; s++) {
-        float *Fs = c->d_tmpA;
+        float *Fs = nullptr;
+        if (l == 1) { // (a single slice: the smoothed image of the scale in tmpA, the direction bytes written by the pixel kernel)
+            rc = pnr_ensure_tmpA(c);
+            if (!rc) rc = pnr_ensure_v(c);
+            if (rc) return rc;
+            Fs = c->d_tmpA;
+        }
         if (l > 1) {
             rc = ensure_scale_volume(c, s);
             if (rc) return rc;

@@ -238,6 +238,8 @@ int pnr_soma_run(pnr_ctx *c, uint8_t *E8_out, int32_t *threshold)
     if (c->prm.somaradius <= 0) { c->have_soma = true; return PNR_OK; } // "no soma detection": empty map (:2482-2486)
     PNR_REQUIRE(c->d_img, PNR_E_STATE, "no volume set (pnr_set_volume)");
     int rc = pnr_ensure_frangi_buffers(c); // scratch: the Frangi buffers are free until pnr_frangi runs
+    if (!rc) rc = pnr_ensure_tmpA(c);
+    if (!rc) rc = pnr_ensure_v(c);
     if (rc) return rc;
     const int w = (int)c->w, h = (int)c->h, l = (int)c->l;
     const i64 n = c->N, rows = (i64)h * l;
