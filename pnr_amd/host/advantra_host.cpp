@@ -4,6 +4,10 @@
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -144,13 +148,30 @@ bool load_stack(const std::string &path, const std::string &raw_dims, Stack &out
         err = "raw stacks need -d w,h,l";
         return false;
     }
-    std::ifstream f(path, std::ios::binary);
-    if (!f) { err = "cannot open " + path; return false; }
-    out.data.resize((size_t)(w * h * l));
-    f.read((char *)out.data.data(), (std::streamsize)out.data.size());
-    if ((long long)f.gcount() != w * h * l) { err = "raw file shorter than w*h*l"; return false; }
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) { err = "cannot open " + path; return false; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (long long)sb.st_size < w * h * l) { close(fd); err = "raw file shorter than w*h*l"; return false; }
+    void *m = mmap(nullptr, (size_t)(w * h * l), PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { // (a file system that cannot map: read it)
+        std::ifstream f(path, std::ios::binary);
+        if (!f) { err = "cannot open " + path; return false; }
+        out.data.resize((size_t)(w * h * l));
+        f.read((char *)out.data.data(), (std::streamsize)out.data.size());
+        if ((long long)f.gcount() != w * h * l) { err = "raw file shorter than w*h*l"; return false; }
+    } else {
+        out.view = (const unsigned char *)m;
+        out.map_len = (size_t)(w * h * l);
+        (void)madvise(m, out.map_len, MADV_SEQUENTIAL);
+    }
     out.w = w; out.h = h; out.l = l;
     return true;
+}
+
+Stack::~Stack()
+{
+    if (view) munmap((void *)view, map_len);
 }
 
 bool save_nodelist(const std::vector<pnr_node> &nodes, const std::vector<int32_t> &links, const std::string &swcname, int type,
@@ -296,7 +317,7 @@ bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *>
     Result local;
     Result *R = result ? result : &local;
     const double t_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
-    if (reconstruction_func(st.data.data(), st.w, st.h, st.l, infiles[0], paras, p, device, R) && settings().rank == 0) {
+    if (reconstruction_func(st.bytes(), st.w, st.h, st.l, infiles[0], paras, p, device, R) && settings().rank == 0) {
         // what a user of advantra_func waits for (Advantra_plugin.cpp:2241 load, :2183-2731 reconstruction_func, :2164 the SWC)
         R->t_load = t_load;
         R->t_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();

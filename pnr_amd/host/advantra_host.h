@@ -14,8 +14,16 @@
 namespace advantra {
 
 struct Stack {
-    std::vector<unsigned char> data; // x fastest: i = z*w*h + y*w + x
+    std::vector<unsigned char> data; // x fastest: i = z*w*h + y*w + x (TIFF: the pages copied out of the file)
     long long w = 0, h = 0, l = 0;
+    // a raw stack is mapped, not copied: 1 GiB through a zero-filled vector cost a quarter of a second that the upload pays anyway
+    const unsigned char *view = nullptr;
+    size_t map_len = 0;
+    const unsigned char *bytes() const { return view ? view : data.data(); }
+    Stack() = default;
+    Stack(const Stack &) = delete;
+    Stack &operator=(const Stack &) = delete;
+    ~Stack();
 };
 
 struct Result {
