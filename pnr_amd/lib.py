@@ -516,8 +516,9 @@ def reconstruct(nodes, links, trace_rsmpl=0.0, sig2radius=0.0, refine_iter=0, ep
         cap = int(n.value)
 
 
-def kernel_source_hash(names=("smc_phased.hip", "smc_device.h", "smc.hip", "stream_sched.h", "frangi.hip", "seeds.hip")):
-    """sha256 (first 16 hex digits) over the kernel sources the library was built from: the committed PMC traffic profiles carry it,
+def kernel_source_hash(names=("smc_phased.hip", "smc_device.h", "smc.hip", "stream_sched.h")):
+    """sha256 (first 16 hex digits) over the sources of the SMC kernels and their scheduler (what the traffic of the particle evaluation
+    depends on): the committed PMC traffic profiles carry it,
     and bench.py only quotes a profile whose hash equals the hash of the sources it runs (a changed kernel is never priced with the
     bytes of an older one)"""
     import hashlib
