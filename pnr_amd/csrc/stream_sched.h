@@ -324,6 +324,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     auto out_record_words = [&](size_t at) { return 4 + (size_t)outbox[at + 3] * 8; };
 
     long long dbg_end[4] = {0, 0, 0, 0}, dbg_act = 0, dbg_turns = 0, dbg_paused = 0, dbg_free = 0;
+    long long dbg_size[5] = {0, 0, 0, 0, 0}, dbg_drain = 0, dbg_drain_act = 0; // launches by size (< 16, < 32, < 64, < 128, more); launches after the last admission
     bool single = false; // admissions go to group 0 only (see the admission)
     int rc = PNR_OK;
     int idle_turns = 0;
@@ -642,6 +643,10 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
             q.lag = o.lag >= 0 ? std::min(o.lag, o.poll - 1) : (alone ? o.poll / 2 : std::min(1, o.poll - 1));
             rc = E.launch(g, q.active, o.poll, q.lag);
             if (rc) { err = E.error(); return fail(rc); }
+            if (o.timing) {
+                dbg_size[q.active < 16 ? 0 : q.active < 32 ? 1 : q.active < 64 ? 2 : q.active < 128 ? 3 : 4]++;
+                if (next >= n) { dbg_drain++; dbg_drain_act += q.active; }
+            }
             st.steps += o.poll;
             q.inflight = true;
         } else {
@@ -671,6 +676,9 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
                 rank, world, (long long)n, NT, o.look0, o.look_pct, o.target, (long long)st.steps,
                 (long long)st.polls, (long long)st.iters, (long long)st.exchanges, (long long)st.carried, r.nodes.size(), (long long)st.tent_passes,
                 (long long)st.tent_nodes, (long long)st.paused, (long long)st.resumed, (long long)st.ended, st.tent_ms, st.wait_ms);
+    if (o.timing)
+        fprintf(stderr, "[pnr trace] launches of < 16 / < 32 / < 64 / < 128 / more traces: %lld / %lld / %lld / %lld / %lld; after the last admission: %lld launches, %.1f traces each\n",
+                dbg_size[0], dbg_size[1], dbg_size[2], dbg_size[3], dbg_size[4], dbg_drain, dbg_drain ? (double)dbg_drain_act / dbg_drain : 0.0);
     if (o.timing && dbg_turns)
         fprintf(stderr, "[pnr trace] admissions ended by: no seeds left %lld, lookahead %lld, no free slot %lld, target / group share %lld; per turn: %.1f launched, %.1f paused in the group, %.1f free slots\n",
                 dbg_end[0], dbg_end[1], dbg_end[2], dbg_end[3], (double)dbg_act / dbg_turns, (double)dbg_paused / dbg_turns, (double)dbg_free / dbg_turns);

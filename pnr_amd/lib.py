@@ -516,9 +516,9 @@ def reconstruct(nodes, links, trace_rsmpl=0.0, sig2radius=0.0, refine_iter=0, ep
         cap = int(n.value)
 
 
-def kernel_source_hash(names=("smc_phased.hip", "smc_device.h", "smc.hip", "stream_sched.h")):
-    """sha256 (first 16 hex digits) over the sources of the SMC kernels and their scheduler (what the traffic of the particle evaluation
-    depends on): the committed PMC traffic profiles carry it,
+def kernel_source_hash(names=("smc_phased.hip", "smc_device.h", "smc.hip")):
+    """sha256 (first 16 hex digits) over the sources of the SMC kernels (what the bytes a trace-iteration moves depend on; the host
+    scheduler only decides how many trace-iterations a launch holds, which bench.py scales for): the committed PMC traffic profiles carry it,
     and bench.py only quotes a profile whose hash equals the hash of the sources it runs (a changed kernel is never priced with the
     bytes of an older one)"""
     import hashlib
