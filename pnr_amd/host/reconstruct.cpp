@@ -2,7 +2,10 @@
 #include "reconstruct.h"
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <sched.h>
 #include <thread>
@@ -65,28 +68,58 @@ void resample_links(List &g, float step)
         }
 }
 
-// uniform grid over node positions (indices >= 1); cell lists are ascending by construction
+// uniform grid over node positions (indices >= 1).  The nodes are kept cell by cell (ascending index inside a cell) with their
+// coordinates packed beside them, so a query streams contiguous memory; cells are found through an open-addressing table.
 struct Grid {
     float cell;
-    std::unordered_map<long long, std::vector<int>> cells;
+    std::vector<int> idx;          // node indices, sorted by (cell, index)
+    std::vector<float> px, py, pz; // their coordinates, in the same order
+    std::vector<long long> hkey;   // table: cell key (-1 = empty) -> [hbeg, hend) in idx
+    std::vector<int> hbeg, hend;
+    size_t mask = 0;
     static long long key(int a, int b, int c) { return ((long long)(a + (1 << 20)) << 42) | ((long long)(b + (1 << 20)) << 21) | (long long)(c + (1 << 20)); }
+    static size_t mix(long long k) { return (size_t)(((unsigned long long)k * 0x9E3779B97F4A7C15ull) >> 20); }
     Grid(const List &g, float cell_) : cell(cell_)
     {
-        cells.reserve(g.size());
-        for (size_t i = 1; i < g.size(); i++) cells[key(bin(g[i].x), bin(g[i].y), bin(g[i].z))].push_back((int)i);
+        const size_t n = g.size() > 0 ? g.size() - 1 : 0;
+        std::vector<std::pair<long long, int>> ki(n);
+        for (size_t i = 1; i < g.size(); i++) ki[i - 1] = {key(bin(g[i].x), bin(g[i].y), bin(g[i].z)), (int)i};
+        std::sort(ki.begin(), ki.end());
+        idx.resize(n); px.resize(n); py.resize(n); pz.resize(n);
+        size_t ncell = 0;
+        for (size_t k = 0; k < n; k++) {
+            const N &v = g[ki[k].second];
+            idx[k] = ki[k].second; px[k] = v.x; py[k] = v.y; pz[k] = v.z;
+            if (k == 0 || ki[k].first != ki[k - 1].first) ncell++;
+        }
+        size_t cap = 16;
+        while (cap < 2 * ncell) cap <<= 1;
+        mask = cap - 1;
+        hkey.assign(cap, -1); hbeg.assign(cap, 0); hend.assign(cap, 0);
+        for (size_t k = 0; k < n;) {
+            size_t e = k + 1;
+            while (e < n && ki[e].first == ki[k].first) e++;
+            size_t h = mix(ki[k].first) & mask;
+            while (hkey[h] != -1) h = (h + 1) & mask;
+            hkey[h] = ki[k].first; hbeg[h] = (int)k; hend[h] = (int)e;
+            k = e;
+        }
     }
     int bin(float v) const { return (int)std::floor(v / cell); }
-    // all node indices whose cell intersects the cube of half-width R around (x,y,z), ascending
-    void query(float x, float y, float z, float R, std::vector<int> &out) const
+    // calls visit(first, last) -- a range of positions in idx / px / py / pz -- for every non-empty cell that intersects the cube
+    // of half-width R around (x,y,z); the caller filters by distance first and orders what is left (the sums of the reference
+    // run over ascending node index)
+    template <class F>
+    void for_cells(float x, float y, float z, float R, F &&visit) const
     {
-        out.clear();
-        for (int a = bin(x - R); a <= bin(x + R); a++)
-            for (int b = bin(y - R); b <= bin(y + R); b++)
-                for (int c = bin(z - R); c <= bin(z + R); c++) {
-                    auto it = cells.find(key(a, b, c));
-                    if (it != cells.end()) out.insert(out.end(), it->second.begin(), it->second.end());
+        const int a0 = bin(x - R), a1 = bin(x + R), b0 = bin(y - R), b1 = bin(y + R), c0 = bin(z - R), c1 = bin(z + R);
+        for (int a = a0; a <= a1; a++)
+            for (int b = b0; b <= b1; b++)
+                for (int c = c0; c <= c1; c++) {
+                    const long long k = key(a, b, c);
+                    for (size_t h = mix(k) & mask; hkey[h] != -1; h = (h + 1) & mask)
+                        if (hkey[h] == k) { visit(hbeg[h], hend[h]); break; }
                 }
-        std::sort(out.begin(), out.end());
     }
 };
 
@@ -116,21 +149,23 @@ void mean_shift(const List &src, List &dst, float SIG2RAD, int MAXITER, float EP
                 cnt = 0;
                 next[0] = next[1] = next[2] = next[3] = 0;
                 const float r2 = (float)std::pow((double)(SIG2RAD * conv[3]), 2);
-                // candidates in ascending index: the accepted ones are summed in the order of the reference's full scan
-                grid.query(conv[0], conv[1], conv[2], std::sqrt(r2) * 1.0001f + 1e-3f, cand);
-                for (int j : cand) {
-                    const float x2 = (float)std::pow((double)(src[j].x - conv[0]), 2);
-                    if (x2 <= r2) {
-                        const float y2 = (float)std::pow((double)(src[j].y - conv[1]), 2);
-                        if (x2 + y2 <= r2) {
-                            const float z2 = (float)std::pow((double)(src[j].z - conv[2]), 2);
-                            if (x2 + y2 + z2 <= r2) {
-                                next[0] += src[j].x; next[1] += src[j].y; next[2] += src[j].z; next[3] += src[j].sig;
-                                cnt++;
-                            }
-                        }
+                // the members of the ball, then in ascending index: summed in the order of the reference's full scan
+                cand.clear();
+                grid.for_cells(conv[0], conv[1], conv[2], std::sqrt(r2) * 1.0001f + 1e-3f, [&](int p, int e) {
+                    for (; p < e; p++) {
+                        const float x2 = (float)std::pow((double)(grid.px[p] - conv[0]), 2);
+                        if (!(x2 <= r2)) continue;
+                        const float y2 = (float)std::pow((double)(grid.py[p] - conv[1]), 2);
+                        if (!(x2 + y2 <= r2)) continue;
+                        const float z2 = (float)std::pow((double)(grid.pz[p] - conv[2]), 2);
+                        if (x2 + y2 + z2 <= r2) cand.push_back(grid.idx[p]);
                     }
+                });
+                std::sort(cand.begin(), cand.end());
+                for (int j : cand) {
+                    next[0] += src[j].x; next[1] += src[j].y; next[2] += src[j].z; next[3] += src[j].sig;
                 }
+                cnt = (int)cand.size();
                 next[0] /= cnt; next[1] /= cnt; next[2] /= cnt; next[3] /= cnt;
                 d2 = (float)(std::pow((double)(next[0] - conv[0]), 2) + std::pow((double)(next[1] - conv[1]), 2) + std::pow((double)(next[2] - conv[2]), 2));
                 for (int q = 0; q < 4; q++) conv[q] = next[q];
@@ -174,10 +209,15 @@ void group_spheres(List &src, List &dst, float rad)
 {
     const size_t n = src.size();
     src[0].corr = FLT_MAX;
+    // the reference's std::sort by corr is unstable; equal corr keeps index order here (the keys are sorted beside their
+    // indices: a comparator that reads the nodes themselves spends its time on cache misses)
+    std::vector<std::pair<float, int>> keyed(n);
+    for (size_t i = 0; i < n; i++) keyed[i] = {src[i].corr, (int)i};
+    std::sort(keyed.begin(), keyed.end(), [](const std::pair<float, int> &a, const std::pair<float, int> &b) {
+        return a.first > b.first || (a.first == b.first && a.second < b.second);
+    });
     std::vector<int> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    // the reference's std::sort by corr is unstable; equal corr keeps index order here
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return src[a].corr > src[b].corr; });
+    for (size_t i = 0; i < n; i++) order[i] = keyed[i].second;
     std::vector<int> to(n, -1);
     to[0] = 0;
     dst.clear();
@@ -196,15 +236,21 @@ void group_spheres(List &src, List &dst, float rad)
         to[ci] = (int)dst.size();
         N grp = src[ci];
         float members = 1;
-        grid.query(src[ci].x, src[ci].y, src[ci].z, rad * 1.0001f + 1e-3f, cand);
+        cand.clear();
+        grid.for_cells(src[ci].x, src[ci].y, src[ci].z, rad * 1.0001f + 1e-3f, [&](int p, int e) {
+            for (; p < e; p++) {
+                const int j = grid.idx[p];
+                if (j == ci || to[j] != -1) continue;
+                float d2 = (float)std::pow((double)(grid.px[p] - src[ci].x), 2);
+                if (!(d2 <= r2)) continue;
+                d2 = (float)(d2 + std::pow((double)(grid.py[p] - src[ci].y), 2));
+                if (!(d2 <= r2)) continue;
+                d2 = (float)(d2 + std::pow((double)(grid.pz[p] - src[ci].z), 2));
+                if (d2 <= r2) cand.push_back(j);
+            }
+        });
+        std::sort(cand.begin(), cand.end());
         for (int j : cand) {
-            if (j == ci || to[j] != -1) continue;
-            float d2 = (float)std::pow((double)(src[j].x - src[ci].x), 2);
-            if (!(d2 <= r2)) continue;
-            d2 = (float)(d2 + std::pow((double)(src[j].y - src[ci].y), 2));
-            if (!(d2 <= r2)) continue;
-            d2 = (float)(d2 + std::pow((double)(src[j].z - src[ci].z), 2));
-            if (!(d2 <= r2)) continue;
             to[j] = (int)dst.size();
             grp.nbr.insert(grp.nbr.end(), src[j].nbr.begin(), src[j].nbr.end());
             members++;
@@ -316,12 +362,28 @@ void reconstruct(const std::vector<pnr_node> &nodes, const std::vector<int32_t> 
         n0[links[k + 1]].nbr.push_back(links[k]);
     }
     List n1, n2, forest, kept;
+    // PNR_RECON_TIMING=1: the stages' wall times on stderr
+    const bool timing = std::getenv("PNR_RECON_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what, size_t n) {
+        if (!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pnr reconstruct] %-14s %8.2f ms  (%zu nodes)\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count(), n);
+        t_prev = t;
+    };
+    lap("graph", n0.size());
     resample_links(n0, rp.trace_rsmpl);
+    lap("resample_links", n0.size());
     mean_shift(n0, n1, rp.sig2radius, rp.refine_iter, rp.epsilon2, rp.threads);
+    lap("mean_shift", n1.size());
     group_spheres(n1, n2, rp.group_radius);
+    lap("group_spheres", n2.size());
     bfs_forest(n2, forest);
+    lap("bfs_forest", forest.size());
     drop_small_trees(forest, kept, rp.tree_size_min);
+    lap("drop_small", kept.size());
     resample_tree(kept, 1.0f, 2 /* Node::AXON */);
+    lap("resample_tree", kept.size());
     out_nodes.resize(kept.size());
     out_parent.resize(kept.size());
     for (size_t i = 0; i < kept.size(); i++) {

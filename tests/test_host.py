@@ -154,6 +154,37 @@ def test_reconstruct_matches_oracle(oracle, vol, tree_min):
     assert set(np.unique(got_n["type"][1:])) == {2}
 
 
+def test_reconstruct_dense_graph_matches_oracle(oracle):
+    """a dense graph (random-walk traces that cross each other: balls of the mean-shift hold dozens of nodes out of many grid
+    cells, thousands of nodes share a corr value so the grouping order falls back to the node index) through the packed grid,
+    the filter-then-order neighbour scan and the keyed corr sort of the host implementation, against the oracle's O(n^2) scan"""
+    rs = np.random.RandomState(5)
+    shape = (40, 64, 72)
+    l, h, w = shape
+    ni, nseed = 50, 45
+    s = np.zeros((nseed, 8), np.float32)
+    s[:, 0] = rs.uniform(20, w - 20, nseed); s[:, 1] = rs.uniform(20, h - 20, nseed); s[:, 2] = rs.uniform(12, l - 12, nseed)
+    s[:, 3:6] = rs.randn(nseed, 3); s[:, 6] = 0.9; s[:, 7] = 2.0
+    T = rs.randint(30, ni + 1, 2 * nseed).astype(np.int32)
+    xc = np.zeros((2 * nseed, ni, 8), np.float32)
+    for t in range(2 * nseed):
+        d = rs.randn(3); d /= np.linalg.norm(d)
+        pos = s[t // 2, :3] + np.cumsum(1.3 * d + 0.4 * rs.randn(ni, 3), 0)
+        pos[:, 0] = np.clip(pos[:, 0], 0, w - 1.01); pos[:, 1] = np.clip(pos[:, 1], 0, h - 1.01); pos[:, 2] = np.clip(pos[:, 2], 0, l - 1.01)
+        xc[t, :, 0:3] = pos
+        xc[t, :, 3:6] = d
+        xc[t, :, 6] = rs.choice([2.0, 4.0, 6.0], ni)
+        xc[t, :, 7] = np.round(rs.uniform(0.4, 0.9, ni), 1)  # six distinct corr values
+    nodes, links, _ = orc.replay(oracle, s, T, xc, ni, shape, 4, 5)
+    assert len(nodes) > 2500
+    want_n, want_p = orc.reconstruct(oracle, nodes, links, tree_size_min=4)
+    got_n, got_p = lib.reconstruct(nodes.astype(lib.NODE_DT), links, tree_size_min=4)
+    assert len(got_n) == len(want_n) > 300
+    assert np.array_equal(got_p, want_p)
+    for k in got_n.dtype.names:
+        assert np.array_equal(got_n[k], want_n[k], equal_nan=True), k
+
+
 def test_replay_and_reconstruct_with_soma_match_oracle(oracle):
     """soma nodes in the node list: the oracle's replay with a soma map supplies a graph whose traces end on
     SOMA nodes; group1 keeps soma nodes as groups of their own (Advantra_plugin.cpp:1580-1588), bfs keeps their type."""
