@@ -1,6 +1,7 @@
 // reconstruct.cpp -- see reconstruct.h.  Pure host code (the reference keeps this stage on the host as well).
 #include "reconstruct.h"
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -132,59 +133,65 @@ unsigned usable_cpus()
 }
 
 // :968-1052 -- non-blurring mean-shift of (x,y,z,sig) with a kernel radius SIG2RAD*sig
-void mean_shift(const List &src, List &dst, float SIG2RAD, int MAXITER, float EPS2, int threads)
+void mean_shift(List &g, float SIG2RAD, int MAXITER, float EPS2, int threads)
 {
-    dst = src;
+    // in place: every trajectory reads the positions as they were on entry (kept packed, in index order), the results are
+    // written back once all of them are known
+    struct P4 { float x, y, z, s; };
+    const size_t n = g.size();
+    std::vector<P4> src(n), res(n);
     float smax = 0;
-    for (size_t i = 1; i < src.size(); i++) smax = std::max(smax, src[i].sig);
-    const Grid grid(src, std::max(4.0f, SIG2RAD * smax));
-    // every node's trajectory only reads `src`: the nodes are independent and are spread over host threads
-    auto shift_range = [&](size_t i0, size_t i1) {
+    for (size_t i = 0; i < n; i++) src[i] = P4{g[i].x, g[i].y, g[i].z, g[i].sig};
+    for (size_t i = 1; i < n; i++) smax = std::max(smax, src[i].s);
+    const Grid grid(g, std::max(4.0f, SIG2RAD * smax));
+    // the nodes are independent: host threads take them in blocks from a shared counter (tubes are dense in places)
+    std::atomic<size_t> next_block{1};
+    constexpr size_t BLOCK = 256;
+    auto shift_blocks = [&]() {
         std::vector<int> cand;
-        for (size_t i = i0; i < i1; i++) {
-            float conv[4] = {src[i].x, src[i].y, src[i].z, src[i].sig}, next[4];
-            int iter = 0, cnt;
-            float d2;
-            do {
-                cnt = 0;
-                next[0] = next[1] = next[2] = next[3] = 0;
-                const float r2 = (float)std::pow((double)(SIG2RAD * conv[3]), 2);
-                // the members of the ball, then in ascending index: summed in the order of the reference's full scan
-                cand.clear();
-                grid.for_cells(conv[0], conv[1], conv[2], std::sqrt(r2) * 1.0001f + 1e-3f, [&](int p, int e) {
-                    for (; p < e; p++) {
-                        const float x2 = (float)std::pow((double)(grid.px[p] - conv[0]), 2);
-                        if (!(x2 <= r2)) continue;
-                        const float y2 = (float)std::pow((double)(grid.py[p] - conv[1]), 2);
-                        if (!(x2 + y2 <= r2)) continue;
-                        const float z2 = (float)std::pow((double)(grid.pz[p] - conv[2]), 2);
-                        if (x2 + y2 + z2 <= r2) cand.push_back(grid.idx[p]);
+        for (;;) {
+            const size_t i0 = next_block.fetch_add(BLOCK), i1 = std::min(n, i0 + BLOCK);
+            if (i0 >= n) break;
+            for (size_t i = i0; i < i1; i++) {
+                float conv[4] = {src[i].x, src[i].y, src[i].z, src[i].s}, next[4];
+                int iter = 0, cnt;
+                float d2;
+                do {
+                    next[0] = next[1] = next[2] = next[3] = 0;
+                    const float r2 = (float)std::pow((double)(SIG2RAD * conv[3]), 2);
+                    // the members of the ball, then in ascending index: summed in the order of the reference's full scan
+                    cand.clear();
+                    grid.for_cells(conv[0], conv[1], conv[2], std::sqrt(r2) * 1.0001f + 1e-3f, [&](int p, int e) {
+                        for (; p < e; p++) {
+                            const float x2 = (float)std::pow((double)(grid.px[p] - conv[0]), 2);
+                            if (!(x2 <= r2)) continue;
+                            const float y2 = (float)std::pow((double)(grid.py[p] - conv[1]), 2);
+                            if (!(x2 + y2 <= r2)) continue;
+                            const float z2 = (float)std::pow((double)(grid.pz[p] - conv[2]), 2);
+                            if (x2 + y2 + z2 <= r2) cand.push_back(grid.idx[p]);
+                        }
+                    });
+                    std::sort(cand.begin(), cand.end());
+                    for (int j : cand) {
+                        next[0] += src[j].x; next[1] += src[j].y; next[2] += src[j].z; next[3] += src[j].s;
                     }
-                });
-                std::sort(cand.begin(), cand.end());
-                for (int j : cand) {
-                    next[0] += src[j].x; next[1] += src[j].y; next[2] += src[j].z; next[3] += src[j].sig;
-                }
-                cnt = (int)cand.size();
-                next[0] /= cnt; next[1] /= cnt; next[2] /= cnt; next[3] /= cnt;
-                d2 = (float)(std::pow((double)(next[0] - conv[0]), 2) + std::pow((double)(next[1] - conv[1]), 2) + std::pow((double)(next[2] - conv[2]), 2));
-                for (int q = 0; q < 4; q++) conv[q] = next[q];
-                iter++;
-            } while (iter < MAXITER && d2 > EPS2);
-            dst[i].x = conv[0]; dst[i].y = conv[1]; dst[i].z = conv[2]; dst[i].sig = conv[3];
+                    cnt = (int)cand.size();
+                    next[0] /= cnt; next[1] /= cnt; next[2] /= cnt; next[3] /= cnt;
+                    d2 = (float)(std::pow((double)(next[0] - conv[0]), 2) + std::pow((double)(next[1] - conv[1]), 2) + std::pow((double)(next[2] - conv[2]), 2));
+                    for (int q = 0; q < 4; q++) conv[q] = next[q];
+                    iter++;
+                } while (iter < MAXITER && d2 > EPS2);
+                res[i] = P4{conv[0], conv[1], conv[2], conv[3]};
+            }
         }
     };
-    const size_t n = dst.size();
     unsigned nt = threads > 0 ? (unsigned)threads : usable_cpus();
     if (n < 4096) nt = 1;
     std::vector<std::thread> th;
-    const size_t chunk = (n - 1 + nt - 1) / nt;
-    for (unsigned t = 1; t < nt; t++) {
-        const size_t a = 1 + t * chunk, b = std::min(n, a + chunk);
-        if (a < b) th.emplace_back(shift_range, a, b);
-    }
-    shift_range(1, std::min(n, 1 + chunk));
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(shift_blocks);
+    shift_blocks();
     for (auto &t : th) t.join();
+    for (size_t i = 1; i < n; i++) { g[i].x = res[i].x; g[i].y = res[i].y; g[i].z = res[i].z; g[i].sig = res[i].s; }
 }
 
 // :1532-1564 -- unique neighbour lists, no self links, links made bidirectional
@@ -361,7 +368,7 @@ void reconstruct(const std::vector<pnr_node> &nodes, const std::vector<int32_t> 
         n0[links[k]].nbr.push_back(links[k + 1]);
         n0[links[k + 1]].nbr.push_back(links[k]);
     }
-    List n1, n2, forest, kept;
+    List n2, forest, kept;
     // PNR_RECON_TIMING=1: the stages' wall times on stderr
     const bool timing = std::getenv("PNR_RECON_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -374,9 +381,9 @@ void reconstruct(const std::vector<pnr_node> &nodes, const std::vector<int32_t> 
     lap("graph", n0.size());
     resample_links(n0, rp.trace_rsmpl);
     lap("resample_links", n0.size());
-    mean_shift(n0, n1, rp.sig2radius, rp.refine_iter, rp.epsilon2, rp.threads);
-    lap("mean_shift", n1.size());
-    group_spheres(n1, n2, rp.group_radius);
+    mean_shift(n0, rp.sig2radius, rp.refine_iter, rp.epsilon2, rp.threads);
+    lap("mean_shift", n0.size());
+    group_spheres(n0, n2, rp.group_radius);
     lap("group_spheres", n2.size());
     bfs_forest(n2, forest);
     lap("bfs_forest", forest.size());

@@ -20,6 +20,8 @@ for rep in range(2):  # (the first run pays the page cache and the driver's firs
     t0 = time.time()
     pr = subprocess.run(cmd, capture_output=True, text=True)
     wall = time.time() - t0
+    for ln in pr.stderr.splitlines():  # (PNR_RECON_TIMING=1: the stages of reconstruct())
+        if ln.startswith("[pnr reconstruct]"): print(ln, file=sys.stderr)
     m = re.search(r"wall: load ([\d.]+) s, context \+ upload ([\d.]+) s, frangi ([\d.]+) s, seeds ([\d.]+) s, selection ([\d.]+) s, tracing ([\d.]+) s, reconstruct ([\d.]+) s, write ([\d.]+) s \| total ([\d.]+) s", pr.stdout)
     m2 = re.search(r"(\d+) trace nodes, (\d+) traces, (\d+) SMC iterations, (\d+) tree nodes", pr.stdout)
     if not m:
