@@ -317,7 +317,10 @@ bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *>
     Result local;
     Result *R = result ? result : &local;
     const double t_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
-    if (reconstruction_func(st.bytes(), st.w, st.h, st.l, infiles[0], paras, p, device, R) && settings().rank == 0) {
+    // a failure of the device library (no GPU, out of memory, a failed exchange) has no counterpart in the reference's contract:
+    // it is reported on stderr by reconstruction_func and makes the function -- and the CLI's exit status -- fail
+    if (!reconstruction_func(st.bytes(), st.w, st.h, st.l, infiles[0], paras, p, device, R)) return false;
+    if (settings().rank == 0) {
         // what a user of advantra_func waits for (Advantra_plugin.cpp:2241 load, :2183-2731 reconstruction_func, :2164 the SWC)
         R->t_load = t_load;
         R->t_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();

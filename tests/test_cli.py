@@ -34,6 +34,22 @@ def test_cli_usage_errors():
     assert run("-f", "nonsense").returncode == 1
 
 
+def test_cli_fails_loudly_without_a_gpu(tmp_path):
+    """a valid call on a machine without an MI355X: the device library's error on stderr, no SWC, exit status 1 (there is no CPU
+    path; the reference's own contract -- status 0 after a parameter / image message -- only covers its own failure modes)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    if not os.path.exists(CLI):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(CLI)], check=True)
+    raw = str(tmp_path / "s.raw")
+    synth.synth(32, 24, 8, seed=1).tofile(raw)
+    for extra in ((), ("--ranks", "2")):
+        r = run("-d", "32,24,8", *extra, "-f", "advantra_func", "-i", raw, "-p", *"2 0 5 0.3 3 2 20 20 2 4 5".split())
+        assert r.returncode == 1 and "no HIP device" in r.stderr, (r.returncode, r.stderr)
+        assert not os.path.exists(raw + "_Advantra.swc")
+
+
 @pytest.mark.gpu
 def test_cli_matches_python_pipeline(tmp_path):
     from PIL import Image
