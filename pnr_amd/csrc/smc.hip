@@ -301,7 +301,7 @@ __global__ __launch_bounds__(768) void smc_trace(Vol V, Tab T, TabX X, const flo
                 const int nv = __builtin_amdgcn_readfirstlane(gr.nv), nu = __builtin_amdgcn_readfirstlane(gr.nu);
                 const int nw = __builtin_amdgcn_readfirstlane(gr.nw);
                 const float *ax = X.axes + __builtin_amdgcn_readfirstlane(X.axes_off[sI]);
-                sample_slice<CS>(V, Bx, f, nv, nu, nw, ax, iv, slot_base + (i64)(sI * ngroups + g) * X.wave_floats + (tid & 63));
+                sample_slice<CS>(V, Bx, f, nv, nu, nw, ax, iv, slot_base + (i64)(sI * ngroups + g) * X.wave_floats);
             }
             __syncthreads(); // stash written by other waves of this work-group: same CU, same L1
             STAMP(6); // phase A (sampling)

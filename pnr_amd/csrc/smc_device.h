@@ -473,7 +473,7 @@ __device__ __forceinline__ float zncc_chain_box(const Vol &V, const Box &B, cons
 // no longer pin the iteration time to the longest chain.  Values go to the stash at [sample][lane].
 template <int CS, bool IS2D = false, bool FAST = false, int PITCH = CS, bool INVOL = false>
 __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const Frame &f, int nv, int nu, int nw,
-                                             const float *__restrict__ ax, int iv, float *__restrict__ stash_lane, int iu0 = 0,
+                                             const float *__restrict__ ax, int iv, float *__restrict__ stash_wave, int iu0 = 0,
                                              int iu1 = 1 << 30)
 {
     constexpr int G = CHAIN_G;
@@ -483,17 +483,43 @@ __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const F
     const float vv = ax[iv]; // wave-uniform
     const float x0 = f.px + vv * f.nvx, y0 = f.py + vv * f.nvy, z0 = f.pz + vv * f.nvz;
     if (iu1 > nu) iu1 = nu; // rows [iu0, iu1) of the v-slice (default: all)
-    float *sp = stash_lane + ((i64)iv * nu + iu0) * nw * 64;
+    // one 64-bit scalar base for the whole row chunk (told to the compiler with readfirstlane), the lane as a 32-bit offset and
+    // the sample within a group as the store's immediate: one address instruction per group of five stores, not one per store
+    typedef __attribute__((address_space(1))) float gfloat; // (an integer round trip would make the pointer generic: flat stores)
+    gfloat *sp;
+    {
+        const unsigned long long a = (unsigned long long)(stash_wave + ((i64)iv * nu + iu0) * nw * 64);
+        sp = (gfloat *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a));
+    }
+    const unsigned ulane = (unsigned)lane;
     for (int iu = iu0; iu < iu1; ++iu) {
         const float uu = bcast(r_au, iu);
         const float x1 = x0 + uu * f.ux, y1 = y0 + uu * f.uy, z1 = z0 + uu * f.uz;
-        for (int iw0 = 0; iw0 < nw; iw0 += G) {
+        // full groups first, free of per-sample tests (nw = 25: all of them; the five interpolations of a group are then one
+        // straight piece of code for the scheduler); a last, partly filled group (nw = 13) afterwards
+        int iw0 = 0;
+        for (; iw0 + G <= nw; iw0 += G) {
+            float xs[G], ys[G], zs[G];
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                const float ww = bcast(r_aw, iw0 + j);
+                const f32x2 xy = (f32x2){x1, y1} + (f32x2){ww, ww} * (f32x2){f.wx, f.wy}; // packed: same two roundings each
+                xs[j] = xy.x;
+                ys[j] = xy.y;
+                zs[j] = z1 + ww * f.wz;
+            }
+            const Samples<G> sm = interp_group<G, CS, IS2D, FAST, PITCH, INVOL>(V, B, xs, ys, zs);
+            gfloat *const pl = (sp + iw0 * 64) + ulane;
+#pragma unroll
+            for (int j = 0; j < G; j++) STASH_ST(&pl[j * 64], sm.v[j]);
+        }
+        if (iw0 < nw) {
             float xs[G], ys[G], zs[G];
 #pragma unroll
             for (int j = 0; j < G; j++) {
                 const int iw = (iw0 + j < nw) ? iw0 + j : nw - 1; // wave-uniform
                 const float ww = bcast(r_aw, iw);
-                const f32x2 xy = (f32x2){x1, y1} + (f32x2){ww, ww} * (f32x2){f.wx, f.wy}; // packed: same two roundings each
+                const f32x2 xy = (f32x2){x1, y1} + (f32x2){ww, ww} * (f32x2){f.wx, f.wy};
                 xs[j] = xy.x;
                 ys[j] = xy.y;
                 zs[j] = z1 + ww * f.wz;
@@ -501,7 +527,7 @@ __device__ __forceinline__ void sample_slice(const Vol &V, const Box &B, const F
             const Samples<G> sm = interp_group<G, CS, IS2D, FAST, PITCH, INVOL>(V, B, xs, ys, zs);
 #pragma unroll
             for (int j = 0; j < G; j++)
-                if (iw0 + j < nw) STASH_ST(&sp[(iw0 + j) * 64], sm.v[j]);
+                if (iw0 + j < nw) STASH_ST(&((sp + iw0 * 64) + ulane)[j * 64], sm.v[j]);
         }
         sp += nw * 64;
     }
@@ -531,13 +557,30 @@ __device__ __forceinline__ void sample_slice_packed(const Vol &V, const Box &B, 
         const float uu = __shfl(r_au, iuc);
         const float x1 = x0 + uu * f.ux, y1 = y0 + uu * f.uy, z1 = z0 + uu * f.uz;
         float *sp = stash_col + ((i64)(iv * nu + iuc) * nw) * stride;
-        for (int iw0 = 0; iw0 < nw; iw0 += G) {
+        int iw0 = 0;
+        for (; iw0 + G <= nw; iw0 += G) { // full groups, free of per-sample tests (see sample_slice)
+            float xs[G], ys[G], zs[G];
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                const float ww = bcast(r_aw, iw0 + j);
+                const f32x2 xy = (f32x2){x1, y1} + (f32x2){ww, ww} * (f32x2){f.wx, f.wy}; // packed: same two roundings each
+                xs[j] = xy.x;
+                ys[j] = xy.y;
+                zs[j] = z1 + ww * f.wz;
+            }
+            const Samples<G> sm = interp_group<G, CS, IS2D, FAST, PITCH, INVOL>(V, B, xs, ys, zs);
+            if (ok) {
+#pragma unroll
+                for (int j = 0; j < G; j++) STASH_ST(&sp[(iw0 + j) * stride], sm.v[j]);
+            }
+        }
+        if (iw0 < nw) {
             float xs[G], ys[G], zs[G];
 #pragma unroll
             for (int j = 0; j < G; j++) {
                 const int iw = (iw0 + j < nw) ? iw0 + j : nw - 1; // wave-uniform
                 const float ww = bcast(r_aw, iw);
-                const f32x2 xy = (f32x2){x1, y1} + (f32x2){ww, ww} * (f32x2){f.wx, f.wy}; // packed: same two roundings each
+                const f32x2 xy = (f32x2){x1, y1} + (f32x2){ww, ww} * (f32x2){f.wx, f.wy};
                 xs[j] = xy.x;
                 ys[j] = xy.y;
                 zs[j] = z1 + ww * f.wz;

@@ -269,7 +269,7 @@ __device__ unsigned long long g_ph_stamps[8];
 #endif
 
 template <int CS, bool IS2D>
-__global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it_arg, int lp, int nslots)
+__global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it_arg, int lp, int nslots)
 {
     extern __shared__ unsigned char cube[];
     // part-major: the first nslots work-groups are one per trace, the later ones join whatever is left of their trace
@@ -397,11 +397,11 @@ __global__ __launch_bounds__(PH_THREADS) void ph_sample(Vol V, Tab T, TabX X, Ph
             const float *q = (k >= np) ? xc_pen : cur + k * PSTRIDE; // (the centroid before the first one exists: zeros, discarded)
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
             if (fastmask >> sI & 1)
-                sample_slice<CS, IS2D, true, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+                sample_slice<CS, IS2D, true, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64, ch * ROWS, ch * ROWS + ROWS);
             else if (volmask >> sI & 1)
-                sample_slice<CS, IS2D, false, PH_PITCH, true>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+                sample_slice<CS, IS2D, false, PH_PITCH, true>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64, ch * ROWS, ch * ROWS + ROWS);
             else
-                sample_slice<CS, IS2D, false, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64 + lane, ch * ROWS, ch * ROWS + ROWS);
+                sample_slice<CS, IS2D, false, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64, ch * ROWS, ch * ROWS + ROWS);
             PNR_HOOK_AFTER_FULL_ITEM(sbase + (i64)g * Ms * 64 + lane + ((i64)iv * nu + ch * ROWS) * nw * 64, (min(ch * ROWS + ROWS, nu) - ch * ROWS) * nw);
         } else {
             const bool act = lane < parts * rem;
