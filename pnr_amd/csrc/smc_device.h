@@ -144,9 +144,6 @@ __device__ __forceinline__ float zncc_chain(const Vol &V, const Frame &f, const 
     }
     for (; k < M; ++k) ag += sample(V, f, tm[k]);
     ag /= (float)M;
-#ifdef PNR_SMC_STAMPS
-    if (stamp_pass1) *stamp_pass1 = __builtin_amdgcn_s_memtime();
-#endif
     float corra = 0.f, corrb = 0.f;
     for (k = 0; k + ZB <= M; k += ZB) {
         float v[ZB], w[ZB];
@@ -634,6 +631,9 @@ __device__ __forceinline__ float zncc_from_stash(const float *__restrict__ stash
             if (j < tail) ag += cur[j];
     }
     ag /= (float)M;
+#ifdef PNR_SMC_STAMPS
+    if (stamp_pass1) *stamp_pass1 = __builtin_amdgcn_s_memtime();
+#endif
     float corra = 0.f, corrb = 0.f;
     if (nfull > 0) {
 #pragma unroll
@@ -716,7 +716,11 @@ __device__ __forceinline__ void stash_chunks(const float *__restrict__ stash_lan
 }
 
 template <int STRIDE = 64, int CH = 16, int NB = 4>
-__device__ __forceinline__ float zncc_from_stash_deep(const float *__restrict__ stash_lane, int M, const float *__restrict__ wd, float corrc)
+__device__ __forceinline__ float zncc_from_stash_deep(const float *__restrict__ stash_lane, int M, const float *__restrict__ wd, float corrc
+#ifdef PNR_SMC_STAMPS
+                                                      , unsigned long long *stamp_pass1 = nullptr
+#endif
+)
 {
     const int nfull = M / CH, tail = M - nfull * CH; // wave-uniform
     float ag = 0.f;
@@ -734,6 +738,9 @@ __device__ __forceinline__ float zncc_from_stash_deep(const float *__restrict__ 
             if (j < tail) ag += t[j];
     }
     ag /= (float)M;
+#ifdef PNR_SMC_STAMPS
+    if (stamp_pass1) *stamp_pass1 = __builtin_amdgcn_s_memtime();
+#endif
     float corra = 0.f, corrb = 0.f;
     stash_chunks<STRIDE, CH, NB>(stash_lane, nfull, [&](const float (&v)[CH], int c) {
         const float *wk = wd + c * CH; // wave-uniform address: scalar loads

@@ -453,7 +453,8 @@ __global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, 
 #endif
     if (g < ngf) {
 #ifdef PNR_SMC_STAMPS
-        cv = zncc_from_stash<64, PH_CH>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI], &sst1);
+        if constexpr (DEEP) cv = zncc_from_stash_deep<64>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI], &sst1);
+        else cv = zncc_from_stash<64, PH_CH>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI], &sst1);
 #else
         if constexpr (DEEP) cv = zncc_from_stash_deep<64>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI]);
         else cv = zncc_from_stash<64, PH_CH>(sbase + (i64)g * M * 64 + lane, M, wd, T.corrc[sI]);

@@ -1,5 +1,5 @@
 """Diagnostic: where a sampling work-group of the phased driver spends its cycles (needs `make -C pnr_amd/csrc stamps`; run with
-PNR_LIB_DIAG=pnr_amd/libpnr_hip_stamps.so).  Never quote this build's run time.  usage: ph_stamps.py [size] [nseeds]"""
+PNR_LIB_DIAG=pnr_amd/libpnr_hip_stamps.so).  Never quote this build's run time.  usage: [PNR_STAMP_OPTS=target=40] ph_stamps.py [size] [nseeds]"""
 import os, sys, ctypes as C
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import numpy as np, torch, synth, pnr_amd
@@ -11,6 +11,7 @@ p = pnr_amd.make_params(sigmas=(2, 4, 6), np_=200, ni=200, zdist=2)
 c = pnr_amd.Context(p, 0)
 c.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
 c.set_option("groups", 1)
+c.set_options(os.environ.get("PNR_STAMP_OPTS"))  # e.g. target=40: the small launches of a sharded rank
 c.frangi(); s = c.score_filter_sort(c.extract_seeds())[:nseed]
 L = lib.load()
 st = (C.c_ulonglong * 8)()

@@ -14,6 +14,18 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session", autouse=True)
+def default_options():
+    """PNR_TEST_OPTIONS="key=value,key=value": scheduler / kernel-form options every Context of the session starts with (the results
+    must not depend on them: running the suite with e.g. sums_run_max=100000 puts every launch through the form that option
+    selects)"""
+    spec = os.environ.get("PNR_TEST_OPTIONS", "")
+    if spec:
+        import pnr_amd.lib as lib
+        lib.DEFAULTS["options"] = {k: int(v) for k, v in (kv.split("=") for kv in spec.split(",") if kv)}
+    yield
+
+
+@pytest.fixture(scope="session", autouse=True)
 def built_tree():
     """A fresh checkout has no binaries: compile the HIP library (hipcc cross-compiles without a GPU) and the head-less CLI once
     per session, as __graft_entry__.build() does.  This only builds -- pnr_amd.lib.load() still fails loudly without the .so."""
