@@ -66,10 +66,19 @@ __device__ __forceinline__ unsigned int pose_hash(float x, float y, float z, flo
 __device__ __forceinline__ int last_group_stride(int rem) { return rem > 32 ? 64 : (rem > 16 ? 32 : 16); }
 
 
+#ifdef PNR_SMC_STAMPS
+// diagnostic build only: shader-clock sums over the phases of ph_predict ([0..6], [7] = work-groups) and ph_update ([8..14], [15])
+__device__ unsigned long long g_pu_stamps[16];
+#define PU_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define PU_STAMP(var)
+#endif
+
 __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, const float *__restrict__ seeds6, Vol V, int np, int ni, int it_arg,
                                                    int lp, int CS)
 {
     const int tid = threadIdx.x, B = blockDim.x;
+    PU_STAMP(pt0);
     if (blockIdx.x == 0 && tid == 0) P.cnt[lp ^ 1] = 0; // filled by ph_update of this step
     if ((int)blockIdx.x >= P.cnt[lp]) return;
     const int tr = P.list[lp * P.cap + blockIdx.x];
@@ -92,6 +101,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     if (tid < 3) { sbox[tid] = 0x7fffffff; sbox[3 + tid] = -0x7fffffff; }
     if (tid == 3) { P.ctr[tr] = 0; sbox[6] = 0; }
     __syncthreads();
+    PU_STAMP(pt1);
     for (int k = tid; k <= np; k += B) {
         float qx, qy, qz, qvx, qvy, qvz;
         if (k == np) {
@@ -153,6 +163,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
         }
     }
     __syncthreads();
+    PU_STAMP(pt2);
     if (tid == 0) { // cube origin: centred on the bounding box of all templates, kept inside the volume
         const int dim[3] = {V.w, V.h, V.l};
         for (int a = 0; a < 3; a++) {
@@ -179,6 +190,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
         sbox[7] = ((1 << T.nsig) - 1) * 0x101; // bits 0..7: inside cube and volume, bits 8..15: inside the volume
     }
     __syncthreads();
+    PU_STAMP(pt3);
     // Per sigma: do ALL templates of this trace lie inside the cube and inside the volume?  Then the sampling kernel takes
     // the variant without clamps, range tests and fallback for that sigma (the common case for the smaller scales).
     {
@@ -210,6 +222,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
         if (ok != (1u << T.nsig) - 1u || okv != (1u << T.nsig) - 1u) atomicAnd(&sbox[7], (int)(ok | (okv << 8)));
     }
     __syncthreads();
+    PU_STAMP(pt4);
     if (tid == 0) fl[FL_FAST] = sbox[7];
     // ---- exact duplicates among the particles (after a resampling several children of one parent draw the same prediction
     // offset: identical pose, identical likelihood -- 17 % of the evaluations of the bench workload): a particle whose six pose
@@ -243,6 +256,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
         rep[k] = r;
     }
     __syncthreads();
+    PU_STAMP(pt5);
     if (tid < 64) { // chain numbers in particle order: ballots over 64 particles at a time
         int cbase = 0;
         for (int base = 0; base < np; base += 64) {
@@ -260,6 +274,14 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     }
     __syncthreads();
     for (int k = tid; k < np; k += B) cmap[k] = (int)hs[rep[k]];
+#ifdef PNR_SMC_STAMPS
+    if (tid == 0) {
+        const unsigned long long pt6 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_pu_stamps[0], pt1 - pt0); atomicAdd(&g_pu_stamps[1], pt2 - pt1); atomicAdd(&g_pu_stamps[2], pt3 - pt2);
+        atomicAdd(&g_pu_stamps[3], pt4 - pt3); atomicAdd(&g_pu_stamps[4], pt5 - pt4); atomicAdd(&g_pu_stamps[5], pt6 - pt5);
+        atomicAdd(&g_pu_stamps[7], 1ull);
+    }
+#endif
 }
 
 #ifdef PNR_SMC_STAMPS
@@ -493,6 +515,7 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
 {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, B = blockDim.x, S = T.nsig;
+    PU_STAMP(ut0);
     if ((int)blockIdx.x >= P.cnt[lp]) return;
     const int tr = P.list[lp * P.cap + blockIdx.x];
     int *fl = P.flags + (i64)tr * FL_N;
@@ -524,6 +547,7 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
         for (int k = tid; k < np; k += B) { prvw[k] = gprv[k * PSTRIDE + PW]; prior[k] = P.prior[(i64)tr * np + k]; }
     }
     __syncthreads();
+    PU_STAMP(ut1);
 
     // ---- finish the pending centroid: corr, stop tests of that iteration (tracker.cpp:1072-1079) ----
     if (pending >= 0 && tid == 0) {
@@ -548,6 +572,7 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
         return;
     }
 
+    PU_STAMP(ut2);
     // ---- max over sigma, likelihood exp(Kc*corr) (:1028-1029) ----
     for (int k = tid; k < np; k += B) {
         float best = -FLT_MAX, bs = 0.f;
@@ -562,6 +587,7 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
     }
     __syncthreads();
 
+    PU_STAMP(ut3);
     // ---- weights, N_eff, CDF, centroid: sequential sums in particle order (:1035-1071) ----
     const bool carry = (it > 0) && !resampled_prev;
     if (tid == 0) {
@@ -589,6 +615,7 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
         for (int k = tid; k < np; k += B) cur[k * PSTRIDE + PW] = cur[k * PSTRIDE + PW] / wsum;
     }
     __syncthreads();
+    PU_STAMP(ut4);
     if (tid < 7) {
         const int comp = (tid < 6) ? tid : PSIG;
         float a = 0.f;
@@ -609,6 +636,7 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
         }
     }
     __syncthreads();
+    PU_STAMP(ut5);
     if (tid == 0) {
         const float cx = sxc[0], cy = sxc[1], cz = sxc[2], cvx = sxc[3], cvy = sxc[4], cvz = sxc[5];
         const float neff = sneff[0];
@@ -630,6 +658,7 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
         sres[0] = res;
     }
     __syncthreads();
+    PU_STAMP(ut6);
     if (tid < 7) xc_cur[tid] = sxc[tid];
     if (sres[0]) { // systematic resampling by bisection on the monotone CDF (clamped; :1082-1090)
         const float u1 = (float)((1.0 / np) * (double)((float)T.rng[(it == 0) ? 1 : np] / (float)2147483647));
@@ -653,6 +682,14 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
         float *dst = O.xfilt + ((i64)tr * O.dbg_iters + it) * np * PSTRIDE;
         for (int e = tid; e < np * PSTRIDE; e += B) dst[e] = cur[e];
     }
+#ifdef PNR_SMC_STAMPS
+    if (tid == 0) {
+        const unsigned long long ut7 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_pu_stamps[8], ut1 - ut0); atomicAdd(&g_pu_stamps[9], ut2 - ut1); atomicAdd(&g_pu_stamps[10], ut3 - ut2);
+        atomicAdd(&g_pu_stamps[11], ut4 - ut3); atomicAdd(&g_pu_stamps[12], ut5 - ut4); atomicAdd(&g_pu_stamps[13], ut6 - ut5);
+        atomicAdd(&g_pu_stamps[14], ut7 - ut6); atomicAdd(&g_pu_stamps[15], 1ull);
+    }
+#endif
 }
 
 // streaming mode: hand `m` free slots to new traces and append them to the list of this step (one work-group, runs
@@ -756,6 +793,13 @@ static void phased_free(pnr_phased *h)
 }
 
 #ifdef PNR_SMC_STAMPS
+extern "C" int pnr_debug_pu_stamps(unsigned long long *out16, int reset)
+{
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pu_stamps), 128) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pu_stamps), z, 128) != hipSuccess) return -1; }
+    return 0;
+}
+
 extern "C" int pnr_debug_ph_stamps(unsigned long long *out8, int reset)
 {
     if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ph_stamps), 64) != hipSuccess) return -1;

@@ -8,7 +8,8 @@ from pnr_amd import lib
 pytestmark = pytest.mark.gpu
 
 
-def test_options_roundtrip_and_errors():
+def test_options_roundtrip_and_errors(monkeypatch):
+    monkeypatch.setitem(lib.DEFAULTS, "options", {})  # (this test is about the library's own defaults: no PNR_TEST_OPTIONS here)
     c = pnr_amd.Context(pnr_amd.make_params(sigmas=[2.0], np_=20, ni=5), 0)
     assert c.get_option("groups") == 0 and c.get_option("window") == 0 and c.get_option("look_pct") == -1
     c.set_option("window", 64)
