@@ -269,11 +269,11 @@ int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
 
 /* Scheduling and host-side knobs of a context; none of them changes a result (the library reads no environment variable).
  *   window (0 = automatic: 1536 on one GPU, 768 sharded or without the tentative replay) trace slots kept busy | look0, look_pct (0 / -1 = automatic) admission lookahead max(look0, frontier*look_pct/100)
- *   target (-1 = automatic: 200 on one GPU, 128 per rank sharded, 0 = off without the tentative replay) seeds are admitted only while fewer traces than this are running |
+ *   target (-1 = automatic: 120 on one GPU, 96 per rank sharded, 0 = off without the tentative replay) seeds are admitted only while fewer traces than this are running |
  *   lag (-1 = automatic: half a poll when no other trace group covers the host's share of a poll, else one step) steps of a poll that run on while the host works on the state in front of them |
  *   overfill (1) the target is the mean over a poll | concentrate (1) with several trace groups new seeds go to one group while few traces survive a poll |
  *   sums_deep (-1 = automatic: launches of at most sums_deep_max (96) traces, or one trace group; 0 / 1) form of the ordered sums (four chunk buffers in turn) |
- *   poll (4) SMC steps between polls | groups (0 = automatic: 2 on one GPU, 1 sharded; 1..4) trace groups on separate streams | split_x10 (0 = automatic), max_split (96) sampling
+ *   poll (3) SMC steps between polls | groups (0 = automatic: 2 on one GPU, 1 sharded; 1..4) trace groups on separate streams | split_x10 (0 = automatic), max_split (96) sampling
  *   work-groups per CU x 10 / per trace | stash_mb (65536) sample-stash budget | host_threads (0 = CPUs of this process /
  *   local_ranks) workers of the seed flood fill and of pnr_reconstruct_ctx | local_ranks (1) processes sharing this host |
  *   trace_timing, seed_timing (0/1) statistics on stderr | trace_log (0/1) keep every trace's end for pnr_get_trace_log | replay_batches (0/1), batch_growth, batch_max: rank batches instead

@@ -59,13 +59,13 @@ int gaussian_taps(float sig, std::vector<float> &g); // returns radius L
 struct Options {
     int window = 0;           // trace slots the streaming tracer keeps busy (0: automatic -- 1536 on one GPU with the tentative replay, 768 otherwise)
     int look0 = 0, look_pct = -1; // admission lookahead max(look0, frontier * look_pct / 100); 0 / -1 = automatic (stream_sched.h)
-    int target = -1;          // running traces the admission keeps up (0: off, -1: automatic -- 200 on one GPU with the tentative replay)
+    int target = -1;          // running traces the admission keeps up (0: off, -1: automatic -- 120 on one GPU with the tentative replay)
     int sums_deep = -1;       // form of the ordered sums: -1 automatic (smc_phased.hip sums_deep()), 0 two buffers folded, 1 four buffers in turn
     int sums_deep_max = 96;   // ... automatic with several trace groups: the four-buffer form for launches of at most this many traces (round 4: 64 -> 96, -1 % on both bench workloads)
     int lag = -1;             // steps of a poll that run while the host works on the state in front of them (-1 automatic: stream_sched.h)
     int concentrate = 1;      // several trace groups: new seeds go to group 0 only while few traces survive a poll (experiment switch)
     int overfill = 1;         // the target is the mean over a poll, not the count at its start (experiment switch)
-    int poll = 4;             // SMC steps between two polls
+    int poll = 3;             // SMC steps between two polls (round 4: 4 -> 3 together with target 200 -> 120)
     int groups = 0;           // trace groups on separate streams (0: automatic -- 2 on one GPU: one group's ordered sums overlap the other's sampling;
                               // 1 sharded: every poll is then an exchange, and small launches gain nothing from sharing the CUs)
     int split_x10 = 0;        // sampling work-groups per CU x 10 and launch; 0 = automatic (40 with one trace group, 22 with several)

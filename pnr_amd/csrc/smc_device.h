@@ -198,6 +198,41 @@ __device__ __forceinline__ int cdf_search(const float *__restrict__ cws, int n, 
     return lo;
 }
 
+// The same index as cdf_search (the array is a running sum of non-negative terms: monotone, so "first s with !(u > cws[s])" does
+// not depend on the order of the probes), found with seven probes in flight per round instead of one: 2 + 1 memory latencies for
+// the 256 prediction offsets instead of 8.
+__device__ __forceinline__ int cdf_search_wide(const float *__restrict__ cws, int n, float u)
+{
+    int lo = 0, hi = n - 1; // invariant: answer in [lo, hi]
+    while (hi - lo > 8) {
+        const int w = hi - lo;
+        int pos[7];
+        float c[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++) pos[j] = lo + ((w * (j + 1)) >> 3); // lo < pos[0] < ... < pos[6] < hi (w > 8)
+#pragma unroll
+        for (int j = 0; j < 7; j++) c[j] = cws[pos[j]];
+        int nlo = lo, nhi = hi;
+        bool found = false;
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            if (!found) {
+                if (!(u > c[j])) { nhi = pos[j]; found = true; }
+                else nlo = pos[j] + 1;
+            }
+        lo = nlo;
+        hi = nhi;
+    }
+    float c[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) c[j] = cws[lo + j < hi ? lo + j : hi];
+    int ans = hi;
+#pragma unroll
+    for (int j = 7; j >= 0; j--)
+        if (lo + j < hi && !(u > c[j])) ans = lo + j;
+    return ans;
+}
+
 // The u8 neighbourhood of the current particle cloud, staged in LDS once per SMC iteration: a
 // CS^3 byte cube (CS compile-time: corner offsets become immediates) centred on the bounding box of
 // every particle's template.  The union of 200 differently oriented 13x37x37 templates does not fit

@@ -56,9 +56,19 @@ struct PhState {
 
 __device__ __forceinline__ unsigned int pose_hash(float x, float y, float z, float vx, float vy, float vz)
 {
-    auto rotl = [](unsigned int v, int r) { return (v << r) | (v >> (32 - r)); };
-    return __float_as_uint(x) ^ rotl(__float_as_uint(y), 5) ^ rotl(__float_as_uint(z), 11) ^ rotl(__float_as_uint(vx), 17) ^ rotl(__float_as_uint(vy), 23) ^
-           rotl(__float_as_uint(vz), 29);
+    // multiply-and-fold over the six words (poses of one trace differ by small lattice offsets and share directions: an XOR of
+    // rotated words put 1.2 % of the particles behind a hash leader with another pose -- each of them a scan over everything in
+    // front of it)
+    unsigned int h = 0x811c9dc5u;
+    const unsigned int w[6] = {__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), __float_as_uint(vx), __float_as_uint(vy), __float_as_uint(vz)};
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        h = (h ^ w[i]) * 0x9e3779b1u;
+        h ^= h >> 15;
+    }
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    return h;
 }
 
 // chains of a trace in this iteration: FL_NCH = unique particles + the centroid (1 in the tail pass); they are laid out as
@@ -69,13 +79,14 @@ __device__ __forceinline__ int last_group_stride(int rem) { return rem > 32 ? 64
 #ifdef PNR_SMC_STAMPS
 // diagnostic build only: shader-clock sums over the phases of ph_predict ([0..6], [7] = work-groups) and ph_update ([8..14], [15])
 __device__ unsigned long long g_pu_stamps[16];
+__device__ unsigned long long g_pu_fine[8]; // ph_predict, thread 0: [0] until the parent pose is there, [1] direction loop, [2] CDF search, [3] count [4] particles whose hash leader has another pose (fall-back scans), [5] particles looked up (racy adds: a diagnostic)
 #define PU_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
 #define PU_STAMP(var)
 #endif
 
 __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, const float *__restrict__ seeds6, Vol V, int np, int ni, int it_arg,
-                                                   int lp, int CS)
+                                                   int lp, int CS, int tbl)
 {
     const int tid = threadIdx.x, B = blockDim.x;
     PU_STAMP(pt0);
@@ -86,7 +97,8 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     if (fl[FL_PAUSE]) return; // paused by the scheduler (stream_sched.h, tentative replay): not stepped, state kept
     const int it = it_arg >= 0 ? it_arg : fl[FL_IT]; // streaming mode: every trace has its own iteration count
     __shared__ int sbox[8];
-    extern __shared__ unsigned int dsm[]; // [np] pose hash, [np] representative (the duplicate search at the end)
+    __shared__ float s_v[3 * 64]; // the ndir (50 / 30) unit directions of the predictor: read np x ndir times
+    extern __shared__ unsigned int dsm[]; // [np] pose hash, [np] representative, [6 np] pose words, [tbl] + [tbl] table (the duplicate search)
     const bool tail = (it == ni) || (fl[FL_STOP] != 0);
     const int pending = it - 1; // the previous iteration's centroid is evaluated with this iteration's chains
     float *part = P.part + (i64)tr * 2 * np * PSTRIDE;
@@ -100,6 +112,15 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     const float x0 = sd[0], y0 = sd[1], z0 = sd[2], vx0 = sd[3], vy0 = sd[4], vz0 = sd[5];
     if (tid < 3) { sbox[tid] = 0x7fffffff; sbox[3 + tid] = -0x7fffffff; }
     if (tid == 3) { P.ctr[tr] = 0; sbox[6] = 0; }
+    if (tid < 3 * T.ndir && tid < 3 * 64) s_v[tid] = T.v[tid];
+    unsigned int *spose = dsm + 2 * np;
+    // first-occurrence table of the duplicate search: hash -> smallest particle index with that hash (open addressing, tbl slots)
+    unsigned int *tkey = spose + 6 * np;
+    int *tval = (int *)(tkey + tbl);
+    if (P.dedup)
+        for (int i = tid; i < tbl; i += B) { tkey[i] = 0xffffffffu; tval[i] = 0x7fffffff; }
+    int bmin[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, bmax[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff}; // this thread's share of the box
+    bool badpose = false;
     __syncthreads();
     PU_STAMP(pt1);
     for (int k = tid; k <= np; k += B) {
@@ -114,7 +135,7 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
                 const float stepw = T.w0cws[T.sz - 1] / np;
                 const float u1 = stepw * ((float)T.rng[0] / (float)2147483647);
                 const float ui = u1 + k * stepw;
-                const int s = cdf_search(T.w0cws, T.sz, ui);
+                const int s = cdf_search_wide(T.w0cws, T.sz, ui);
                 q[PX] = x0 + T.p[3 * s + 0];
                 q[PY] = y0 + T.p[3 * s + 1];
                 q[PZ] = z0 + T.p[3 * s + 2];
@@ -127,14 +148,28 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
                 const float *par = prv + k1 * PSTRIDE;
                 int vi = -1;
                 float best = -FLT_MAX;
+#ifdef PNR_SMC_STAMPS
+                if (tid == 0) { const float keep = par[PVX]; asm volatile("" ::"v"(keep)); g_pu_fine[0] += __builtin_amdgcn_s_memtime() - pt1; }
+                const unsigned long long fa = __builtin_amdgcn_s_memtime();
+#endif
+                const float pvx = par[PVX], pvy = par[PVY], pvz = par[PVZ];
+#pragma unroll 10
                 for (int a = 0; a < T.ndir; a++) {
-                    const float dp = par[PVX] * T.v[3 * a] + par[PVY] * T.v[3 * a + 1] + par[PVZ] * T.v[3 * a + 2];
+                    const float dp = pvx * s_v[3 * a] + pvy * s_v[3 * a + 1] + pvz * s_v[3 * a + 2];
                     if (dp > best) { best = dp; vi = a; }
                 }
                 if (vi < 0) vi = 0;
+#ifdef PNR_SMC_STAMPS
+                asm volatile("" ::"v"(vi));
+                const unsigned long long fb = __builtin_amdgcn_s_memtime();
+#endif
                 const float *cws = T.wcws + (i64)vi * T.sz;
                 const float u1 = cws[T.sz - 1] * ((float)T.rng[k] / (float)2147483647);
-                const int s = cdf_search(cws, T.sz, u1);
+                const int s = cdf_search_wide(cws, T.sz, u1);
+#ifdef PNR_SMC_STAMPS
+                asm volatile("" ::"v"(s));
+                if (tid == 0) { const unsigned long long fc = __builtin_amdgcn_s_memtime(); g_pu_fine[1] += fb - fa; g_pu_fine[2] += fc - fb; g_pu_fine[3] += 1; }
+#endif
                 q[PX] = par[PX] + T.p[3 * s + 0];
                 q[PY] = par[PY] + T.p[3 * s + 1];
                 q[PZ] = par[PZ] + T.p[3 * s + 2];
@@ -144,7 +179,21 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
                 prior[k] = T.w[(i64)vi * T.sz + s];
             }
             qx = q[PX]; qy = q[PY]; qz = q[PZ]; qvx = q[PVX]; qvy = q[PVY]; qvz = q[PVZ];
-            dsm[k] = pose_hash(qx, qy, qz, qvx, qvy, qvz);
+            {
+                unsigned int h = pose_hash(qx, qy, qz, qvx, qvy, qvz);
+                if (h == 0xffffffffu) h = 0xfffffffeu; // (the table's "empty")
+                if (P.dedup) dsm[k] = h;
+                if (P.dedup) {
+                    for (unsigned int slot = h & (tbl - 1);; slot = (slot + 1) & (tbl - 1)) { // tbl >= 2 np: an empty slot exists
+                        const unsigned int old = atomicCAS(&tkey[slot], 0xffffffffu, h);
+                        if (old == 0xffffffffu || old == h) { atomicMin(&tval[slot], k); break; }
+                    }
+                }
+            }
+            if (P.dedup) { // (without the search the kernel is launched without room for the poses and the table)
+                spose[6 * k + 0] = __float_as_uint(qx); spose[6 * k + 1] = __float_as_uint(qy); spose[6 * k + 2] = __float_as_uint(qz);
+                spose[6 * k + 3] = __float_as_uint(qvx); spose[6 * k + 4] = __float_as_uint(qvy); spose[6 * k + 5] = __float_as_uint(qvz);
+            }
         }
         const Frame f = make_frame(qx, qy, qz, qvx, qvy, qvz);
         const float ex = X.ext_v * fabsf(qvx) + X.ext_uw * (fabsf(f.ux) + fabsf(f.wx)) + 1.5f;
@@ -152,16 +201,31 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
         const float ez = X.ext_v * fabsf(qvz) + X.ext_uw * (fabsf(f.uz) + fabsf(f.wz)) + 1.5f;
         if (qx == qx && qy == qy && qz == qz && ex == ex && ey == ey && ez == ez) {
             const float big = 1e6f;
-            atomicMin(&sbox[0], (int)floorf(fmaxf(qx - ex, -big)));
-            atomicMin(&sbox[1], (int)floorf(fmaxf(qy - ey, -big)));
-            atomicMin(&sbox[2], (int)floorf(fmaxf(qz - ez, -big)));
-            atomicMax(&sbox[3], (int)floorf(fminf(qx + ex, big)) + 2);
-            atomicMax(&sbox[4], (int)floorf(fminf(qy + ey, big)) + 2);
-            atomicMax(&sbox[5], (int)floorf(fminf(qz + ez, big)) + 2);
+            bmin[0] = min(bmin[0], (int)floorf(fmaxf(qx - ex, -big)));
+            bmin[1] = min(bmin[1], (int)floorf(fmaxf(qy - ey, -big)));
+            bmin[2] = min(bmin[2], (int)floorf(fmaxf(qz - ez, -big)));
+            bmax[0] = max(bmax[0], (int)floorf(fminf(qx + ex, big)) + 2);
+            bmax[1] = max(bmax[1], (int)floorf(fminf(qy + ey, big)) + 2);
+            bmax[2] = max(bmax[2], (int)floorf(fminf(qz + ez, big)) + 2);
         } else {
-            sbox[6] = 1; // NaN / inf pose: its clamped samples may land anywhere in the cube
+            badpose = true; // NaN / inf pose: its clamped samples may land anywhere in the cube
         }
     }
+    // the box of the wave first (six values through the lanes), then one LDS atomic each: 200 atomics on one address are served
+    // one lane after the other
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            bmin[a] = min(bmin[a], __shfl_xor(bmin[a], o));
+            bmax[a] = max(bmax[a], __shfl_xor(bmax[a], o));
+        }
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { atomicMin(&sbox[a], bmin[a]); atomicMax(&sbox[3 + a], bmax[a]); }
+    }
+    if (badpose) sbox[6] = 1;
     __syncthreads();
     PU_STAMP(pt2);
     if (tid == 0) { // cube origin: centred on the bounding box of all templates, kept inside the volume
@@ -234,22 +298,35 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
     }
     unsigned int *hs = dsm; // filled where the particles were made; later the chain number of a representative
     int *rep = (int *)(dsm + np);
-    const unsigned int *curw = (const unsigned int *)cur;
+    constexpr int PSTRIDE6 = 6; // (the six pose words of a particle, kept in LDS where the particles were made)
+    const unsigned int *curw = spose;
     for (int k = tid; k < np; k += B) {
         int r = k;
         if (P.dedup) {
+            // the earliest particle with this hash, from the table; an identical pose has an identical hash, so if that particle is
+            // k itself nobody in front of k has k's pose.  Otherwise compare the poses; if they differ (two poses, one hash: about
+            // np^2 / 2^33 of the steps) fall back to the scan over everything in front of k.
             const unsigned int hk = hs[k];
-            const unsigned int *qk = curw + k * PSTRIDE;
-            for (int j0 = 0; j0 < k && r == k; j0 += 8) { // eight hashes per round: independent LDS reads
-                unsigned int hv[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) hv[u] = hs[j0 + u < np ? j0 + u : 0];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int j = j0 + u;
-                    if (r != k || j >= k || hv[u] != hk) continue; // (the pose itself is compared only when the hashes match)
-                    const unsigned int *qj = curw + j * PSTRIDE;
-                    if (qj[PX] == qk[PX] && qj[PY] == qk[PY] && qj[PZ] == qk[PZ] && qj[PVX] == qk[PVX] && qj[PVY] == qk[PVY] && qj[PVZ] == qk[PVZ]) r = j;
+            const unsigned int *qk = curw + k * PSTRIDE6;
+            int r0 = k;
+#ifdef PNR_SMC_STAMPS
+            if (tid == 0) atomicAdd(&g_pu_fine[5], (unsigned long long)np);
+#endif
+            for (unsigned int slot = hk & (tbl - 1);; slot = (slot + 1) & (tbl - 1))
+                if (tkey[slot] == hk) { r0 = tval[slot]; break; }
+            if (r0 < k) {
+                const unsigned int *q0 = curw + r0 * PSTRIDE6;
+                if (q0[PX] == qk[PX] && q0[PY] == qk[PY] && q0[PZ] == qk[PZ] && q0[PVX] == qk[PVX] && q0[PVY] == qk[PVY] && q0[PVZ] == qk[PVZ]) {
+                    r = r0;
+                } else {
+#ifdef PNR_SMC_STAMPS
+                    atomicAdd(&g_pu_fine[4], 1ull);
+#endif
+                    for (int j = 0; j < k && r == k; j++) {
+                        if (hs[j] != hk) continue;
+                        const unsigned int *qj = curw + j * PSTRIDE6;
+                        if (qj[PX] == qk[PX] && qj[PY] == qk[PY] && qj[PZ] == qk[PZ] && qj[PVX] == qk[PVX] && qj[PVY] == qk[PVY] && qj[PVZ] == qk[PVZ]) r = j;
+                    }
                 }
             }
         }
@@ -510,6 +587,24 @@ __global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, 
 #endif
 }
 
+// a[0] + a[1] + ... in this order (one f32 add after the other, as the reference's loops), read from LDS eight terms at a time so
+// that the chain of adds does not wait for one load after the other.  Every thread that calls it gets the sum: the address is
+// the same in all lanes (a broadcast read), so a value that all threads need is simply added up by all of them.
+__device__ __forceinline__ float lds_seq_sum(const float *a, int n)
+{
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) t[j] = a[k + j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += t[j];
+    }
+    for (; k < n; k++) s += a[k];
+    return s;
+}
+
 __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np, int np_pad, int ni, int it_arg, int lp, float Kc, float znccth,
                                                   float neff_ratio, const unsigned char *__restrict__ den, int nodepervol, TraceOut O)
 {
@@ -589,50 +684,77 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
 
     PU_STAMP(ut3);
     // ---- weights, N_eff, CDF, centroid: sequential sums in particle order (:1035-1071) ----
+    // The sums run in the reference's order, one add after the other.  What all threads need (the two normalisations) every
+    // thread adds up for itself from contiguous LDS arrays (broadcast reads, eight terms in flight): nothing is handed over and
+    // waited for.  The nine chains of the last step run side by side: the seven centroid sums in seven lanes of wave 0, N_eff in
+    // wave 1, the CDF in wave 2 (in one wave they would run one after the other).
     const bool carry = (it > 0) && !resampled_prev;
-    if (tid == 0) {
-        float a = 0.f;
-        for (int k = 0; k < np; k++) a += prior[k];
-        sneff[1] = a;
-    }
-    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
     {
-        const float wnorm_prior = sneff[1];
+        const float wnorm_prior = lds_seq_sum(prior, np);
         for (int k = tid; k < np; k += B) {
             const double base = carry ? (double)prvw[k] : (1.0 / np);
-            cur[k * PSTRIDE + PW] = (float)(base * (double)(prior[k] / wnorm_prior) * (double)lhood[k]);
+            const float w = (float)(base * (double)(prior[k] / wnorm_prior) * (double)lhood[k]);
+            cur[k * PSTRIDE + PW] = w;
+            lhood[k] = w; // from here on: the unnormalised weights, contiguous
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        float a = 0.f;
-        for (int k = 0; k < np; k++) a += cur[k * PSTRIDE + PW];
-        sneff[1] = a;
-    }
-    __syncthreads();
     {
-        const float wsum = sneff[1];
-        for (int k = tid; k < np; k += B) cur[k * PSTRIDE + PW] = cur[k * PSTRIDE + PW] / wsum;
+        const float wsum = lds_seq_sum(lhood, np);
+        for (int k = tid; k < np; k += B) {
+            const float wn = lhood[k] / wsum;
+            cur[k * PSTRIDE + PW] = wn;
+            prvw[k] = wn; // from here on: the normalised weights, contiguous (nobody reads prvw or writes lhood any more)
+        }
     }
     __syncthreads();
     PU_STAMP(ut4);
-    if (tid < 7) {
-        const int comp = (tid < 6) ? tid : PSIG;
-        float a = 0.f;
-        for (int k = 0; k < np; k++) a += cur[k * PSTRIDE + PW] * cur[k * PSTRIDE + comp];
-        sxc[tid] = a;
-    } else if (tid == 7) {
-        float neff = 0.f;
-        for (int k = 0; k < np; k++) {
-            const float wk = cur[k * PSTRIDE + PW];
-            neff = (float)((double)neff + (double)wk * (double)wk);
+    const float *wn = prvw;
+    if (wv == 0) {
+        if (lane < 7) {
+            const int comp = (lane < 6) ? lane : PSIG;
+            float a = 0.f;
+            int k = 0;
+            for (; k + 8 <= np; k += 8) {
+                float w8[8], c8[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { w8[j] = wn[k + j]; c8[j] = cur[(k + j) * PSTRIDE + comp]; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) a += w8[j] * c8[j];
+            }
+            for (; k < np; k++) a += wn[k] * cur[k * PSTRIDE + comp];
+            sxc[lane] = a;
         }
-        sneff[0] = (float)(1.0 / (double)neff);
-    } else if (tid == 8) {
-        float acc = 0.f;
-        for (int k = 0; k < np; k++) {
-            acc = cur[k * PSTRIDE + PW] + ((k > 0) ? acc : 0.f);
-            csw[k] = acc;
+    } else if (wv == 1) {
+        if (lane == 0) { // N_eff: f64 add of the f64 square, rounded to f32 at every step
+            float neff = 0.f;
+            int k = 0;
+            for (; k + 8 <= np; k += 8) {
+                float w8[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) w8[j] = wn[k + j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) neff = (float)((double)neff + (double)w8[j] * (double)w8[j]);
+            }
+            for (; k < np; k++) {
+                const float wk = wn[k];
+                neff = (float)((double)neff + (double)wk * (double)wk);
+            }
+            sneff[0] = (float)(1.0 / (double)neff);
+        }
+    } else if (wv == 2) {
+        if (lane == 0) { // CDF (:1062: the first term is added to 0.f, as there)
+            float acc = 0.f;
+            int k = 0;
+            for (; k + 8 <= np; k += 8) {
+                float w8[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) w8[j] = wn[k + j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { acc = w8[j] + acc; csw[k + j] = acc; }
+            }
+            for (; k < np; k++) { acc = wn[k] + acc; csw[k] = acc; }
         }
     }
     __syncthreads();
@@ -793,6 +915,13 @@ static void phased_free(pnr_phased *h)
 }
 
 #ifdef PNR_SMC_STAMPS
+extern "C" int pnr_debug_pu_fine(unsigned long long *out4, int reset)
+{
+    if (out4 && hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_pu_fine), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_pu_fine), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+
 extern "C" int pnr_debug_pu_stamps(unsigned long long *out16, int reset)
 {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pu_stamps), 128) != hipSuccess) return -1;
@@ -849,6 +978,17 @@ static bool sums_deep(const pnr_ctx *c, int active, int ngroups)
     if (c->opt.sums_deep >= 0) return c->opt.sums_deep != 0;
     return ngroups <= 1 || active <= c->opt.sums_deep_max;
 }
+
+// slots of ph_predict's first-occurrence table: a power of two >= 2 np (its LDS: hashes, representatives, poses, the table)
+static int ph_tbl(int np)
+{
+    int t = 64;
+    while (t < 2 * np) t <<= 1;
+    return t;
+}
+
+// dynamic LDS of ph_predict: representatives (+ hashes, poses and the table when it searches for duplicates)
+static size_t ph_predict_lds(int np, int dedup) { return dedup ? (size_t)(np * 8 + 2 * ph_tbl(np)) * 4 : (size_t)np * 8; }
 
 static int pick_nsplit(int active, int ncu, int max_split, int x10 /* work-groups per CU x 10 */)
 {
@@ -944,7 +1084,7 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     E.P.cap = (int)h->cap_traces;
     E.P.W = W;
     E.P.np_pad = np_pad;
-    E.P.dedup = np <= 1024 ? 1 : 0; // the duplicate search is quadratic in np
+    E.P.dedup = np <= 1024 ? 1 : 0; // (beyond that the poses and the table of the duplicate search no longer fit 64 KB of LDS)
     E.X.grid = (const Grid *)c->d_grid; E.X.axes = c->d_axes; E.X.axes_off = c->d_axes_off; E.X.wd = c->d_wd;
     E.X.ext_v = c->tab.ext_v; E.X.ext_uw = c->tab.ext_uw;
     for (int s2 = 0; s2 < 8; s2++) { E.X.ext_vs[s2] = s2 < S ? c->tab.ext_vs[s2] : 0.f; E.X.ext_uws[s2] = s2 < S ? c->tab.ext_uws[s2] : 0.f; }
@@ -1022,7 +1162,7 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
             }
             const int nsplit = pick_nsplit(active, ncu, max_split, c->opt.split_x10);
             c->tic(st);
-            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, T, X, P, (const float *)h->d_s6, V, np, ni, it, it & 1, CS);
+            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), ph_predict_lds(np, P.dedup), st, T, X, P, (const float *)h->d_s6, V, np, ni, it, it & 1, CS, ph_tbl(np));
             c->toc("smc_predict", 1, st);
             c->tic(st);
             if (V.l == 1)
@@ -1179,7 +1319,7 @@ struct PhasedEngine final : pnr::StreamEngine {
             const int lp = q.lp;
             const int nsplit = pick_nsplit(active, E.ncu, E.max_split, x10);
             c->tic(st, k > 0); // (the first step of a poll follows the admission copies: its own opening event)
-            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), (size_t)np * 8, st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS);
+            hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), ph_predict_lds(np, P.dedup), st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS, ph_tbl(np));
             c->toc("smc_predict", 1, st);
             c->tic(st, true);
             if (E.V.l == 1)

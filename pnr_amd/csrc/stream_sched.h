@@ -48,10 +48,11 @@ struct SchedOptions {
                        // binds), max(128, 64 * world) / min(400, 50 * world) otherwise (scripts/sim_sharded.py)
     int target = -1;   // > 0: seeds are admitted only while fewer than this many traces are RUNNING on this rank (all groups; paused ones do
                        // not count): late seeds live a few iterations, early ones dozens, so a constant number of running traces wastes
-                       // fewer iterations per step than a rank window (scripts/sim_tentative.py).  0: off.  -1: automatic -- 200 on one GPU
-                       // with the tentative replay (measured 160 / 200 / 240 / 320: 1130 / 1131 / 1131 / 1168 ms against 1172 ms without; flat in
-                       // the polling period, 4 ... 8 steps), 128 per rank sharded (emulated ranks, one trace group: 4 ranks 507 -> 499 ms, 8 ranks
-                       // 367 -> 353 ms), off without the tentative replay
+                       // fewer iterations per step than a rank window (scripts/sim_tentative.py).  0: off.  -1: automatic -- 120 on one GPU
+                       // with the tentative replay and poll = 3 (round 3 measured 160 / 200 / 240 / 320: 1130 / 1131 / 1131 / 1168 ms and took 200;
+                       // with ph_predict / ph_update at a third of their time smaller launches cost less -- round 4, bench step: target
+                       // 100 / 110 / 120 / 130 / 140 / 160 / 200 at poll 3: 917 / 898 / 890 / 899 / 905 / 918 / 941 ms), 96 per rank sharded
+                       // (emulated ranks: 2 / 4 / 8 ranks 654 / 408 / 291 ms at 128, 652 / 401 / 277 ms at 96), off without the tentative replay
     int overfill = 1;  // ... counted as the mean over a poll (see the admission)
     int lag = -1;      // steps of a poll that run while the host works on the state in front of them (see StreamEngine::launch): hides the host's
                        // share of a poll (tentative pass, exchange) where no other trace group covers it, at the price of `lag` more
@@ -208,7 +209,7 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     const int world = std::max(1, sh.world), rank = sh.rank;
     if (world > 1 && !sh.exchange) { err = "sharded tracing needs an exchange callback"; return PNR_E_ARG; }
     if (rank < 0 || rank >= world) { err = "rank out of range"; return PNR_E_ARG; }
-    if (o.target < 0) o.target = o.tentative ? (world == 1 ? 200 : 128) : 0;
+    if (o.target < 0) o.target = o.tentative ? (world == 1 ? 120 : 96) : 0; // (200 until ph_predict / ph_update took a third of their time: smaller launches cost less now)
     if (o.look0 <= 0) o.look0 = (world == 1 && o.tentative) ? (o.target > 0 ? 512 : 256) : std::max(128, 64 * world);
     if (o.look_pct < 0) o.look_pct = (world == 1 && o.tentative) ? (o.target > 0 ? 200 : 100) : std::min(400, 50 * world);
     o.poll = std::max(1, o.poll);

@@ -224,6 +224,7 @@ void build_tables(const pnr_params &P, bool is2d, Tables &t)
     t.nsig = P.nsig;
     t.is2d = is2d;
     t.ndir = is2d ? 30 : 50; // Tracker::ndirs2d / ndirs3d (tracker.cpp:27-28)
+    static_assert(50 <= 64 && 30 <= 64, "ph_predict keeps the directions in an LDS array of 64");
     build_templates(P, is2d, t);
     build_prediction(P, is2d, t);
     build_directions(is2d, t);

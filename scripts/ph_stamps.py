@@ -18,12 +18,18 @@ st = (C.c_ulonglong * 8)()
 L.pnr_debug_ph_stamps(st, 1)
 pu = (C.c_ulonglong * 16)()
 L.pnr_debug_pu_stamps(pu, 1)
+fine = (C.c_ulonglong * 8)()
+L.pnr_debug_pu_fine(fine, 1)
 c.trace_replay(s)
 L.pnr_debug_ph_stamps(st, 0)
 L.pnr_debug_pu_stamps(pu, 0)
+L.pnr_debug_pu_fine(fine, 0)
 stage, items, wgs, nit = st[0], st[1], st[2], st[3]
 print(f"ph_sums, full groups of the longest template: pass 1 {st[5] / max(st[7], 1):.0f} cycles, pass 2 {st[6] / max(st[7], 1):.0f} cycles per wave ({st[7]} waves; s_memtime ticks)")
 print(f"flags wait {st[4] / wgs:.0f} cycles; work-groups {wgs}, staging {stage / wgs:.0f} cycles per work-group, item loop of wave 0 {items / wgs:.0f} cycles ({nit / wgs:.2f} items), staging share {stage / (stage + items):.3f}")
 n1, n2 = max(pu[7], 1), max(pu[15], 1)
 print("ph_predict, cycles per work-group: init %d | particles + box %d | cube origin %d | per-sigma fit %d | duplicate search %d | chain numbers + map %d (%d work-groups)" % (pu[0] / n1, pu[1] / n1, pu[2] / n1, pu[3] / n1, pu[4] / n1, pu[5] / n1, pu[7]))
 print("ph_update, cycles per work-group: loads %d | pending centroid %d | (exit test) %d | likelihood %d | weights, two serial sums %d | N_eff / CDF / centroid %d | decisions %d | resampling + write-back %d (%d)" % (pu[8] / n2, pu[9] / n2, 0, pu[10] / n2, pu[11] / n2, pu[12] / n2, pu[13] / n2, pu[14] / n2, pu[15]))
+nf = max(fine[3], 1)
+print("ph_predict, thread 0 inside 'particles + box': parent pose there after %d cycles | direction loop %d | CDF search %d" % (fine[0] / nf, fine[1] / nf, fine[2] / nf))
+print("ph_predict duplicate search: %d of %d particles fell back to the scan" % (fine[4], fine[5]))
