@@ -220,6 +220,9 @@ def main():
     ctx = pnr_amd.Context(p, local)
     ctx.set_smc_driver(a.driver)
     ctx.set_option("local_ranks", local_world)  # the host threads of the seed flood fill are shared between the ranks of this node
+    # the event pairs around every SMC launch cost 1.2 % of the step (~9000 launches per stack): the streaming tracer times every 4th poll
+    # of a trace group and counts it fourfold (the per-launch averages are unbiased, the totals are estimates; PNR_BENCH_OPTS=profile_every=1: all)
+    ctx.set_option("profile_every", 4)
     opts = ctx.set_options(os.environ.get("PNR_BENCH_OPTS"))
     ctx.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
     ctx.set_profiling(not os.environ.get("PNR_BENCH_NOPROF"))  # NOPROF: how much do the HIP events of the kernel timers cost? (diagnostic; no roofline then)

@@ -852,7 +852,7 @@ const OptEntry OPTS[] = {
     {"exchange_block", nullptr, &pnr::Options::exchange_block, 0, 1 << 28}, {"frangi_prune", &pnr::Options::frangi_prune, nullptr, 0, 1},
     {"tentative", &pnr::Options::tentative, nullptr, 0, 1},      {"target", &pnr::Options::target, nullptr, -1, 1 << 20},
     {"sums_deep", &pnr::Options::sums_deep, nullptr, -1, 1},      {"sums_deep_max", &pnr::Options::sums_deep_max, nullptr, 0, 1 << 20},
-    {"lag", &pnr::Options::lag, nullptr, -1, 1023},
+    {"lag", &pnr::Options::lag, nullptr, -1, 1023},               {"profile_every", &pnr::Options::profile_every, nullptr, 1, 1024},
     {"overfill", &pnr::Options::overfill, nullptr, 0, 1},        {"concentrate", &pnr::Options::concentrate, nullptr, 0, 100},
 };
 } // namespace

@@ -74,6 +74,8 @@ struct Options {
     int host_threads = 0;     // host worker threads of the seed flood fill / reconstruct(); 0 = hardware threads / local_ranks
     int local_ranks = 1;      // processes that share this host (one per GPU)
     int trace_timing = 0, seed_timing = 0; // statistics on stderr
+    int profile_every = 1;    // with pnr_set_profiling: the streaming tracer times the kernels of every n-th poll of a trace group only and counts
+                              // them n-fold (the event pairs around ~9000 launches per stack are 1.2 % of the bench step; every 4th: 0.3 %)
     int trace_log = 0;        // keep how every replayed trace ended (pnr_get_trace_log)
     int replay_batches = 0;   // 1: seed-rank batches instead of the streaming window (always so with the persistent driver)
     int batch_growth = 200, batch_max = 1024;
@@ -179,6 +181,7 @@ struct pnr_ctx {
         hipEvent_t a, b;
         int launches;
         bool a_shared = false; // a is the b of the entry before (chained timers): not freed twice
+        int weight = 1;        // sampled timers (option "profile_every"): this measurement stands for `weight` launches like it
     };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> free_events;
@@ -237,13 +240,13 @@ struct pnr_ctx {
         cur_a_shared = false;
         (void)hipEventRecord(cur_a, s);
     }
-    void toc(const char *group, int launches = 1, hipStream_t on = nullptr)
+    void toc(const char *group, int launches = 1, hipStream_t on = nullptr, int weight = 1)
     {
         if (!profiling || !cur_a) return;
         hipStream_t s = on ? on : stream;
         hipEvent_t b = get_event();
         (void)hipEventRecord(b, s);
-        pending.push_back(Pending{group, cur_a, b, launches, cur_a_shared});
+        pending.push_back(Pending{group, cur_a, b, launches, cur_a_shared, weight});
         cur_a = nullptr;
         last_b = b;
         last_b_stream = s;
@@ -255,8 +258,8 @@ struct pnr_ctx {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, p.a, p.b);
             auto &t = timers[p.group];
-            t.ms += ms;
-            t.launches += p.launches;
+            t.ms += (double)ms * p.weight;
+            t.launches += (int64_t)p.launches * p.weight;
             if (!p.a_shared) free_events.push_back(p.a);
             free_events.push_back(p.b);
         }

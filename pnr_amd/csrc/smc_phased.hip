@@ -867,6 +867,76 @@ __global__ __launch_bounds__(256) void ph_control(PhState P, const int *__restri
     if (threadIdx.x == 0) P.cnt[lp] = base + nr;
 }
 
+// What a poll asks of a trace group, in ONE dispatch (each dispatch in front of the group's next step costs ~14 us of its chain, and
+// there were three): work-group 0 runs ph_control's and then ph_admit's work (same order, same code); the work-groups behind it
+// raise the density map (den_scatter's monotone byte-wise maximum).  The lists are read from pinned host staging by the kernel.
+__global__ __launch_bounds__(256) void ph_poll(PhState P, float *__restrict__ s6, int do_ctl, const int *__restrict__ pause, int np_,
+                                                const int *__restrict__ resume, int nr, const int *__restrict__ new_slots,
+                                                const float *__restrict__ new_s6, int m, int lp, int ni, unsigned char *__restrict__ den,
+                                                const i64 *__restrict__ didx, const unsigned char *__restrict__ dval, int nt)
+{
+    if (blockIdx.x > 0) {
+        const int i = ((int)blockIdx.x - 1) * (int)blockDim.x + (int)threadIdx.x;
+        if (i >= nt) return;
+        const i64 at = didx[i];
+        unsigned *w = (unsigned *)(den + (at & ~(i64)3)); // (the map is allocated in whole dwords)
+        const int sh = (int)(at & 3) * 8;
+        const unsigned v = dval[i];
+        unsigned old = __atomic_load_n(w, __ATOMIC_RELAXED);
+        while (((old >> sh) & 0xffu) < v) {
+            const unsigned got = atomicCAS(w, old, (old & ~(0xffu << sh)) | (v << sh));
+            if (got == old) break;
+            old = got;
+        }
+        return;
+    }
+    __shared__ int kept, cntv;
+    if (threadIdx.x == 0) { cntv = P.cnt[lp]; kept = 0; }
+    __syncthreads();
+    int *list = P.list + (size_t)lp * P.cap, *tmp = P.list + (size_t)(lp ^ 1) * P.cap; // (the other list is only filled by the next ph_update)
+    if (do_ctl) { // ---- ph_control
+        const int n = cntv;
+        for (int j = threadIdx.x; j < np_; j += blockDim.x) P.flags[(i64)pause[j] * FL_N + FL_PAUSE] = 1;
+        __syncthreads();
+        if (np_ > 0) {
+            for (int j = threadIdx.x; j < n; j += blockDim.x) {
+                const int tr = list[j];
+                if (!P.flags[(i64)tr * FL_N + FL_PAUSE]) tmp[atomicAdd(&kept, 1)] = tr;
+            }
+            __syncthreads();
+            for (int j = threadIdx.x; j < kept; j += blockDim.x) list[j] = tmp[j];
+            __syncthreads();
+        } else if (threadIdx.x == 0) {
+            kept = n;
+        }
+        __syncthreads();
+        const int base = kept;
+        for (int j = threadIdx.x; j < nr; j += blockDim.x) {
+            P.flags[(i64)resume[j] * FL_N + FL_PAUSE] = 0;
+            list[base + j] = resume[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) cntv = base + nr;
+        __syncthreads();
+    }
+    if (m > 0) { // ---- ph_admit
+        const int base = cntv;
+        for (int j = threadIdx.x; j < m; j += blockDim.x) {
+            const int slot = new_slots[j];
+            for (int a = 0; a < 6; a++) s6[(i64)slot * 6 + a] = new_s6[(i64)j * 6 + a];
+            int *fl = P.flags + (i64)slot * FL_N;
+            for (int a = 0; a < FL_N; a++) fl[a] = 0;
+            fl[FL_T] = ni;
+            for (int a = 0; a < 16; a++) P.xcs[(i64)slot * 16 + a] = 0.f;
+            list[base + j] = slot;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) cntv = base + m;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) P.cnt[lp] = cntv;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------
@@ -905,8 +975,8 @@ struct pnr_phased {
 
 static void phased_free(pnr_phased *h)
 {
-    hipFree(h->P.part); hipFree(h->P.prior); hipFree(h->P.idxres); hipFree(h->P.corr); hipFree(h->P.xcs); hipFree(h->P.flags);
-    hipFree(h->P.stash); hipFree(h->P.list); hipFree(h->P.cnt); hipFree(h->P.ctr); hipFree(h->P.uidx); hipFree(h->P.cmap); hipFree(h->d_s6);
+    hipFree(h->P.part); hipFree(h->P.prior); hipFree(h->P.idxres); hipFree(h->P.corr); hipFree(h->P.xcs);
+    hipFree(h->P.stash); hipFree(h->P.list); hipFree(h->P.cnt) /* (and the flags behind the counters) */; hipFree(h->P.ctr); hipFree(h->P.uidx); hipFree(h->P.cmap); hipFree(h->d_s6);
     hipFree(h->O.T); hipFree(h->O.stop); hipFree(h->O.xc); hipFree(h->O.xfilt); hipFree(h->O.idxres); hipFree(h->O.neff);
     h->P = PhState{};
     h->O = TraceOut{};
@@ -1058,10 +1128,11 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
         PNR_HIP(hipMalloc(&h->P.idxres, (size_t)cap * np * 4));
         PNR_HIP(hipMalloc(&h->P.corr, (size_t)cap * S * np_pad * 4));
         PNR_HIP(hipMalloc(&h->P.xcs, (size_t)cap * 16 * 4));
-        PNR_HIP(hipMalloc(&h->P.flags, (size_t)cap * FL_N * 4));
+        // the counters of the step lists sit in front of the flags in ONE buffer: the streaming tracer's poll copies both with one copy
+        PNR_HIP(hipMalloc(&h->P.cnt, ((size_t)cap * FL_N + 2 * pnr_phased::MAXG) * 4));
+        h->P.flags = h->P.cnt + 2 * pnr_phased::MAXG;
         PNR_HIP(hipMalloc(&h->P.stash, (size_t)cap * trace_floats * 4));
         PNR_HIP(hipMalloc(&h->P.list, (size_t)cap * 2 * 4 * pnr_phased::MAXG)); // one pair of lists per trace group of the streaming tracer
-        PNR_HIP(hipMalloc(&h->P.cnt, 2 * 4 * pnr_phased::MAXG));
         PNR_HIP(hipMalloc(&h->P.ctr, (size_t)cap * 4));
         PNR_HIP(hipMalloc(&h->P.uidx, (size_t)cap * np_pad * 4));
         PNR_HIP(hipMalloc(&h->P.cmap, (size_t)cap * np_pad * 4));
@@ -1219,7 +1290,10 @@ struct PhasedEngine final : pnr::StreamEngine {
     TraceOut O{};
     struct Grp {
         PhState P; hipStream_t st; int lp = 0;
-        int *h_flags, *h_cnt, *h_new, *d_new; float *h_new_s6, *d_new_s6;
+        int *h_snap, *h_flags, *h_cnt, *h_new, *d_new; float *h_new_s6, *d_new_s6;
+        // what this turn's control() / density_update() / admit() asked for: sent as one dispatch by flush()
+        bool p_ctl = false; int p_np = 0, p_nr = 0, p_m = 0; size_t p_nt = 0;
+        long long poll_no = 0;
         hipEvent_t ev_state = nullptr; // the copies of flags and count of the last launch have landed
         int running = 0; // traces of the group's last launch still running (0 once its poll has been collected empty)
     };
@@ -1260,7 +1334,7 @@ struct PhasedEngine final : pnr::StreamEngine {
             h->stream_cap = 0;
             PE_HIP(hipHostMalloc(&h->h_xc, (size_t)NT * ni * sizeof(pnr_xest)));
             constexpr int MG = pnr_phased::MAXG; // one set per trace group
-            PE_HIP(hipHostMalloc(&h->h_flags, (size_t)NT * FL_N * 4 * MG));
+            PE_HIP(hipHostMalloc(&h->h_flags, ((size_t)NT * FL_N + 2 * MG) * 4 * MG)); // per group: [2 MG counters | NT x FL_N flags]
             PE_HIP(hipHostMalloc(&h->h_new, (size_t)NT * 4 * MG));
             PE_HIP(hipHostMalloc(&h->h_new_s6, (size_t)NT * 24 * MG));
             PE_HIP(hipMalloc(&h->d_new, (size_t)NT * 4 * MG));
@@ -1284,7 +1358,8 @@ struct PhasedEngine final : pnr::StreamEngine {
             q.P.cnt = E.P.cnt + 2 * g;
             q.st = g == 0 ? c->stream : h->stg[g];
             q.ev_state = h->ev_state[g];
-            q.h_flags = h->h_flags + (size_t)g * h->stream_cap * FL_N; q.h_cnt = h->h_cnt + g;
+            q.h_snap = h->h_flags + (size_t)g * ((size_t)h->stream_cap * FL_N + 2 * pnr_phased::MAXG);
+            q.h_flags = q.h_snap + 2 * pnr_phased::MAXG; q.h_cnt = q.h_snap + 2 * g;
             q.h_new = h->h_new + (size_t)g * h->stream_cap; q.d_new = h->d_new + (size_t)g * h->stream_cap;
             q.h_new_s6 = h->h_new_s6 + (size_t)g * h->stream_cap * 6; q.d_new_s6 = h->d_new_s6 + (size_t)g * h->stream_cap * 6;
         }
@@ -1298,14 +1373,12 @@ struct PhasedEngine final : pnr::StreamEngine {
         PE_HIP(hipEventSynchronize(h->ev_adm[g]));      // pinned staging of this group: its previous admission has been consumed
         std::memcpy(q.h_new, slots, (size_t)m * 4);     // (normally long ago: a wait() lies between two admissions unless the group
         std::memcpy(q.h_new_s6, s6, (size_t)m * 24);    // had nothing to step)
-        PE_HIP(hipMemcpyAsync(q.d_new, q.h_new, (size_t)m * 4, hipMemcpyHostToDevice, q.st));
-        PE_HIP(hipMemcpyAsync(q.d_new_s6, q.h_new_s6, (size_t)m * 24, hipMemcpyHostToDevice, q.st));
-        hipLaunchKernelGGL(ph_admit, dim3(1), dim3(256), 0, q.st, q.P, h->d_s6, (const int *)q.d_new, (const float *)q.d_new_s6, m, q.lp, E.ni);
-        PE_HIP(hipEventRecord(h->ev_adm[g], q.st));
+        q.p_m = m; // (flush(): the kernel reads the pinned staging itself -- a few hundred bytes over the bus, no copies in front of it)
         return PNR_OK;
     }
     int launch(int g, int active, int poll, int lag) override
     {
+        { const int rc = flush(g); if (rc) return rc; }
         Grp &q = grp[g];
         hipStream_t st = q.st;
         const PhState &P = q.P;
@@ -1315,32 +1388,36 @@ struct PhasedEngine final : pnr::StreamEngine {
         int sharing = 1;
         for (int k = 0; k < ngroups; k++) sharing += (k != g && grp[k].running > 0) ? 1 : 0;
         const int x10 = c->opt.split_x10 > 0 ? c->opt.split_x10 : (sharing > 1 ? 22 : 40);
+        const int pw = std::max(1, c->opt.profile_every);
+        const bool prof = (q.poll_no++ % pw) == 0; // the kernel timers (pnr_set_profiling) look at every pw-th poll of the group
         for (int k = 0; k < poll; k++) { // `poll` SMC steps over the group's active list (every trace at its own iteration)
             const int lp = q.lp;
             const int nsplit = pick_nsplit(active, E.ncu, E.max_split, x10);
-            c->tic(st, k > 0); // (the first step of a poll follows the admission copies: its own opening event)
+            if (prof) c->tic(st, k > 0); // (the first step of a poll follows the admission copies: its own opening event)
             hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), ph_predict_lds(np, P.dedup), st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS, ph_tbl(np));
-            c->toc("smc_predict", 1, st);
-            c->tic(st, true);
+            if (prof) c->toc("smc_predict", 1, st, pw);
+            if (prof) c->tic(st, true);
             if (E.V.l == 1)
                 hipLaunchKernelGGL((ph_sample<PH_CS, true>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
             else
                 hipLaunchKernelGGL((ph_sample<PH_CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
-            c->toc("smc", 1, st);
-            c->tic(st, true);
+            if (prof) c->toc("smc", 1, st, pw);
+            if (prof) c->tic(st, true);
             if (sums_deep(c, active, sharing))
                 hipLaunchKernelGGL(ph_sums<true>, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp, ng);
             else
                 hipLaunchKernelGGL(ph_sums<false>, dim3((unsigned)(active * S * ng)), dim3(64), 0, st, E.T, E.X, P, np, np_pad, ni, -1, lp, ng);
-            c->toc("smc_sums", 1, st);
-            c->tic(st, true);
+            if (prof) c->toc("smc_sums", 1, st, pw);
+            if (prof) c->tic(st, true);
             hipLaunchKernelGGL(ph_update, dim3(active), dim3(256), E.upd_lds, st, E.V, E.T, P, np, np_pad, ni, -1, lp, c->prm.Kc, c->prm.znccth,
                                c->prm.neff_ratio, c->d_den, c->prm.nodepervol, O);
-            c->toc("smc_update", 1, st);
+            if (prof) c->toc("smc_update", 1, st, pw);
             q.lp ^= 1;
             if (k == poll - 1 - lag) { // what wait() hands to the host: the state behind this step (the last `lag` steps run on meanwhile)
-                PE_HIP(hipMemcpyAsync(q.h_flags, P.flags, (size_t)NT * FL_N * 4, hipMemcpyDeviceToHost, st));
-                PE_HIP(hipMemcpyAsync(q.h_cnt, P.cnt + q.lp, 4, hipMemcpyDeviceToHost, st));
+                // one copy: the counters of all step lists and the flags of all slots (every copy is a dispatch of its own in the stream,
+                // ~10 us each on the chain of this group's steps)
+                PE_HIP(hipMemcpyAsync(q.h_snap, E.P.cnt, ((size_t)NT * FL_N + 2 * pnr_phased::MAXG) * 4, hipMemcpyDeviceToHost, st));
+                q.h_cnt = q.h_snap + 2 * g + q.lp; // the list of the step that follows
                 PE_HIP(hipEventRecord(q.ev_state, st));
             }
         }
@@ -1374,14 +1451,30 @@ struct PhasedEngine final : pnr::StreamEngine {
         PE_HIP(hipEventSynchronize(h->ev_ctl[g]));                  // pinned staging of this group: its previous lists have been consumed
         if (np_ > 0) std::memcpy(hc, pause, (size_t)np_ * 4);
         if (nr > 0) std::memcpy(hc + h->stream_cap, resume, (size_t)nr * 4);
-        if (np_ > 0) PE_HIP(hipMemcpyAsync(dc, hc, (size_t)np_ * 4, hipMemcpyHostToDevice, q.st));
-        if (nr > 0) PE_HIP(hipMemcpyAsync(dc + h->stream_cap, hc + h->stream_cap, (size_t)nr * 4, hipMemcpyHostToDevice, q.st));
-        hipLaunchKernelGGL(ph_control, dim3(1), dim3(256), 0, q.st, q.P, (const int *)dc, np_, (const int *)(dc + h->stream_cap), nr, q.lp);
-        PE_HIP(hipEventRecord(h->ev_ctl[g], q.st));
+        (void)dc;
+        q.p_ctl = true; q.p_np = np_; q.p_nr = nr;
         return PNR_OK;
     }
+    // one dispatch for what control() / density_update() / admit() of this turn asked for, in that order
+    int flush(int g)
+    {
+        Grp &q = grp[g];
+        if (!q.p_ctl && q.p_m == 0 && q.p_nt == 0) return PNR_OK;
+        int *hc = h->h_ctl + (size_t)g * 2 * h->stream_cap;
+        hipLaunchKernelGGL(ph_poll, dim3((unsigned)(1 + (q.p_nt + 255) / 256)), dim3(256), 0, q.st, q.P, h->d_s6, q.p_ctl ? 1 : 0, (const int *)hc, q.p_np,
+                           (const int *)(hc + h->stream_cap), q.p_nr, (const int *)q.h_new, (const float *)q.h_new_s6, q.p_m, q.lp, E.ni, c->d_den,
+                           (const i64 *)h->h_den_idx[g], (const unsigned char *)h->h_den_val[g], (int)q.p_nt);
+        PE_HIP(hipGetLastError());
+        if (q.p_ctl) PE_HIP(hipEventRecord(h->ev_ctl[g], q.st));
+        if (q.p_m > 0) PE_HIP(hipEventRecord(h->ev_adm[g], q.st));
+        if (q.p_nt > 0) PE_HIP(hipEventRecord(h->ev_den[g], q.st));
+        q.p_ctl = false; q.p_np = q.p_nr = q.p_m = 0; q.p_nt = 0;
+        return PNR_OK;
+    }
+    int end_turn(int g) override { return flush(g); }
     int settle(int g) override
     {
+        { const int rc = flush(g); if (rc) return rc; }
         PE_HIP(hipStreamSynchronize(grp[g].st));
         return PNR_OK;
     }
@@ -1413,11 +1506,7 @@ struct PhasedEngine final : pnr::StreamEngine {
             h->h_den_idx[g][i] = r.touched[i];
             h->h_den_val[g][i] = (unsigned char)r.den_at(r.touched[i]); // final value: duplicates agree
         }
-        PE_HIP(hipMemcpyAsync(h->d_den_idx[g], h->h_den_idx[g], nt * 8, hipMemcpyHostToDevice, q.st));
-        PE_HIP(hipMemcpyAsync(h->d_den_val[g], h->h_den_val[g], nt, hipMemcpyHostToDevice, q.st));
-        const int rc = pnr_density_scatter_async(c, h->d_den_idx[g], h->d_den_val[g], nt, q.st);
-        if (rc) { msg = pnr_last_error(); return rc; }
-        PE_HIP(hipEventRecord(h->ev_den[g], q.st));
+        q.p_nt = nt;
         return PNR_OK;
     }
     void drain() override

@@ -106,6 +106,9 @@ public:
     virtual int density_update(const Replayer &r, int g) = 0;
     // block until everything queued for group g (control, admissions) has executed; only called for a group with nothing in flight
     virtual int settle(int g) { (void)g; return 0; }
+    // the end of group g's turn (after its control / density_update / admit and, if it had anything to step, its launch): an engine
+    // that gathers those requests into one dispatch sends whatever no launch has carried
+    virtual int end_turn(int g) { (void)g; return 0; }
     virtual void drain() = 0;
     virtual const char *error() const { return ""; }
 };
@@ -653,6 +656,8 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
         } else {
             E.idle(g); // (nothing of this group runs until its next launch: the other groups have the GPU to themselves)
         }
+        rc = E.end_turn(g);
+        if (rc) { err = E.error(); return fail(rc); }
         // ---- nothing running anywhere and nothing admitted: the frontier cannot move any more
         if (world > 1 && !sync_turn) continue; // the idle count only moves in the turns every rank synchronises in
         bool any = frontier > frontier_was;
