@@ -273,7 +273,7 @@ int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
  *   lag (-1 = automatic: half a poll when no other trace group covers the host's share of a poll, else one step) steps of a poll that run on while the host works on the state in front of them |
  *   overfill (1) the target is the mean over a poll | concentrate (1) with several trace groups new seeds go to one group while few traces survive a poll |
  *   sums_deep (-1 = automatic: launches of at most sums_deep_max (96) traces, or one trace group; 0 / 1) form of the ordered sums (four chunk buffers in turn) |
- *   profile_every (1) with pnr_set_profiling: the streaming tracer times every n-th poll of a trace group and counts it n-fold | poll (3) SMC steps between polls | groups (0 = automatic: 2 on one GPU, 1 sharded; 1..4) trace groups on separate streams | split_x10 (0 = automatic), max_split (96) sampling
+ *   profile_every (1) with pnr_set_profiling: the streaming tracer times every n-th poll of a trace group and counts it n-fold | poll (0 = automatic: 2 on one or two GPUs, 4 from four ranks on) SMC steps between polls | groups (0 = automatic: 2 on one GPU, 1 sharded; 1..4) trace groups on separate streams | split_x10 (0 = automatic), max_split (96) sampling
  *   work-groups per CU x 10 / per trace | stash_mb (65536) sample-stash budget | host_threads (0 = CPUs of this process /
  *   local_ranks) workers of the seed flood fill and of pnr_reconstruct_ctx | local_ranks (1) processes sharing this host |
  *   trace_timing, seed_timing (0/1) statistics on stderr | trace_log (0/1) keep every trace's end for pnr_get_trace_log | replay_batches (0/1), batch_growth, batch_max: rank batches instead

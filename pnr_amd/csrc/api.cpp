@@ -841,7 +841,7 @@ namespace {
 struct OptEntry { const char *key; int pnr::Options::*i32; int64_t pnr::Options::*i64; int64_t lo, hi; };
 const OptEntry OPTS[] = {
     {"window", &pnr::Options::window, nullptr, 0, 1 << 20},      {"look0", &pnr::Options::look0, nullptr, 0, 1 << 24},
-    {"look_pct", &pnr::Options::look_pct, nullptr, -1, 100000},   {"poll", &pnr::Options::poll, nullptr, 1, 1024},
+    {"look_pct", &pnr::Options::look_pct, nullptr, -1, 100000},   {"poll", &pnr::Options::poll, nullptr, 0, 1024},
     {"groups", &pnr::Options::groups, nullptr, 0, 4},            {"split_x10", &pnr::Options::split_x10, nullptr, 0, 10000},
     {"max_split", &pnr::Options::max_split, nullptr, 1, 4096},   {"stash_mb", nullptr, &pnr::Options::stash_mb, 1, 1 << 20},
     {"host_threads", &pnr::Options::host_threads, nullptr, 0, 1024}, {"local_ranks", &pnr::Options::local_ranks, nullptr, 1, 1024},

@@ -65,7 +65,7 @@ struct Options {
     int lag = -1;             // steps of a poll that run while the host works on the state in front of them (-1 automatic: stream_sched.h)
     int concentrate = 1;      // several trace groups: new seeds go to group 0 only while few traces survive a poll (experiment switch)
     int overfill = 1;         // the target is the mean over a poll, not the count at its start (experiment switch)
-    int poll = 3;             // SMC steps between two polls (round 4: 4 -> 3 together with target 200 -> 120)
+    int poll = 0;             // SMC steps between two polls; 0 = automatic (stream_sched.h run_stream: 2 on one or two GPUs, 4 from four ranks on)
     int groups = 0;           // trace groups on separate streams (0: automatic -- 2 on one GPU: one group's ordered sums overlap the other's sampling;
                               // 1 sharded: every poll is then an exchange, and small launches gain nothing from sharing the CUs)
     int split_x10 = 0;        // sampling work-groups per CU x 10 and launch; 0 = automatic (40 with one trace group, 22 with several)

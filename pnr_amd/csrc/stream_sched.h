@@ -60,7 +60,7 @@ struct SchedOptions {
                        // one running (one trace group, or `concentrate` at work), one step otherwise (measured with two groups on one GPU,
                        // lag 0 / 1 / 2 / 3: tracing 988 / 929 / 945 / 968 ms; 8 emulated ranks, one group each: 391 / 316 / 308 / 304 ms)
     int concentrate = 1; // one GPU, several groups: admit into group 0 only while few traces survive a poll (see the admission)
-    int poll = 4;      // SMC steps between two polls
+    int poll = 0;      // SMC steps between two polls (0: automatic, see run_stream)
     int groups = 2;    // trace groups stepping independently (engine permitting)
     int tentative = 1; // pause traces that a tentative replay of everything recorded so far cuts (see above)
     int timing = 0;    // one line of statistics on stderr
@@ -215,6 +215,10 @@ inline int run_stream(StreamEngine &E, const pnr_seed *seeds, int64_t n, int ni,
     if (o.target < 0) o.target = o.tentative ? (world == 1 ? 120 : 96) : 0; // (200 until ph_predict / ph_update took a third of their time: smaller launches cost less now)
     if (o.look0 <= 0) o.look0 = (world == 1 && o.tentative) ? (o.target > 0 ? 512 : 256) : std::max(128, 64 * world);
     if (o.look_pct < 0) o.look_pct = (world == 1 && o.tentative) ? (o.target > 0 ? 200 : 100) : std::min(400, 50 * world);
+    // 0: automatic.  On one GPU a poll is one dispatch and one state copy in the stream (round 4): two steps between polls beat three
+    // and four on both bench workloads; a sharded poll also exchanges and replays every rank's records, and from four ranks on four
+    // steps are better (emulated ranks, step in ms at poll 2 / 3 / 4: 2 ranks 647 / 665 / 673, 4 ranks 430 / 436 / 425, 8 ranks 309 / 311 / 297)
+    if (o.poll <= 0) o.poll = world <= 2 ? 2 : 4;
     o.poll = std::max(1, o.poll);
     const int NT = E.slots() - (E.slots() & 1);
     if (NT < 2) { err = "no trace slots"; abort_exchange(sh, ni); return PNR_E_STATE; }
