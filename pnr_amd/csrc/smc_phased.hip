@@ -495,7 +495,32 @@ __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5
             const int k = uidx[c];
             const float *q = (k >= np) ? xc_pen : cur + k * PSTRIDE; // (the centroid before the first one exists: zeros, discarded)
             const Frame f = make_frame(q[0], q[1], q[2], q[3], q[4], q[5]);
-            if (fastmask >> sI & 1)
+            // Where ph_predict could not promise the fast form for ALL templates of this sigma (a slab of 37 x 37 samples at an oblique
+            // angle pokes out of the 54^3 cube somewhere), this item alone may still lie inside: its five rows of this v-slice for its
+            // 64 chains.  The positions are affine in (uu, ww), so the extremes sit at the four corners of the item's (uu, ww) range,
+            // evaluated with the very operations sample_slice uses; a margin covers the rounding of the samples in between.
+            bool item_fast = (fastmask >> sI & 1) != 0;
+            if (!item_fast) {
+                const int iu0 = ch * ROWS, iu1 = min(ch * ROWS + ROWS, nu) - 1;
+                const float vv = ax[iv], uA = ax[nv + iu0], uB = ax[nv + iu1], wA = ax[nv + nu], wB = ax[nv + nu + nw - 1];
+                const float bx = f.px + vv * f.nvx, by = f.py + vv * f.nvy, bz = f.pz + vv * f.nvz;
+                bool ok = true;
+                const float base[3] = {bx, by, bz}, ud[3] = {f.ux, f.uy, f.uz}, wd3[3] = {f.wx, f.wy, f.wz}, lim[3] = {V.xmax, V.ymax, V.zmax};
+                const int org[3] = {Bx.ox, Bx.oy, Bx.oz};
+#pragma unroll
+                for (int a = 0; a < (IS2D ? 2 : 3); a++) {
+                    const float c0 = (base[a] + uA * ud[a]) + wA * wd3[a], c1 = (base[a] + uA * ud[a]) + wB * wd3[a];
+                    const float c2 = (base[a] + uB * ud[a]) + wA * wd3[a], c3 = (base[a] + uB * ud[a]) + wB * wd3[a];
+                    const float lo = fminf(fminf(c0, c1), fminf(c2, c3)) - 1e-3f, hi = fmaxf(fmaxf(c0, c1), fmaxf(c2, c3)) + 1e-3f;
+                    // inside the volume (the clamp is the identity) and the corner pairs inside the cube; false for NaN
+                    ok = ok && lo >= 0.f && hi <= lim[a] && floorf(lo) >= (float)org[a] && floorf(hi) + 1.f <= (float)(org[a] + CS - 1);
+                }
+                item_fast = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+            }
+#ifdef PNR_SMC_STAMPS
+            if (lane == 0) atomicAdd(&g_pu_fine[item_fast ? 6 : 7], 1ull);
+#endif
+            if (item_fast)
                 sample_slice<CS, IS2D, true, PH_PITCH>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64, ch * ROWS, ch * ROWS + ROWS);
             else if (volmask >> sI & 1)
                 sample_slice<CS, IS2D, false, PH_PITCH, true>(V, Bx, f, nv, nu, nw, ax, iv, sbase + (i64)g * Ms * 64, ch * ROWS, ch * ROWS + ROWS);

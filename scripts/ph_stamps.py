@@ -33,3 +33,4 @@ print("ph_update, cycles per work-group: loads %d | pending centroid %d | (exit 
 nf = max(fine[3], 1)
 print("ph_predict, thread 0 inside 'particles + box': parent pose there after %d cycles | direction loop %d | CDF search %d" % (fine[0] / nf, fine[1] / nf, fine[2] / nf))
 print("ph_predict duplicate search: %d of %d particles fell back to the scan" % (fine[4], fine[5]))
+print("ph_sample full-group items: %d on the fast path (no clamp, no range test), %d on the others" % (fine[6], fine[7]))
