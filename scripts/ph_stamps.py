@@ -1,5 +1,6 @@
 """Diagnostic: where a sampling work-group of the phased driver spends its cycles (needs `make -C pnr_amd/csrc stamps`; run with
-PNR_LIB_DIAG=pnr_amd/libpnr_hip_stamps.so).  Never quote this build's run time.  usage: [PNR_STAMP_OPTS=target=40] ph_stamps.py [size] [nseeds]"""
+PNR_LIB_DIAG=pnr_amd/libpnr_hip_stamps.so; through gpurun, which does not send that file: `make -C pnr_amd/csrc variant NAME=st DEFS=-DPNR_SMC_STAMPS`
+and PNR_LIB_DIAG=$PWD/pnr_amd/libpnr_hip_st.so).  Never quote this build's run time.  usage: [PNR_STAMP_OPTS=target=40] ph_stamps.py [size] [nseeds]"""
 import os, sys, ctypes as C
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import numpy as np, torch, synth, pnr_amd
