@@ -224,6 +224,7 @@ def main():
     # of a trace group and counts it fourfold (the per-launch averages are unbiased, the totals are estimates; PNR_BENCH_OPTS=profile_every=1: all)
     ctx.set_option("profile_every", 4)
     opts = ctx.set_options(os.environ.get("PNR_BENCH_OPTS"))
+    pe = max(1, ctx.get_option("profile_every"))
     ctx.set_volume_device(img.data_ptr(), (S, S, S), keepalive=img)
     ctx.set_profiling(not os.environ.get("PNR_BENCH_NOPROF"))  # NOPROF: how much do the HIP events of the kernel timers cost? (diagnostic; no roofline then)
     nvox = S * S * S
@@ -368,6 +369,16 @@ def main():
                 if wl.get("kernel_source_hash") != src_hash:  # taken from other kernels than the ones that run here: never quoted
                     stale.append(os.path.basename(tpath))
                     continue
+                # options that select another kernel form or split than this run's (anything but the number of trace groups, which the
+                # profile fixes at one so that no two kernels overlap under the counters): not this run's bytes either
+                po = dict((wl.get("config") or {}).get("options") or {})
+                ro = dict(opts or {})
+                for o_ in (po, ro):
+                    o_.pop("groups", None)
+                    o_.pop("profile_every", None)
+                if po != ro:
+                    stale.append(os.path.basename(tpath) + " (options %s)" % json.dumps(po, sort_keys=True))
+                    continue
                 # the profile was taken with one trace group (no two kernels overlap while the counters run): its launches hold more
                 # traces than this run's when the groups differ -- scale by the SMC iterations per launch (bytes per trace-iteration are
                 # what the kernels' traffic is made of)
@@ -443,6 +454,9 @@ def main():
                 "note": "(S+12) B/voxel compulsory bytes over the Frangi kernel group; VALU-bound: three Gaussian passes with separate multiply and add (the reference's rounding) and the Hessian stencil with its zero-response tests; the fp64 JAMA eigen-solver runs only where the response can reach J8 > 0"},
             "stages_ms": {k: v for k, v in st.items() if k.endswith("_ms")},
             "kernel_ms_per_step": {g: km[g][0] / a.steps for g in km},
+            "kernel_timers": ("HIP events on the launching stream; the streaming tracer times every %d-th poll of a trace group (always its first) and counts it "
+                              "%d-fold: per-launch averages unbiased, totals and launch counts of the SMC kernels are estimates (PNR_BENCH_OPTS=profile_every=1 times "
+                              "every launch); the untimed one-group pass (roofline_isolated) times every launch" % (pe, pe)) if pe > 1 else "HIP events around every launch",
             "counts": {k: v for k, v in st.items() if not k.endswith("_ms")},
             "smc_launches_per_step": smc_n / a.steps,
             "Mvox_per_s_frangi": (nvox / (fr_ms * 1e-3) / 1e6) if (fr_vox and fr_ms > 0) else None,
@@ -454,11 +468,13 @@ def main():
                 # the same step with ONE trace group (launches never overlap): what each kernel needs alone, and the evaluation
                 # over summed device time -- what rocprofv3 --kernel-trace --stats shows with option groups=1
                 ctx.set_option("groups", 1)
+                ctx.set_option("profile_every", 1)  # outside the timed region: every launch is timed
                 ctx.reset_kernel_ms()
                 t0i = time.perf_counter()
                 _, _, _, it_iso = ctx.trace_replay(s_all)
                 t_iso = 1e3 * (time.perf_counter() - t0i)
                 ctx.set_option("groups", groups_opt)
+                ctx.set_option("profile_every", pe)
                 ki = {g: ctx.kernel_ms(g) for g in EV}
                 ev_i = it_iso * (a.np + 1)
                 all_i = sum(v[0] for v in ki.values())

@@ -116,14 +116,6 @@ int pnr_quantise_j8(pnr_ctx *ctx, float Jmin, float Jmax);
  * the shortcut did not assume (Jmin other than 0, or a Jmax below the run's own maximum; the global extremes of a sharded stack
  * never are). */
 int pnr_get_frangi(pnr_ctx *ctx, float *J, uint8_t *J8, uint8_t *Vx, uint8_t *Vy, uint8_t *Vz);
-/* Test taps: Frangi::imgaussian (frangi.cpp:647) and Frangi::hessian3d (:291) for one sigma.
- * Host outputs, N floats each; Hessian order Dzz,Dyy,Dyz,Dxx,Dxy,Dxz (any may be NULL). */
-int pnr_gaussian(pnr_ctx *ctx, float sig, float *F);
-int pnr_hessian(pnr_ctx *ctx, float sig, float *Dzz, float *Dyy, float *Dyz, float *Dxx, float *Dxy, float *Dxz);
-/* Feed externally produced J8/V (host, N each) instead of pnr_frangi's: lets extractSeeds be
- * tested in isolation exactly like SeedExtractor::extractSeeds(tolerance,J8,...,Vx,Vy,Vz). */
-int pnr_set_j8_v(pnr_ctx *ctx, const uint8_t *J8, const uint8_t *Vx, const uint8_t *Vy, const uint8_t *Vz);
-
 /* SeedExtractor::extractSeeds (seed.cpp:556-791; Advantra_plugin.cpp:2549).  Library-owned
  * array, valid until the next call or pnr_destroy.  z-major, value-descending-per-layer order. */
 int pnr_extract_seeds(pnr_ctx *ctx, const pnr_seed **seeds, int64_t *n);
@@ -228,27 +220,6 @@ int pnr_shm_exchange_open(const char *name, int rank, int world, int64_t capacit
 int pnr_shm_allgather(void *user, const void *send, void *recv, int64_t bytes_per_rank);
 void pnr_shm_exchange_close(pnr_shm_exchange *x);
 
-/* The scheduler behind pnr_trace_replay[_sharded] (stream_sched.h) over a HOST engine that plays back map-free traces which
- * `trace(user, pos_dir[6], &T, xc[ni])` supplies (0 = ok; rows 0..min(T, ni)-1 of xc valid) -- pure host code, no GPU: the
- * multi-process tests drive the window / admission / exchange / replay logic with it, and a recorded workload can be
- * re-scheduled offline.  Same outputs as pnr_trace_replay_sharded.  look0 / look_pct: the admission lookahead (options of the same
- * name; 0 / -1 = automatic). */
-typedef int (*pnr_trace_fn)(void *user, const float *pos_dir, int32_t *T, pnr_xest *xc);
-int pnr_sched_playback(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n, int rank,
-                       int world, pnr_allgather_fn exchange, void *exchange_user, int64_t block_bytes, pnr_trace_fn trace,
-                       void *trace_user, int window, int groups, int poll, int look0, int look_pct, pnr_node *nodes, int64_t cap_nodes,
-                       int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links, int64_t *n_traces_used,
-                       int64_t *n_iterations_here);
-
-/* The same with the scheduler's tentative replay switched on or off (pnr_sched_playback: on, as in pnr_trace_replay[_sharded]; option
- * "tentative"), the number of running traces the admission keeps up (option "target"; -1 = automatic, 0 = off) and the steps of a poll
- * that run on while the host works (option "lag"; -1 = automatic): results are identical either way, only the number of iterations run differs. */
-int pnr_sched_playback2(const pnr_params *p, int64_t w, int64_t h, int64_t l, const pnr_seed *seeds, int64_t n, int rank,
-                        int world, pnr_allgather_fn exchange, void *exchange_user, int64_t block_bytes, pnr_trace_fn trace,
-                        void *trace_user, int window, int groups, int poll, int look0, int look_pct, int tentative, int target, int lag,
-                        pnr_node *nodes, int64_t cap_nodes, int64_t *n_nodes, int32_t *links, int64_t cap_links, int64_t *n_links,
-                        int64_t *n_traces_used, int64_t *n_iterations_here);
-
 /* reconstruct() chain of the plugin (Advantra_plugin.cpp:2096-2181), pure host: link resampling
  * (TRACE_RSMPL) -> mean-shift refinement (SIG2RADIUS, REFINE_ITER, EPSILON2) -> sphere grouping (GROUP_RADIUS) ->
  * BFS trees -> drop trees < TREE_SIZE_MIN -> tree resampling.  Input: the node graph of pnr_trace_replay /
@@ -257,11 +228,6 @@ int pnr_sched_playback2(const pnr_params *p, int64_t w, int64_t h, int64_t l, co
 int pnr_reconstruct(const pnr_node *nodes, int64_t n_nodes, const int32_t *links, int64_t n_links, float trace_rsmpl,
                     float sig2radius, int refine_iter, float epsilon2, float group_radius, int tree_size_min,
                     pnr_node *out_nodes, int32_t *out_parent, int64_t cap, int64_t *n_out);
-
-/* Tracker tables for parity tests: name in {"p","u","w0","w0_cws","v","w","w_cws","rng",
- * "model_vuw<s>","model_wgt<s>","model_avg","gauss_xy<s>","gauss_z<s>"}.  Copies up to cap
- * 4-byte words into out; *n receives the element count. */
-int pnr_get_table(pnr_ctx *ctx, const char *name, void *out, int64_t cap, int64_t *n);
 
 /* How pnr_trace_batch / pnr_trace_replay schedule the particle filter on the GPU (results are bit-identical):
  * 0 = one launch per SMC phase over all active traces of a batch (default), 1 = one persistent work-group per trace. */
@@ -276,7 +242,7 @@ int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
  *   profile_every (1) with pnr_set_profiling: the streaming tracer times every n-th poll of a trace group and counts it n-fold | poll (0 = automatic: 2 on one or two GPUs, 4 from four ranks on) SMC steps between polls | groups (0 = automatic: 2 on one GPU, 1 sharded; 1..4) trace groups on separate streams | split_x10 (0 = automatic), max_split (96) sampling
  *   work-groups per CU x 10 / per trace | stash_mb (65536) sample-stash budget | host_threads (0 = CPUs of this process /
  *   local_ranks) workers of the seed flood fill and of pnr_reconstruct_ctx | local_ranks (1) processes sharing this host |
- *   trace_timing, seed_timing (0/1) statistics on stderr | trace_log (0/1) keep every trace's end for pnr_get_trace_log | replay_batches (0/1), batch_growth, batch_max: rank batches instead
+ *   trace_timing, seed_timing (0/1) statistics on stderr | recon_timing (0/1) stage times of every pnr_reconstruct on stderr (process-wide: that call takes no context) | trace_log (0/1) keep every trace's end for pnr_get_trace_log | replay_batches (0/1), batch_growth, batch_max: rank batches instead
  *   of the streaming window | no_stash (0/1) persistent driver without the sample stash | exchange_block (0 = 256 KB / world) bytes per rank
  *   and exchange of pnr_trace_replay_sharded | frangi_prune (1) skip the eigen-solver below the first J8 level (pnr_get_frangi) |
  *   tentative (1) the streaming scheduler pauses traces that a tentative replay of everything recorded so far cuts, and ends them
@@ -292,10 +258,6 @@ int pnr_get_option(pnr_ctx *ctx, const char *key, int64_t *value);
 int pnr_set_profiling(pnr_ctx *ctx, int enable);
 int pnr_get_kernel_ms(pnr_ctx *ctx, const char *group, double *ms, int64_t *launches);
 int pnr_reset_kernel_ms(pnr_ctx *ctx);
-
-/* expf used for the particle likelihood exp(Kc*corr) (tracker.cpp:1029,1136), exposed so the
- * tests can compare the device implementation with the host libm over many inputs. */
-int pnr_expf_batch(pnr_ctx *ctx, const float *x, int64_t n, float *y);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@
  *   - the shipped v2 source nests `if (!ENFORCE_SINGLE_TREE)` inside `if (ENFORCE_SINGLE_TREE)` (:2142-2166) and
  *     therefore writes no final SWC with default settings; the evident intent (and the commented variant at
  *     :2171) -- extract_trees(TREE_SIZE_MIN) -> interpolate_treelist(1.0, AXON) -> save -- is what is restated.
- *   - group1 sorts node indices by corr with an unstable std::sort (:1570); ties keep index order here.
+ *   - group1 sorts node indices by corr with an unstable std::sort (:1570); ties keep index order here, NaN corr sorts last.
  */
 #include "pnr_oracle.h"
 #include <float.h>
@@ -144,8 +144,14 @@ typedef struct { float corr; long idx; } cidx;
 static int cmp_corr_desc(const void *a, const void *b)
 {
     const cidx *x = (const cidx *)a, *y = (const cidx *)b;
-    if (x->corr > y->corr) return -1;
-    if (x->corr < y->corr) return 1;
+    /* a NaN corr makes the reference's comparator (:1571) no strict weak order (undefined behaviour in std::sort); the restatement
+     * fixes a total order: numbers by decreasing corr, NaNs behind all of them, equal keys by index */
+    const int xn = x->corr != x->corr, yn = y->corr != y->corr;
+    if (xn != yn) return xn - yn;
+    if (!xn) {
+        if (x->corr > y->corr) return -1;
+        if (x->corr < y->corr) return 1;
+    }
     return (x->idx > y->idx) - (x->idx < y->idx);
 }
 static void group1(nvec *nX, nvec *nY, float rad)

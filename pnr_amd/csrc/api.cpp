@@ -860,6 +860,11 @@ const OptEntry OPTS[] = {
 int pnr_set_option(pnr_ctx *c, const char *key, int64_t value)
 {
     PNR_REQUIRE(c && key, PNR_E_ARG, "null argument");
+    if (std::strcmp(key, "recon_timing") == 0) { // process-wide: pnr_reconstruct takes no context
+        PNR_REQUIRE(value == 0 || value == 1, PNR_E_ARG, "option recon_timing = %lld outside [0, 1]", (long long)value);
+        advantra::set_recon_timing(value != 0);
+        return PNR_OK;
+    }
     for (const OptEntry &e : OPTS)
         if (std::strcmp(e.key, key) == 0) {
             PNR_REQUIRE(value >= e.lo && value <= e.hi, PNR_E_ARG, "option %s = %lld outside [%lld, %lld]", key, (long long)value, (long long)e.lo, (long long)e.hi);
@@ -873,6 +878,7 @@ int pnr_set_option(pnr_ctx *c, const char *key, int64_t value)
 int pnr_get_option(pnr_ctx *c, const char *key, int64_t *value)
 {
     PNR_REQUIRE(c && key && value, PNR_E_ARG, "null argument");
+    if (std::strcmp(key, "recon_timing") == 0) { *value = advantra::recon_timing() ? 1 : 0; return PNR_OK; }
     if (std::strcmp(key, "host_threads_effective") == 0) { *value = pnr::host_threads(c->opt); return PNR_OK; }
     if (std::strcmp(key, "frangi_recomputes") == 0) { *value = c->frangi_recomputes; return PNR_OK; } // exact Frangi re-runs so far (one pnr_frangi of GPU time each)
     for (const OptEntry &e : OPTS)
@@ -985,6 +991,12 @@ int pnr_expf_batch(pnr_ctx *c, const float *x, int64_t n, float *y)
 {
     PNR_REQUIRE(c && (n == 0 || (x && y)), PNR_E_ARG, "null argument");
     return pnr_expf_run(c, x, n, y);
+}
+
+int pnr_eigen_batch(pnr_ctx *c, const double *A, int64_t n, double *V, double *d)
+{
+    PNR_REQUIRE(c && n >= 0 && (n == 0 || (A && d)), PNR_E_ARG, "null argument");
+    return pnr_eigen_run(c, A, n, V, d);
 }
 
 } // extern "C"

@@ -2,6 +2,7 @@
 // translation units of libpnr_hip.so.  Not part of the C ABI.
 #pragma once
 #include "../../include/pnr_hip.h"
+#include "../../include/pnr_hip_test.h" // the test taps (implemented beside the product entry points)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdarg>
@@ -298,6 +299,7 @@ int pnr_density_reset(pnr_ctx *c);                       // zero the device dens
 int pnr_density_update(pnr_ctx *c, const pnr::Replayer &r, hipStream_t on = nullptr); // push the voxels touched since Replayer::touched was cleared
 int pnr_density_scatter_async(pnr_ctx *c, const long long *d_idx, const unsigned char *d_val, size_t n, hipStream_t st); // (staging owned by the caller, no wait)
 int pnr_expf_run(pnr_ctx *c, const float *x, int64_t n, float *y);
+int pnr_eigen_run(pnr_ctx *c, const double *A, int64_t n, double *V, double *d); // test tap (pnr_hip_test.h)
 int pnr_ensure_frangi_buffers(pnr_ctx *c);
 int pnr_frangi_materialise_v(pnr_ctx *c);
 int pnr_seed_dirs(pnr_ctx *c, const long long *d_idx, int n, unsigned char *d_dirs); // 0: done, 1: gather from the volumes, < 0: error

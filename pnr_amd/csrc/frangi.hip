@@ -1082,6 +1082,29 @@ __global__ __launch_bounds__(256) void vdir_points(ScaleVols SV, const unsigned 
     }
 }
 
+// ---- test tap (include/pnr_hip_test.h, pnr_eigen_batch): eigen3 on caller-supplied matrices, in the two forms the pipeline compiles --
+// eigenvalues only (eigen_queue: V is dead, the compiler drops that half of the arithmetic) and the full solver (vdir_points) -- so that
+// the reference's known-answer matrices (tests/golden/eigen_kat.npz: zero, diagonal, repeated eigenvalues ...) reach the device code.
+template <bool VECTORS>
+__global__ __launch_bounds__(256) void eigen_kat(const double *__restrict__ A, i64 n, double *__restrict__ Vo, double *__restrict__ dout)
+{
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    double V[3][3], d[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) V[r][cc] = A[t * 9 + r * 3 + cc];
+    eigen3(V, d);
+    dout[t * 3 + 0] = d[0]; dout[t * 3 + 1] = d[1]; dout[t * 3 + 2] = d[2];
+    if (VECTORS) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) Vo[t * 9 + r * 3 + cc] = V[r][cc];
+    }
+}
+
 // ----------------------------------------------------------------------------------------
 // K4': single-slice stacks (P == 1): hessian2d (frangi.cpp:508-574) + the closed-form 2x2 eigen-analysis and the
 // Rb / S2 vesselness of frangi2d (:392-506).  One thread per pixel; mixed f32 / f64 exactly as the reference
@@ -1398,6 +1421,29 @@ int pnr_seed_dirs(pnr_ctx *c, const long long *d_idx, int n, unsigned char *d_di
         return PNR_OK;
     }
     return 1; // the caller gathers from the volumes
+}
+
+// test tap: Frangi::eigen_decomposition (frangi.cpp:1269-1306) of n symmetric 3 x 3 matrices (host, row-major doubles) through the
+// device solver; V == nullptr runs the eigenvalues-only form eigen_queue compiles
+int pnr_eigen_run(pnr_ctx *c, const double *A, int64_t n, double *V, double *d)
+{
+    if (n == 0) return PNR_OK;
+    double *dA = nullptr, *dV = nullptr, *dd = nullptr;
+    PNR_HIP(hipMalloc(&dA, (size_t)n * 72));
+    hipError_t e = hipMalloc(&dd, (size_t)n * 24);
+    if (e == hipSuccess && V) e = hipMalloc(&dV, (size_t)n * 72);
+    if (e == hipSuccess) e = hipMemcpyAsync(dA, A, (size_t)n * 72, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        if (V) hipLaunchKernelGGL(eigen_kat<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double *)dA, (i64)n, dV, dd);
+        else hipLaunchKernelGGL(eigen_kat<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double *)dA, (i64)n, dV, dd);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(d, dd, (size_t)n * 24, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && V) e = hipMemcpyAsync(V, dV, (size_t)n * 72, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dA); (void)hipFree(dV); (void)hipFree(dd);
+    PNR_HIP(e);
+    return PNR_OK;
 }
 
 // J -> J8 with the given extremes (Advantra_plugin.cpp:2499-2512)

@@ -28,6 +28,7 @@ int main(int argc, char **argv)
         if (!strcmp(argv[i], "-f") && i + 1 < argc) { func = argv[++i]; continue; }
         if (!strcmp(argv[i], "-g") && i + 1 < argc) { device = atoi(argv[++i]); continue; }
         if (!strcmp(argv[i], "-v")) { advantra::settings().verbose = true; continue; }
+        if (!strcmp(argv[i], "--timing")) { advantra::settings().timing = true; continue; }
         if (!strcmp(argv[i], "--save-midres")) { advantra::settings().save_midres = true; continue; }
         if (!strcmp(argv[i], "--rng-seed") && i + 1 < argc) { advantra::settings().rng_seed = (uint32_t)strtoul(argv[++i], nullptr, 10); continue; }
         if (!strcmp(argv[i], "-d") && i + 1 < argc) { raw_dims = argv[++i]; continue; }

@@ -470,6 +470,7 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
         // :2658-2710: the particle filters on the GPU (a window of traces refilled as they stop), the bookkeeping replayed on the
         // host in seed order; the graph stays in the context and is fetched once its size is known
         if (settings().verbose) pnr_set_option(ctx, "trace_log", 1);
+        if (settings().timing) { pnr_set_option(ctx, "trace_timing", 1); pnr_set_option(ctx, "recon_timing", 1); }
         if (world == 1)
             ok = pnr_trace_replay(ctx, seeds.data(), nseeds, 0, nullptr, 0, &nn, nullptr, 0, &nl, &used, &iters) == PNR_OK;
         else // every rank traces seeds rank, rank + world, ...; finished traces are exchanged and replayed in seed order on every rank

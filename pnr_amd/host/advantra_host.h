@@ -41,6 +41,7 @@ struct Result {
 // switches of the head-less driver (advantra_cli flags; the plugin's compile-time TRACING_VERBOSE / saveMidres taps)
 struct Settings {
     bool verbose = false;     // -v: per-trace progress and stop reasons in the reference's words (tracker.cpp:866,879,908,916; Advantra_plugin.cpp:2677)
+    bool timing = false;      // --timing: the library's stage statistics on stderr (options trace_timing, seed_timing, recon_timing)
     bool save_midres = false; // --save-midres: also write <inimg>_n0_.swc, the node graph before reconstruct() (:2099)
     uint32_t rng_seed = 42;   // --rng-seed: replaces srand(time(NULL)) of tracker.cpp:1003,1098
     // --ranks N: this process is rank `rank` of `world` processes of one host, one GPU each, that reconstruct ONE stack together

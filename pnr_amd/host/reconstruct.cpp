@@ -220,8 +220,14 @@ void group_spheres(List &src, List &dst, float rad)
     // indices: a comparator that reads the nodes themselves spends its time on cache misses)
     std::vector<std::pair<float, int>> keyed(n);
     for (size_t i = 0; i < n; i++) keyed[i] = {src[i].corr, (int)i};
+    // A NaN corr (tracker.cpp:1079,1184 stop on corr < znccth only, which a NaN passes) would make "a.corr > b.corr" no strict weak
+    // order -- undefined behaviour in std::sort, here as in the reference (:1571).  The order is made total: numbers by decreasing
+    // corr, NaNs behind all of them, equal keys by index.
     std::sort(keyed.begin(), keyed.end(), [](const std::pair<float, int> &a, const std::pair<float, int> &b) {
-        return a.first > b.first || (a.first == b.first && a.second < b.second);
+        const bool an = a.first != a.first, bn = b.first != b.first;
+        if (an != bn) return bn;
+        if (!an && a.first != b.first) return a.first > b.first;
+        return a.second < b.second;
     });
     std::vector<int> order(n);
     for (size_t i = 0; i < n; i++) order[i] = keyed[i].second;
@@ -356,6 +362,10 @@ void resample_tree(List &t, float step, int type)
 
 } // namespace
 
+static std::atomic<bool> g_recon_timing{false};
+void set_recon_timing(bool on) { g_recon_timing.store(on, std::memory_order_relaxed); }
+bool recon_timing() { return g_recon_timing.load(std::memory_order_relaxed); }
+
 void reconstruct(const std::vector<pnr_node> &nodes, const std::vector<int32_t> &links, const ReconParams &rp,
                  std::vector<pnr_node> &out_nodes, std::vector<int32_t> &out_parent)
 {
@@ -369,8 +379,7 @@ void reconstruct(const std::vector<pnr_node> &nodes, const std::vector<int32_t> 
         n0[links[k + 1]].nbr.push_back(links[k]);
     }
     List n2, forest, kept;
-    // PNR_RECON_TIMING=1: the stages' wall times on stderr
-    const bool timing = std::getenv("PNR_RECON_TIMING") != nullptr;
+    const bool timing = recon_timing(); // option "recon_timing": the stages' wall times on stderr
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what, size_t n) {
         if (!timing) return;

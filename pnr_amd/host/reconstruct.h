@@ -24,6 +24,11 @@ struct ReconParams {          // Advantra_plugin.cpp:72-83
 
 // nodes[0] is the dummy; links = pairs (a,b): a.nbr.push_back(b); b.nbr.push_back(a).
 // out_nodes/out_parent: the tree list (index 0 dummy; parent -1 = root), as save_nodelist would write it.
+// stage wall times of every reconstruct() on stderr: a process-wide switch (pnr_reconstruct takes no context), set through
+// pnr_set_option(ctx, "recon_timing", 0 / 1) like every other diagnostic -- the library reads no environment variable
+void set_recon_timing(bool on);
+bool recon_timing();
+
 void reconstruct(const std::vector<pnr_node> &nodes, const std::vector<int32_t> &links, const ReconParams &rp,
                  std::vector<pnr_node> &out_nodes, std::vector<int32_t> &out_parent);
 

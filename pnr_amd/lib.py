@@ -99,6 +99,7 @@ def load():
     L.pnr_get_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i64)]
     L.pnr_reset_kernel_ms.argtypes = [vp]
     L.pnr_expf_batch.argtypes = [vp, vp, i64, vp]
+    L.pnr_eigen_batch.argtypes = [vp, vp, i64, vp, vp]
     L.pnr_get_graph.argtypes = [vp, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64)]
     L.pnr_trace_replay_sharded.argtypes = [vp, vp, i64, i32, i32, ALLGATHER_FN, vp, vp, i64, C.POINTER(i64), vp, i64, C.POINTER(i64),
                                            C.POINTER(i64), C.POINTER(i64)]
@@ -120,13 +121,18 @@ def load():
     return L
 
 
-EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", "pnr_set_stream", "pnr_synchronize",
-           "pnr_set_volume", "pnr_set_volume_device", "pnr_frangi", "pnr_get_frangi", "pnr_gaussian", "pnr_hessian",
-           "pnr_set_j8_v", "pnr_extract_seeds", "pnr_extract_seeds_range", "pnr_zncc_batch",
-           "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_replay_traces_ctx", "pnr_frangi_slab", "pnr_quantise_j8", "pnr_soma", "pnr_get_soma", "pnr_trace_replay", "pnr_reconstruct", "pnr_get_table", "pnr_set_profiling", "pnr_set_smc_driver",
-           "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_expf_batch", "pnr_get_graph", "pnr_trace_replay_sharded", "pnr_sched_playback", "pnr_sched_playback2",
-           "pnr_set_option", "pnr_get_option", "pnr_score_filter_seeds", "pnr_sort_seeds", "pnr_get_trace_log",
-           "pnr_shm_exchange_open", "pnr_shm_allgather", "pnr_shm_exchange_close"]
+# the drop-in boundary (include/pnr_hip.h)
+PRODUCT_EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", "pnr_set_stream", "pnr_synchronize",
+                   "pnr_set_volume", "pnr_set_volume_device", "pnr_frangi", "pnr_get_frangi", "pnr_extract_seeds", "pnr_extract_seeds_range",
+                   "pnr_zncc_batch", "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_replay_traces_ctx",
+                   "pnr_frangi_slab", "pnr_quantise_j8", "pnr_soma", "pnr_get_soma", "pnr_trace_replay", "pnr_reconstruct", "pnr_set_profiling",
+                   "pnr_set_smc_driver", "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_get_graph", "pnr_trace_replay_sharded",
+                   "pnr_set_option", "pnr_get_option", "pnr_score_filter_seeds", "pnr_sort_seeds", "pnr_get_trace_log",
+                   "pnr_shm_exchange_open", "pnr_shm_allgather", "pnr_shm_exchange_close"]
+# test taps (include/pnr_hip_test.h): single stages of the device code and the scheduler over a host engine, for tests/ only
+TEST_EXPORTS = ["pnr_gaussian", "pnr_hessian", "pnr_set_j8_v", "pnr_get_table", "pnr_expf_batch", "pnr_eigen_batch",
+                "pnr_sched_playback", "pnr_sched_playback2"]
+EXPORTS = PRODUCT_EXPORTS + TEST_EXPORTS
 
 
 def check(rc):
@@ -413,6 +419,14 @@ class Context:
     def reset_kernel_ms(self):
         check(self.L.pnr_reset_kernel_ms(self.h))
 
+    def eigen(self, A, vectors=True):
+        """test tap: the device's JAMA solver on n symmetric 3 x 3 matrices -> (V or None, d)"""
+        A = np.ascontiguousarray(A, np.float64).reshape(-1, 3, 3)
+        d = np.empty((len(A), 3), np.float64)
+        V = np.empty((len(A), 3, 3), np.float64) if vectors else None
+        check(self.L.pnr_eigen_batch(self.h, A.ctypes.data, len(A), V.ctypes.data if vectors else None, d.ctypes.data))
+        return V, d
+
     def expf(self, x):
         x = np.ascontiguousarray(x, np.float32)
         y = np.empty_like(x)
@@ -516,11 +530,11 @@ def reconstruct(nodes, links, trace_rsmpl=0.0, sig2radius=0.0, refine_iter=0, ep
         cap = int(n.value)
 
 
-def kernel_source_hash(names=("smc_phased.hip", "smc_device.h", "smc.hip")):
-    """sha256 (first 16 hex digits) over the sources of the SMC kernels (what the bytes a trace-iteration moves depend on; the host
-    scheduler only decides how many trace-iterations a launch holds, which bench.py scales for): the committed PMC traffic profiles carry it,
-    and bench.py only quotes a profile whose hash equals the hash of the sources it runs (a changed kernel is never priced with the
-    bytes of an older one)"""
+def kernel_source_hash(names=("smc_phased.hip", "smc_device.h", "smc.hip", "ctx.h", "stream_sched.h")):
+    """sha256 (first 16 hex digits) over the sources the bytes of a trace-iteration depend on: the SMC kernels, and the defaults
+    (ctx.h: max_split, sums_deep_max ...) and the scheduler (stream_sched.h) that decide which kernel form and split a launch
+    takes.  The committed PMC traffic profiles carry it, and bench.py only quotes a profile whose hash equals the hash of the sources
+    it runs (a changed kernel or default is never priced with the bytes of an older one)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")

@@ -14,14 +14,14 @@ del img
 torch.cuda.empty_cache()
 cli = os.path.join(R, "pnr_amd", "host", "advantra_cli")
 # the 11 parameters of README.md:17: scales, somaradius, tolerance, znccth, kappa, step, ni, np, zdist, nodepervol, vol
-cmd = [cli, "-d", f"{S},{S},{S}", "-f", "advantra_func", "-i", path, "-p", "2,4,6", "0", "5", "0.3", "3", "2", "200", "200", "2", "4", "1"]
+cmd = [cli, "--timing", "-d", f"{S},{S},{S}", "-f", "advantra_func", "-i", path, "-p", "2,4,6", "0", "5", "0.3", "3", "2", "200", "200", "2", "4", "1"]
 out = []
 for rep in range(2):  # (the first run pays the page cache and the driver's first-touch costs)
     t0 = time.time()
     pr = subprocess.run(cmd, capture_output=True, text=True)
     wall = time.time() - t0
-    for ln in pr.stderr.splitlines():  # (PNR_RECON_TIMING=1: the stages of reconstruct())
-        if ln.startswith("[pnr reconstruct]"): print(ln, file=sys.stderr)
+    for ln in pr.stderr.splitlines():  # (--timing: the stages of reconstruct())
+        if ln.startswith("[pnr reconstruct]") or ln.startswith("[pnr trace]"): print(ln, file=sys.stderr)
     m = re.search(r"wall: load ([\d.]+) s, context \+ upload ([\d.]+) s, frangi ([\d.]+) s, seeds ([\d.]+) s, selection ([\d.]+) s, tracing ([\d.]+) s, reconstruct ([\d.]+) s, write ([\d.]+) s \| total ([\d.]+) s", pr.stdout)
     m2 = re.search(r"(\d+) trace nodes, (\d+) traces, (\d+) SMC iterations, (\d+) tree nodes", pr.stdout)
     if not m:

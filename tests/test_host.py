@@ -22,9 +22,12 @@ def _has_gpu():
 
 
 def test_library_exports_header_symbols():
-    hdr = open(os.path.join(ROOT, "include", "pnr_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(pnr_[a-z0-9_]+)\s*\(", hdr)))
-    assert set(declared) == set(lib.EXPORTS), set(declared) ^ set(lib.EXPORTS)
+    declared = []
+    for name, exports in (("pnr_hip.h", lib.PRODUCT_EXPORTS), ("pnr_hip_test.h", lib.TEST_EXPORTS)):
+        hdr = open(os.path.join(ROOT, "include", name)).read()
+        here = sorted(set(re.findall(r"^(?:int|void|const char \*)\s*(pnr_[a-z0-9_]+)\s*\(", hdr, re.M)))
+        assert set(here) == set(exports), (name, set(here) ^ set(exports))
+        declared += here
     L = lib.load()
     for name in declared:
         assert getattr(L, name) is not None
@@ -205,6 +208,33 @@ def test_replay_and_reconstruct_with_soma_match_oracle(oracle):
     for k in got_n.dtype.names:
         assert np.array_equal(got_n[k], want_n[k], equal_nan=True), k
     assert (got_n["type"] == 1).sum() >= 1  # a soma node survives in the tree list with its type
+
+
+def test_reconstruct_with_nan_corr_nodes():
+    """group1's sort by corr (Advantra_plugin.cpp:1571) must stay defined when some nodes carry a NaN corr (the stop test
+    `corr < znccth` lets a NaN through): numbers by decreasing corr, NaNs last, ties by index -- product and oracle alike, on more
+    nodes than std::sort's insertion-sort threshold (16) so that an invalid comparator would walk out of bounds"""
+    rng = np.random.default_rng(11)
+    n = 400
+    nodes = np.zeros(n + 1, lib.NODE_DT)
+    t = np.arange(n)
+    nodes["x"][1:] = 5 + 0.8 * t % 60
+    nodes["y"][1:] = 5 + (t // 75) * 1.5 + rng.random(n).astype(np.float32)
+    nodes["z"][1:] = 5 + rng.random(n).astype(np.float32)
+    nodes["vx"][1:] = 1
+    nodes["sig"][1:] = 2.0
+    nodes["corr"][1:] = rng.uniform(0.3, 0.95, n).astype(np.float32)
+    nodes["corr"][1 + rng.choice(n, 37, replace=False)] = np.nan
+    nodes["corr"][[7, 8, 9]] = np.float32(0.5)  # exact ties beside the NaNs
+    nodes["type"][1:] = 2
+    links = np.array([[i + 1, i] for i in range(1, n) if i % 75], np.int32)
+    L = orc.load_oracle()
+    want_n, want_p = orc.reconstruct(L, nodes, links, tree_size_min=2)
+    for _ in range(2):
+        got_n, got_p = lib.reconstruct(nodes, links, tree_size_min=2)
+        assert len(got_n) == len(want_n) > 20 and np.array_equal(got_p, want_p)
+        for k in got_n.dtype.names:
+            assert np.array_equal(got_n[k], want_n[k], equal_nan=True), k
 
 
 def test_reconstruct_degenerate_inputs():
