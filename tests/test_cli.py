@@ -83,6 +83,50 @@ def test_cli_matches_python_pipeline(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_config0_literal_vs_oracle(tmp_path, oracle):
+    """BASELINE configs[0] as written: a 128 x 128 x 64 synthetic TIFF, scales = {2}, 50 particles, README parameters otherwise
+    (ni 200, step 2, zdist 2, nodepervol 4, vol 1), end to end through advantra_func of the C++ host (advantra_cli -> C ABI -> HIP)
+    into an SWC file -- against the oracle's whole pipeline on the same stack: Frangi -> J8 -> extractSeeds -> znccBBB filter + sort
+    -> every trace to its map-free end -> trackPos / trackNeg replay -> reconstruct() -> SWC.  Node and trace counts equal, SWC equal
+    (ids, types, parents identical; coordinates and radii within the SWC text precision)."""
+    import re
+    import orc
+    from PIL import Image
+    img = synth.synth(128, 128, 64, seed=1)
+    tif = str(tmp_path / "config0.tif")
+    pages = [Image.fromarray(z) for z in img]
+    pages[0].save(tif, save_all=True, append_images=pages[1:], compression=None)
+    r = run("-f", "advantra_func", "-i", tif, "-p", *"2 0 5 0.3 3 2 200 50 2 4 1".split())
+    assert r.returncode == 0, r.stderr
+    swc = tif + "_Advantra.swc"
+    assert os.path.exists(swc)
+    sigs, np_, ni, zdist = [2.0], 50, 200, 2.0
+    J, jmin, jmax, Vx, Vy, Vz = orc.frangi3d(oracle, img, sigs, zdist)
+    s = orc.extract_seeds(oracle, 5, orc.j8(oracle, J, jmin, jmax), Vx, Vy, Vz)
+    To = orc.Tracker(oracle, sigs, 2, np_, ni, 3.0, 0.3, zdist=zdist)
+    corr, _ = To.zncc(img, s[:, :6])
+    s[:, 7] = corr
+    s = s[corr >= 0.3]
+    s = s[np.argsort(-s[:, 7], kind="stable")]
+    Ts, xcs = [], []
+    for sd in s:
+        for sgn in (1, -1):
+            q = sd[:6].copy()
+            q[3:] *= sgn
+            Tn, _, xc, *_ = To.trace(img, q)
+            Ts.append(Tn)
+            xcs.append(xc)
+    nodes_o, links_o, nt = orc.replay(oracle, s, np.array(Ts, np.int32), np.stack(xcs), ni, img.shape, 4, 1)
+    tree_o, par_o = orc.reconstruct(oracle, nodes_o, links_o)
+    m = re.search(r"(\d+) trace nodes, (\d+) traces", r.stdout)
+    assert m and int(m.group(1)) == len(nodes_o) - 1 and int(m.group(2)) == nt, (m and m.groups(), len(nodes_o) - 1, nt)
+    ref = str(tmp_path / "oracle.swc")
+    pnr_amd.write_swc_tree(ref, tree_o, par_o)
+    ok, msg = swc_diff.diff(swc, ref, tol=2e-3)
+    assert ok and len(swc_diff.read_swc(swc)[0]) > 300, msg
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["soma", "slice"])
 def test_cli_soma_and_single_slice(tmp_path, case):
     """the C++ host runs the soma path for somaradius > 0 and the 2-D mode for a one-page TIFF, like the Python mirror"""
