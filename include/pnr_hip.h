@@ -220,6 +220,21 @@ int pnr_shm_exchange_open(const char *name, int rank, int world, int64_t capacit
 int pnr_shm_allgather(void *user, const void *send, void *recv, int64_t bytes_per_rank);
 void pnr_shm_exchange_close(pnr_shm_exchange *x);
 
+/* The same collectives over RCCL (xGMI between the GPUs of a node, the network across nodes) for hosts that are not Python
+ * (advantra_cli --ranks N --exchange rccl; pnr_amd/multigpu.py reaches RCCL through torch.distributed instead): an ncclAllGather of one
+ * fixed-size block per rank -- pass pnr_rccl_allgather as `exchange` and the handle as `user` -- and the 2-float all-reduce of
+ * (Jmin, Jmax) of the z-slab Frangi (one ncclAllReduce(ncclMax) over (-min, max)).  The payloads are host data: every call stages
+ * through pinned host memory and a device buffer on the exchange's own stream.  One rank calls pnr_rccl_unique_id and hands the 128
+ * bytes to the others by any means (advantra_cli: the shared-memory segment; across nodes: the launcher); every rank then opens the
+ * exchange with ITS device -- a collective call, one rank per GPU (RCCL refuses two ranks on one device).  librccl is opened at run
+ * time, when the first of these calls is made; without it they fail with PNR_E_STATE.  capacity_bytes >= the largest block. */
+typedef struct pnr_rccl_exchange pnr_rccl_exchange;
+int pnr_rccl_unique_id(void *id128);
+int pnr_rccl_exchange_open(const void *id128, int rank, int world, int device, int64_t capacity_bytes, pnr_rccl_exchange **out);
+int pnr_rccl_allgather(void *user, const void *send, void *recv, int64_t bytes_per_rank);
+int pnr_rccl_allreduce_minmax(pnr_rccl_exchange *x, float *min_inout, float *max_inout);
+void pnr_rccl_exchange_close(pnr_rccl_exchange *x);
+
 /* reconstruct() chain of the plugin (Advantra_plugin.cpp:2096-2181), pure host: link resampling
  * (TRACE_RSMPL) -> mean-shift refinement (SIG2RADIUS, REFINE_ITER, EPSILON2) -> sphere grouping (GROUP_RADIUS) ->
  * BFS trees -> drop trees < TREE_SIZE_MIN -> tree resampling.  Input: the node graph of pnr_trace_replay /

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 #include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
@@ -21,9 +22,11 @@ int main(int argc, char **argv)
     std::string func = "advantra_func", raw_dims;
     int device = 0, ranks = 1;
     bool share_gpu = false;
+    std::string transport = "shm";
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--ranks") && i + 1 < argc) { ranks = atoi(argv[++i]); continue; }
         if (!strcmp(argv[i], "--share-gpu")) { share_gpu = true; continue; }
+        if (!strcmp(argv[i], "--exchange") && i + 1 < argc) { transport = argv[++i]; continue; }
         if (!strcmp(argv[i], "-x") && i + 1 < argc) { i++; continue; } // plugin name: ignored
         if (!strcmp(argv[i], "-f") && i + 1 < argc) { func = argv[++i]; continue; }
         if (!strcmp(argv[i], "-g") && i + 1 < argc) { device = atoi(argv[++i]); continue; }
@@ -40,7 +43,12 @@ int main(int argc, char **argv)
         return 0;
     }
     if (func != "advantra_func") return 1; // dofunc: unknown function -> false
-    if (ranks <= 1) return advantra::advantra_func(infiles, paras, device, raw_dims) ? 0 : 1;
+    if (transport != "shm" && transport != "rccl") { fprintf(stderr, "--exchange: shm or rccl\n"); return 1; }
+    const bool rccl = transport == "rccl";
+    if (rccl && share_gpu && ranks > 1) { fprintf(stderr, "--exchange rccl needs one GPU per rank (RCCL refuses two ranks on one device)\n"); return 1; }
+    // (--ranks 1 --exchange rccl: the sharded code path with its RCCL collectives on a world of one -- what a one-GPU box can rehearse)
+    if (ranks <= 1 && !rccl) return advantra::advantra_func(infiles, paras, device, raw_dims) ? 0 : 1;
+    if (ranks < 1) ranks = 1;
     if (ranks > 64) { fprintf(stderr, "--ranks: at most 64\n"); return 1; }
     // one process per GPU, forked here -- nothing has touched a GPU yet -- and joined through a shared-memory segment
     // unique to this job, not only to this pid (a recycled pid must never meet the segment of a crashed earlier job)
@@ -58,7 +66,23 @@ int main(int argc, char **argv)
                 fprintf(stderr, "rank %d: %s\n", r, pnr_last_error());
                 _exit(1);
             }
-            const bool okr = advantra::advantra_func(infiles, paras, share_gpu ? device : device + r, raw_dims);
+            const int dev = share_gpu ? device : device + r;
+            if (rccl) { // the ncclUniqueId of rank 0 reaches the others through the shared-memory segment; then every rank joins with its GPU
+                unsigned char id[128] = {0};
+                std::vector<unsigned char> all((size_t)128 * ranks);
+                int okid = (r != 0 || pnr_rccl_unique_id(id) == PNR_OK) ? 1 : 0;
+                if (!okid) fprintf(stderr, "rank 0: %s\n", pnr_last_error());
+                if (pnr_shm_allgather(S.exchange, id, all.data(), 128) != PNR_OK) { fprintf(stderr, "rank %d: %s\n", r, pnr_last_error()); _exit(1); }
+                bool zero = true; // (rank 0 failed to make an id: everybody leaves)
+                for (int b = 0; b < 128; b++) zero = zero && all[(size_t)b] == 0;
+                if (zero || pnr_rccl_exchange_open(all.data(), r, ranks, dev, 1 << 18, &S.rccl) != PNR_OK) {
+                    if (!zero) fprintf(stderr, "rank %d: %s\n", r, pnr_last_error());
+                    _exit(1);
+                }
+                S.force_shard = true;
+            }
+            const bool okr = advantra::advantra_func(infiles, paras, dev, raw_dims);
+            pnr_rccl_exchange_close(S.rccl);
             pnr_shm_exchange_close(S.exchange);
             fflush(stdout); fflush(stderr);
             _exit(okr ? 0 : 1);

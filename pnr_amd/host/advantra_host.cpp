@@ -331,17 +331,18 @@ bool advantra_func(const std::vector<char *> &infiles, const std::vector<char *>
     return true;
 }
 
-// ---- the few collectives of the sharded path, over the shared-memory all-gather of the ranks of this host -------------------
+// ---- the few collectives of the sharded path, over the transport the ranks were joined with: the shared-memory all-gather of the
+// ranks of this host (default) or RCCL (--exchange rccl) -----------------------------------------------------------------------------
 namespace {
-constexpr size_t XCHUNK = 1 << 18; // bytes per rank and call (the segment is opened with this capacity)
-bool allgather_bytes(pnr_shm_exchange *x, int world, const void *send, size_t n, std::vector<unsigned char> &out)
+constexpr size_t XCHUNK = 1 << 18; // bytes per rank and call (both transports are opened with this capacity)
+bool allgather_bytes(pnr_allgather_fn fn, void *user, int world, const void *send, size_t n, std::vector<unsigned char> &out)
 {
     out.assign(n * (size_t)world, 0);
     std::vector<unsigned char> sb(XCHUNK), rb(XCHUNK * (size_t)world);
     for (size_t off = 0; off < n || off == 0; off += XCHUNK) {
         const size_t m = std::min(XCHUNK, n - off);
         if (m) std::memcpy(sb.data(), (const unsigned char *)send + off, m);
-        if (pnr_shm_allgather(x, sb.data(), rb.data(), (int64_t)m) != PNR_OK) return false;
+        if (fn(user, sb.data(), rb.data(), (int64_t)m) != PNR_OK) return false;
         for (int r = 0; r < world; r++)
             if (m) std::memcpy(out.data() + (size_t)r * n + off, rb.data() + (size_t)r * m, m);
         if (n == 0) break;
@@ -354,8 +355,12 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
                          const std::vector<std::string> &paras, pnr_params p, int device, Result *result)
 {
     const int rank = settings().rank, world = settings().world;
-    pnr_shm_exchange *const X = settings().exchange;
-    if (world > 1 && (!X || l < 2)) {
+    // the transport of the sharded path's collectives
+    pnr_rccl_exchange *const RX = settings().rccl;
+    const pnr_allgather_fn xfn = RX ? pnr_rccl_allgather : pnr_shm_allgather;
+    void *const X = RX ? (void *)RX : (void *)settings().exchange;
+    const bool sharded = world > 1 || settings().force_shard;
+    if (sharded && (!X || l < 2)) {
         fprintf(stderr, "--ranks needs a stack of at least 2 planes and an open exchange\n");
         return false;
     }
@@ -387,7 +392,7 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
     std::vector<pnr_seed> seeds;
     int64_t nfound = 0, nseeds = 0;
     auto t0 = clk::now(), t1 = t0, t2 = t0;
-    if (world == 1) {
+    if (!sharded) {
         ok = pnr_set_volume(ctx, data1d, w, h, l) == PNR_OK;
         if (ok) run_soma();
         t0 = clk::now();
@@ -417,13 +422,19 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
             ok = pnr_set_volume(ctx, data1d + zlo * w * h, w, h, zhi - zlo) == PNR_OK;
             ok = ok && pnr_frangi_slab(ctx, z0 - zlo, z1 - zlo, &mm[0], &mm[1]) == PNR_OK;
         }
-        std::vector<unsigned char> all;
-        if (!allgather_bytes(X, world, mm, sizeof(mm), all)) ok = false; // the 2-float all-reduce
+        // the 2-float all-reduce: one ncclAllReduce over RCCL, an all-gather + local reduction through shared memory
         R.Jmin = FLT_MAX; R.Jmax = -FLT_MAX;
-        for (int r = 0; r < world && ok; r++) {
-            float q[2];
-            std::memcpy(q, all.data() + (size_t)r * sizeof(q), sizeof(q));
-            R.Jmin = std::min(R.Jmin, q[0]); R.Jmax = std::max(R.Jmax, q[1]);
+        if (RX) {
+            R.Jmin = mm[0]; R.Jmax = mm[1];
+            if (pnr_rccl_allreduce_minmax(RX, &R.Jmin, &R.Jmax) != PNR_OK) ok = false;
+        } else {
+            std::vector<unsigned char> all;
+            if (!allgather_bytes(xfn, X, world, mm, sizeof(mm), all)) ok = false;
+            for (int r = 0; r < world && ok; r++) {
+                float q[2];
+                std::memcpy(q, all.data() + (size_t)r * sizeof(q), sizeof(q));
+                R.Jmin = std::min(R.Jmin, q[0]); R.Jmax = std::max(R.Jmax, q[1]);
+            }
         }
         t1 = clk::now();
         if (ok && z1 > z0) {
@@ -440,7 +451,7 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
         if (ok && nmine) ok = pnr_score_filter_seeds(ctx, mine.data(), nmine, &cnt[1]) == PNR_OK; // this slab's seeds: znccBBB + threshold
         if (!ok) cnt[0] = -1; // a rank that failed says so: every collective up to here was entered by everybody, none after is
         std::vector<unsigned char> counts;
-        if (!allgather_bytes(X, world, cnt, sizeof(cnt), counts)) ok = false;
+        if (!allgather_bytes(xfn, X, world, cnt, sizeof(cnt), counts)) ok = false;
         int64_t mx = 0;
         std::vector<int64_t> kept((size_t)world);
         for (int r = 0; r < world; r++) {
@@ -451,7 +462,7 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
         }
         mine.resize((size_t)mx); // padded payloads
         std::vector<unsigned char> pay;
-        if (ok && !allgather_bytes(X, world, mine.data(), (size_t)mx * sizeof(pnr_seed), pay)) ok = false;
+        if (ok && !allgather_bytes(xfn, X, world, mine.data(), (size_t)mx * sizeof(pnr_seed), pay)) ok = false;
         for (int r = 0; r < world && ok; r++) { // rank order = the z-major order of the unsharded extraction
             const pnr_seed *q = (const pnr_seed *)(pay.data() + (size_t)r * (size_t)mx * sizeof(pnr_seed));
             seeds.insert(seeds.end(), q, q + kept[(size_t)r]);
@@ -471,10 +482,10 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
         // host in seed order; the graph stays in the context and is fetched once its size is known
         if (settings().verbose) pnr_set_option(ctx, "trace_log", 1);
         if (settings().timing) { pnr_set_option(ctx, "trace_timing", 1); pnr_set_option(ctx, "recon_timing", 1); }
-        if (world == 1)
+        if (!sharded)
             ok = pnr_trace_replay(ctx, seeds.data(), nseeds, 0, nullptr, 0, &nn, nullptr, 0, &nl, &used, &iters) == PNR_OK;
         else // every rank traces seeds rank, rank + world, ...; finished traces are exchanged and replayed in seed order on every rank
-            ok = pnr_trace_replay_sharded(ctx, seeds.data(), nseeds, rank, world, pnr_shm_allgather, X, nullptr, 0, &nn, nullptr, 0, &nl, &used, &iters) == PNR_OK;
+            ok = pnr_trace_replay_sharded(ctx, seeds.data(), nseeds, rank, world, xfn, X, nullptr, 0, &nn, nullptr, 0, &nl, &used, &iters) == PNR_OK;
         if (ok) {
             R.nodes.resize((size_t)nn);
             R.links.resize((size_t)(2 * nl));

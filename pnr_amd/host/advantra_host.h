@@ -48,7 +48,12 @@ struct Settings {
     // (z-slabs of Frangi / seeds, sorted seeds dealt round-robin, finished traces exchanged through shared memory: INTEGRATION.md);
     // rank 0 writes the SWC.  The reference has no counterpart.
     int rank = 0, world = 1;
-    pnr_shm_exchange *exchange = nullptr;
+    pnr_shm_exchange *exchange = nullptr; // the ranks of one host: bootstrap and default transport (shared memory)
+    // --exchange rccl: the collectives of the sharded path -- ncclAllReduce of (Jmin, Jmax), ncclAllGather of the scored seeds and of the
+    // finished trace records at every poll -- over RCCL / xGMI instead (one rank per GPU; the shared-memory segment only carries the
+    // 128-byte ncclUniqueId).  force_shard: the sharded code path also for a world of one (the only RCCL world a one-GPU box can form).
+    pnr_rccl_exchange *rccl = nullptr;
+    bool force_shard = false;
 };
 Settings &settings();
 

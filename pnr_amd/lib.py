@@ -112,10 +112,16 @@ def load():
     L.pnr_shm_allgather.argtypes = [vp, vp, vp, i64]
     L.pnr_shm_exchange_close.argtypes = [vp]
     L.pnr_shm_exchange_close.restype = None
+    L.pnr_rccl_unique_id.argtypes = [vp]
+    L.pnr_rccl_exchange_open.argtypes = [vp, i32, i32, i32, i64, C.POINTER(vp)]
+    L.pnr_rccl_allgather.argtypes = [vp, vp, vp, i64]
+    L.pnr_rccl_allreduce_minmax.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.pnr_rccl_exchange_close.argtypes = [vp]
+    L.pnr_rccl_exchange_close.restype = None
     L.pnr_set_option.argtypes = [vp, C.c_char_p, i64]
     L.pnr_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
     for name in EXPORTS:
-        if name not in ("pnr_last_error", "pnr_default_params", "pnr_destroy", "pnr_shm_exchange_close"):
+        if name not in ("pnr_last_error", "pnr_default_params", "pnr_destroy", "pnr_shm_exchange_close", "pnr_rccl_exchange_close"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -128,7 +134,8 @@ PRODUCT_EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_de
                    "pnr_frangi_slab", "pnr_quantise_j8", "pnr_soma", "pnr_get_soma", "pnr_trace_replay", "pnr_reconstruct", "pnr_set_profiling",
                    "pnr_set_smc_driver", "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_get_graph", "pnr_trace_replay_sharded",
                    "pnr_set_option", "pnr_get_option", "pnr_score_filter_seeds", "pnr_sort_seeds", "pnr_get_trace_log",
-                   "pnr_shm_exchange_open", "pnr_shm_allgather", "pnr_shm_exchange_close"]
+                   "pnr_shm_exchange_open", "pnr_shm_allgather", "pnr_shm_exchange_close",
+                   "pnr_rccl_unique_id", "pnr_rccl_exchange_open", "pnr_rccl_allgather", "pnr_rccl_allreduce_minmax", "pnr_rccl_exchange_close"]
 # test taps (include/pnr_hip_test.h): single stages of the device code and the scheduler over a host engine, for tests/ only
 TEST_EXPORTS = ["pnr_gaussian", "pnr_hessian", "pnr_set_j8_v", "pnr_get_table", "pnr_expf_batch", "pnr_eigen_batch",
                 "pnr_sched_playback", "pnr_sched_playback2"]
@@ -368,7 +375,7 @@ class Context:
         the loop).  Every rank returns the same graph; the iteration count is this rank's."""
         s = np.ascontiguousarray(seeds, SEED_DT)
         nn, nl, nt, it = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
-        fn, user = (exchange.fn, exchange.handle) if isinstance(exchange, ShmExchange) else (exchange, None)
+        fn, user = (exchange.fn, exchange.handle) if hasattr(exchange, "handle") else (exchange, None)  # ShmExchange / RcclExchange: no Python in the loop
         check(self.L.pnr_trace_replay_sharded(self.h, s.ctypes.data, len(s), rank, world, fn, user, None, 0, C.byref(nn), None, 0,
                                               C.byref(nl), C.byref(nt), C.byref(it)))
         nodes, links = self.get_graph()
@@ -478,6 +485,43 @@ class ShmExchange:
             self.handle = None
 
 
+class RcclExchange:
+    """pnr_rccl_exchange: the same collectives over RCCL from a host that is not torch (include/pnr_hip.h): ncclAllGather of one block
+    per rank (`fn` / `handle` = exchange / user of pnr_trace_replay_sharded) and the (min, max) all-reduce.  `uid` = the 128 bytes
+    of RcclExchange.unique_id() of one rank, handed to the others by the launcher.  A collective call: one rank per GPU."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        check(load().pnr_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, uid, rank, world, device, capacity=1 << 20):
+        self.L = load()
+        h = C.c_void_p()
+        check(self.L.pnr_rccl_exchange_open(uid, rank, world, device, capacity, C.byref(h)))
+        self.handle, self.rank, self.world, self.capacity = h, rank, world, capacity
+        self.fn = C.cast(self.L.pnr_rccl_allgather, ALLGATHER_FN)
+
+    def allgather(self, block):
+        n = len(block)
+        send = (C.c_char * max(n, 1)).from_buffer_copy(block.ljust(1, b"\0"))
+        recv = (C.c_char * max(n * self.world, 1))()
+        check(self.L.pnr_rccl_allgather(self.handle, send, recv, n))
+        raw = bytes(recv)
+        return [raw[r * n:(r + 1) * n] for r in range(self.world)]
+
+    def minmax(self, mn, mx):
+        a, b = C.c_float(mn), C.c_float(mx)
+        check(self.L.pnr_rccl_allreduce_minmax(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self.handle:
+            self.L.pnr_rccl_exchange_close(self.handle)
+            self.handle = None
+
+
 def sched_playback(params, shape, seeds, trace_fn, rank=0, world=1, exchange=None, block_bytes=0, window=768, groups=1, poll=4, look0=0, look_pct=-1, tentative=True, target=-1, lag=-1):
     """The streaming scheduler over a host engine that plays back map-free traces (pnr_sched_playback; no GPU): `trace_fn(pos_dir6)`
     -> (T, xc[ni][8]).  Returns nodes, links, traces used, iterations on this rank."""
@@ -501,7 +545,7 @@ def sched_playback(params, shape, seeds, trace_fn, rank=0, world=1, exchange=Non
 
     tcb = TRACE_FN(_tr)
     xuser = None
-    if isinstance(exchange, ShmExchange):
+    if isinstance(exchange, (ShmExchange, RcclExchange)):
         exchange, xuser = exchange.fn, exchange.handle
     xcb = exchange if exchange is not None else C.cast(None, ALLGATHER_FN)
     nn, nl, nt, it = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()

@@ -296,3 +296,51 @@ def test_bench_sharded_path_over_rccl_world_of_one():
     assert sh["config"]["record_exchange"] and sh["n_gpus"] == 1
     for k in ("nodes", "n_seeds", "n_seeds_init", "traces_used"):
         assert sh["counts"][k] == one["counts"][k], k
+
+
+def test_c_abi_rccl_exchange_world_of_one():
+    """pnr_rccl_exchange (include/pnr_hip.h; rccl_exchange.cpp): the ncclAllGather-backed pnr_allgather_fn and the (min, max)
+    ncclAllReduce from a host that is not torch, on the only RCCL world a one-GPU box can form -- in a fresh process, before anything
+    else has touched the GPU, as advantra_cli's ranks do: blocks come back unchanged (several sizes, also after the size changes, up
+    to the capacity), the all-reduce is the identity, a block beyond the capacity is refused."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["PNR_ROOT"])
+os.environ["PNR_NO_TORCH_PRELOAD"] = "1"
+from pnr_amd import lib
+x = lib.RcclExchange(lib.RcclExchange.unique_id(), 0, 1, 0, capacity=1 << 18)
+for nb in (16, 4096, 4096, 65536, 1 << 18, 8):
+    blk = bytes((7 * i + nb) % 251 for i in range(nb))
+    got = x.allgather(blk)
+    assert len(got) == 1 and got[0] == blk, nb
+assert x.minmax(0.25, 3.5) == (0.25, 3.5) and x.minmax(-1.5, -1.0) == (-1.5, -1.0)
+try:
+    x.allgather(bytes((1 << 18) + 16))
+    raise SystemExit("a block beyond the capacity was accepted")
+except lib.PnrError as e:
+    assert "opened for" in str(e)
+x.close()
+print("rccl exchange ok")
+'''
+    env = dict(os.environ, PNR_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl exchange ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_cli_ranks_over_rccl_world_of_one(tmp_path):
+    """advantra_cli --ranks 1 --exchange rccl: the C++ host's sharded path (z-slab Frangi, 2-float ncclAllReduce, ncclAllGather of the
+    scored seeds, pnr_trace_replay_sharded with pnr_rccl_allgather as its exchange) on a world of one, against the plain CLI and against
+    the shared-memory transport's sharded path: the same SWC file, byte for byte"""
+    CLI = os.path.join(ROOT, "pnr_amd", "host", "advantra_cli")
+    raw = str(tmp_path / "s.raw")
+    synth.synth(96, 80, 40, seed=7).tofile(raw)
+    paras = "2,3 0 5 0.3 3 2 40 48 2 4 1".split()
+    outs = {}
+    for name, extra in (("plain", ()), ("rccl", ("--ranks", "1", "--exchange", "rccl"))):
+        r = subprocess.run([CLI, "-d", "96,80,40", *extra, "-f", "advantra_func", "-i", raw, "-p", *paras], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert r.returncode == 0, (name, r.stdout[-800:], r.stderr[-2000:])
+        outs[name] = open(raw + "_Advantra.swc").read()
+        os.remove(raw + "_Advantra.swc")
+    body = lambda t: [ln for ln in t.splitlines() if ln and ln[0] != "#"]
+    assert body(outs["plain"]) == body(outs["rccl"]) and len(body(outs["plain"])) > 50

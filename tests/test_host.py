@@ -45,6 +45,20 @@ def test_no_cpu_fallback():
         pnr_amd.Context(pnr_amd.make_params(), 0)
 
 
+def test_rccl_exchange_needs_the_ranks_gpu():
+    """the C-ABI RCCL transport (pnr_rccl_*): librccl is opened at run time (no link-time dependency of libpnr_hip.so), the unique id
+    is 128 bytes that differ from call to call, and opening an exchange without the rank's GPU fails with PNR_E_NODEVICE -- no fallback"""
+    import subprocess
+    deps = subprocess.run(["ldd", lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in deps
+    a, b = lib.RcclExchange.unique_id(), lib.RcclExchange.unique_id()
+    assert len(a) == 128 and a != b
+    if _has_gpu():
+        pytest.skip("GPU present")
+    with pytest.raises(pnr_amd.PnrError, match="no HIP device"):
+        lib.RcclExchange(a, 0, 1, 0)
+
+
 def test_parameter_validation_messages():
     """range errors of Advantra::dofunc (Advantra_plugin.cpp:317-326) surface before any device work"""
     L = lib.load()
