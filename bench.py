@@ -426,8 +426,11 @@ def main():
                        "trace_groups": groups},
             "roofline": {
                 "kernel": "+".join(KNAME[g] for g in EV if g in KNAME), "dominant_by_device_time": KNAME[dominant],
-                "bound": "hbm", "bound_measured": "lds-gather + valu (ph_sample), hbm stash + serial f32 chains (ph_sums)",
-                "bound_detail": "priced against the HBM peak as SURVEY 8(d) prescribes (the contract's bound is the roofline it is priced against); what the kernels wait for is named in bound_measured",
+                "bound": "hbm",
+                "bound_measured": ("hbm: with two trace groups overlapping, the evaluation as built moves its REAL bytes (traffic: the f32 sample stash written once and read twice, "
+                                   "~1.5 x the algorithmic bytes) at traffic_rate.frac_of_mixed_rw_ceiling_5500 of what HBM delivers to a concurrent writer and reader (scripts/probes/mall_wr); "
+                                   "taken alone ph_sample is bound by LDS gather + VALU issue (roofline_full_occupancy) and a small ph_sums launch by one wave's serial f32 / f64 chain"),
+                "bound_detail": "priced against the 8 TB/s HBM peak on ALGORITHMIC bytes as SURVEY 8(d) prescribes; `traffic` / `traffic_rate` give the real bytes and their rate",
                 "bytes_per_launch": bytes_total / steps_smc, "avg_launch_ms": step_ms, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_time_base": "tracing wall time" if overlapped else "summed device time",
                 "traffic": traffic, "traffic_source": traffic_src, "traffic_per_kernel": traffic_k or None, "traffic_note": traffic_note, "kernel_source_hash": src_hash,

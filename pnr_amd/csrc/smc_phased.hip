@@ -41,8 +41,12 @@ struct PhState {
     float *corr;   // [NT][S][np_pad]
     float *xcs;    // [NT][2][8]
     int *flags;    // [NT][FL_N]
-    float *stash;  // [NT][trace_floats]: per sigma, ngf regions [M][64] of the full chain groups, then [M][R] of the last one
+    // The sample stash lives from ph_sample to ph_sums of ONE step, so it is indexed by a trace's POSITION in the step's list, not by its
+    // slot: [stash_base + position][trace_floats] (per sigma, ngf regions [M][64] of the full chain groups, then [M][R] of the last one).
+    // What it has to hold is the largest launch of a trace group, not the window of slots (paused traces keep slot and state, no stash).
+    float *stash;
     long long trace_floats;
+    int stash_base; // first stash row of this trace group (the groups step concurrently: each has a region of its own)
     int *list;     // [2][cap]: traces still running in iteration it: list[it & 1][0 .. cnt[it & 1])
     int *cnt;      // [2]
     int *ctr;      // [NT] sampling work-item counter of the current iteration
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5
         npksum += nv_s * (((nu_s + parts - 1) / parts + ROWS - 1) / ROWS);
     }
     const int nfull = nchsum * ngf, nitems = nfull + (rem > 0 ? npksum : 0);
-    float *const tbase = P.stash + (i64)tr * P.trace_floats;
+    float *const tbase = P.stash + (i64)(P.stash_base + slot) * P.trace_floats;
     const int lane = tid & 63;
     (void)ni;
     // Items in descending cost: (sigma descending, v-slice, row chunk, full group), then the last group's per (sigma, v-slice,
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(64) void ph_sums(Tab T, TabX X, PhState P, int np, 
     (void)np; (void)ni; (void)it_arg;
     const Grid gr = X.grid[sI];
     const int M = gr.nv * gr.nu * gr.nw;
-    const float *sbase = P.stash + (i64)tr * P.trace_floats + (i64)gr.off * P.W;
+    const float *sbase = P.stash + (i64)(P.stash_base + slot) * P.trace_floats + (i64)gr.off * P.W;
     const float *wd = X.wd + gr.off;
     float cv;
     bool valid = true;
@@ -970,6 +974,7 @@ __global__ __launch_bounds__(256) void ph_poll(PhState P, float *__restrict__ s6
 struct pnr_phased {
     static constexpr int RING = 8;
     int64_t cap_traces = 0, cap_dbg = 0;
+    int64_t cap_stash = 0; // traces the sample stash holds (list positions of all trace groups together)
     int np = 0, np_pad = 0, S = 0, ni = 0;
     long long trace_floats = 0;
     PhState P{};
@@ -1007,6 +1012,7 @@ static void phased_free(pnr_phased *h)
     h->O = TraceOut{};
     h->d_s6 = nullptr;
     h->cap_traces = h->cap_dbg = 0;
+    h->cap_stash = 0;
 }
 
 #ifdef PNR_SMC_STAMPS
@@ -1103,7 +1109,23 @@ struct PhEnv {
 
 // device state for up to `want` concurrent traces (fewer if their sample stash exceeds the budget: PNR_STASH_GB,
 // default 64 GB, or half of the free HBM) and everything the four kernels take as arguments
-static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool idxres, bool neff, PhEnv &E)
+// the sample stash for `traces` list positions (all trace groups together); grows only
+static int ensure_stash(pnr_ctx *c, pnr_phased *h, int64_t traces, long long trace_floats)
+{
+    if (h->cap_stash >= traces && h->P.stash) return PNR_OK;
+    PNR_HIP(hipDeviceSynchronize());
+    (void)hipFree(h->P.stash);
+    h->P.stash = nullptr; h->cap_stash = 0;
+    PNR_HIP(hipMalloc(&h->P.stash, (size_t)traces * trace_floats * 4));
+    h->cap_stash = traces;
+    // a stale stash value is only ever read for a chain whose result is discarded, but keep it finite
+    PNR_HIP(hipMemsetAsync(h->P.stash, 0, (size_t)traces * trace_floats * 4, c->stream));
+    PNR_HIP(hipStreamSynchronize(c->stream)); // (the trace groups' streams do not wait for this one)
+    return PNR_OK;
+}
+
+// stash_want: list positions the stash must hold at once (<= 0: one per trace slot -- a one-shot batch starts all its traces together)
+static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool idxres, bool neff, PhEnv &E, int64_t stash_want = 0)
 {
     int rc = make_vol(c, E.V);
     if (rc) return rc;
@@ -1135,7 +1157,7 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     size_t free_b = 0, total_b = 0;
     PNR_HIP(hipMemGetInfo(&free_b, &total_b));
     size_t budget = (size_t)std::max<int64_t>(1, c->opt.stash_mb) << 20; // option "stash_mb" (tests: force several waves / a narrow window)
-    const size_t have = (size_t)h->cap_traces * (size_t)h->trace_floats * 4; // our own stash counts as free
+    const size_t have = (size_t)h->cap_stash * (size_t)h->trace_floats * 4; // our own stash counts as free
     budget = std::min(budget, (free_b + have) / 2);
     const int64_t nt_max = (int64_t)(budget / ((size_t)trace_floats * 4));
     PNR_REQUIRE(nt_max >= 1, PNR_E_HIP, "not enough device memory for one trace's sample stash (%lld B)", trace_floats * 4);
@@ -1156,7 +1178,6 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
         // the counters of the step lists sit in front of the flags in ONE buffer: the streaming tracer's poll copies both with one copy
         PNR_HIP(hipMalloc(&h->P.cnt, ((size_t)cap * FL_N + 2 * pnr_phased::MAXG) * 4));
         h->P.flags = h->P.cnt + 2 * pnr_phased::MAXG;
-        PNR_HIP(hipMalloc(&h->P.stash, (size_t)cap * trace_floats * 4));
         PNR_HIP(hipMalloc(&h->P.list, (size_t)cap * 2 * 4 * pnr_phased::MAXG)); // one pair of lists per trace group of the streaming tracer
         PNR_HIP(hipMalloc(&h->P.ctr, (size_t)cap * 4));
         PNR_HIP(hipMalloc(&h->P.uidx, (size_t)cap * np_pad * 4));
@@ -1171,11 +1192,11 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
         if (dbg_iters && neff) PNR_HIP(hipMalloc(&h->O.neff, dbg_cap * 4));
         h->cap_traces = cap; h->cap_dbg = (int64_t)dbg_cap;
         h->np = np; h->np_pad = np_pad; h->S = S; h->ni = ni; h->trace_floats = trace_floats;
-        // a stale stash value is only ever read for a chain whose result is discarded, but keep it finite
-        PNR_HIP(hipMemsetAsync(h->P.stash, 0, (size_t)cap * trace_floats * 4, c->stream));
         PNR_HIP(hipMemsetAsync(h->P.part, 0, (size_t)cap * 2 * np * PSTRIDE * 4, c->stream));
     }
+    { const int rcs = ensure_stash(c, h, stash_want > 0 ? std::min<int64_t>(stash_want, NT) : NT, trace_floats); if (rcs) return rcs; }
     E.P = h->P;
+    E.P.stash_base = 0;
     E.P.trace_floats = trace_floats;
     E.P.cap = (int)h->cap_traces;
     E.P.W = W;
@@ -1325,6 +1346,7 @@ struct PhasedEngine final : pnr::StreamEngine {
     Grp grp[pnr_phased::MAXG];
     std::string msg;
     int ngroups = 1;    // trace groups the scheduler steps (what a launch shares the GPU with)
+    int gcap = 0;       // list positions of the sample stash per trace group (grown when a launch holds more traces: grow_stash)
     // (with several trace groups a launch shares the CUs with the other groups' launches: fewer, fatter sampling work-groups -- 22
     // instead of 40 per 10 CUs -- and the form of ph_sums that fits beside them; decided per launch, see launch())
 
@@ -1339,9 +1361,12 @@ struct PhasedEngine final : pnr::StreamEngine {
 
     int init(int64_t window)
     {
-        int rc = phased_env(c, window, 0, false, false, false, E);
+        // the stash holds the traces of a LAUNCH (a trace's position in its group's list), not the window: 192 positions per group to
+        // start with (the automatic target keeps 60 - 120 traces running per group), grown on demand
+        int rc = phased_env(c, window, 0, false, false, false, E, (int64_t)ngroups * 192);
         if (rc) { msg = pnr_last_error(); return rc; }
         h = E.h;
+        gcap = (int)std::max<int64_t>(1, h->cap_stash / ngroups);
         NT = (int)(E.NT - (E.NT & 1)); // slots come in pairs (the two directions of a seed)
         if (NT < 2) { msg = "not enough device memory for two trace slots"; return PNR_E_HIP; }
         const int ni = E.ni;
@@ -1379,6 +1404,7 @@ struct PhasedEngine final : pnr::StreamEngine {
         for (int g = 0; g < pnr_phased::MAXG; g++) {
             Grp &q = grp[g];
             q.P = E.P;
+            q.P.stash_base = (g < ngroups ? g : 0) * gcap;
             q.P.list = E.P.list + (size_t)g * 2 * E.P.cap;
             q.P.cnt = E.P.cnt + 2 * g;
             q.st = g == 0 ? c->stream : h->stg[g];
@@ -1401,8 +1427,23 @@ struct PhasedEngine final : pnr::StreamEngine {
         q.p_m = m; // (flush(): the kernel reads the pinned staging itself -- a few hundred bytes over the bus, no copies in front of it)
         return PNR_OK;
     }
+    // a launch with more traces than a group's stash region holds: every group gets a larger region (rare: the stash starts with room
+    // for the launches the automatic target produces)
+    int grow_stash(int need)
+    {
+        const int ncap = (int)std::min<int64_t>(E.NT, std::max(need, gcap + gcap / 2));
+        if (ncap < need) { msg = "a launch holds more traces than the window has slots"; return PNR_E_STATE; }
+        const int rc = ensure_stash(c, h, (int64_t)ngroups * ncap, E.trace_floats);
+        if (rc) { msg = pnr_last_error(); return rc; }
+        gcap = ncap;
+        E.P.stash = h->P.stash;
+        for (int k = 0; k < pnr_phased::MAXG; k++) { grp[k].P.stash = h->P.stash; grp[k].P.stash_base = (k < ngroups ? k : 0) * gcap; }
+        return PNR_OK;
+    }
     int launch(int g, int active, int poll, int lag) override
     {
+        if (g >= ngroups) { msg = "trace group beyond the stash regions"; return PNR_E_STATE; }
+        if (active > gcap) { const int rc = grow_stash(active); if (rc) return rc; }
         { const int rc = flush(g); if (rc) return rc; }
         Grp &q = grp[g];
         hipStream_t st = q.st;
