@@ -7,6 +7,7 @@
 # the sources it runs have that hash.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+[ -x $ROOT/scripts/probes/fetch_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $ROOT/scripts/probes/fetch_calib $ROOT/scripts/probes/fetch_calib.hip
 cd /tmp && export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/traffic
 rm -rf $OUT && mkdir -p $OUT
