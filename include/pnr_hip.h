@@ -239,10 +239,18 @@ void pnr_rccl_exchange_close(pnr_rccl_exchange *x);
  * (TRACE_RSMPL) -> mean-shift refinement (SIG2RADIUS, REFINE_ITER, EPSILON2) -> sphere grouping (GROUP_RADIUS) ->
  * BFS trees -> drop trees < TREE_SIZE_MIN -> tree resampling.  Input: the node graph of pnr_trace_replay /
  * pnr_replay_traces.  Output: the tree list save_nodelist writes (node 0 dummy; parent -1 = root).  Values <= 0
- * select the plugin constants (1.0, 1.5, 4, 1e-4, 2.0, 10). */
+ * select the plugin constants (1.0, 1.5, 4, 1e-4, 2.0, 10) -- except tree_size_min < 0, which selects the plugin's ENFORCE_SINGLE_TREE
+ * branch (:81, :2142-2152): only the largest tree is kept (extract_largest_tree :546-589; the plugin names that file _Advantra1.swc). */
 int pnr_reconstruct(const pnr_node *nodes, int64_t n_nodes, const int32_t *links, int64_t n_links, float trace_rsmpl,
                     float sig2radius, int refine_iter, float epsilon2, float group_radius, int tree_size_min,
                     pnr_node *out_nodes, int32_t *out_parent, int64_t cap, int64_t *n_out);
+
+/* The plugin's saveMidres taps inside reconstruct() (:2098-2141): the node list as it stands behind stage 1 = interpolate_nodelist
+ * (_n0res_), 2 = non_blurring (_n1_), 3 = group1 (_n2_), 4 = compute_trees (_n2tree_).  out_links: pairs, every undirected link once
+ * (stage 4: (child, parent)); counts are returned even when the buffers are too small. */
+int pnr_reconstruct_stage(const pnr_node *nodes, int64_t n_nodes, const int32_t *links, int64_t n_links, float trace_rsmpl,
+                          float sig2radius, int refine_iter, float epsilon2, float group_radius, int stage, pnr_node *out_nodes,
+                          int64_t cap_nodes, int64_t *n_out_nodes, int32_t *out_links, int64_t cap_links, int64_t *n_out_links);
 
 /* How pnr_trace_batch / pnr_trace_replay schedule the particle filter on the GPU (results are bit-identical):
  * 0 = one launch per SMC phase over all active traces of a batch (default), 1 = one persistent work-group per trace. */

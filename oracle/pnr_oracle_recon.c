@@ -273,6 +273,26 @@ static void extract_trees(const nvec *X, nvec *Y, int min_size)
     free(rm); free(X2Y);
 }
 
+/* ---- extract_largest_tree (:546-589), the ENFORCE_SINGLE_TREE branch of reconstruct() (:2142-2152) ---- */
+static void extract_largest_tree(const nvec *X, nvec *Y)
+{
+    long n = X->n;
+    long root_curr = 1, root_prev = 1, tree_max_size = -2147483647L, tree_max_beg = -2147483647L, tree_max_end = -2147483647L;
+    for (long i = 1; i <= n; ++i)
+        if (i == n || X->v[i].nbr.n == 0) {
+            root_prev = root_curr;
+            root_curr = i;
+            if (root_curr - root_prev > tree_max_size) { tree_max_size = root_curr - root_prev; tree_max_beg = root_prev; tree_max_end = root_curr; }
+        }
+    long *X2Y = (long *)malloc(sizeof(long) * (size_t)(n > 0 ? n : 1));
+    for (long i = 0; i < n; ++i) {
+        X2Y[i] = -1;
+        if (i == 0 || (i >= tree_max_beg && i < tree_max_end)) { X2Y[i] = Y->n; nv_push(Y, node_copy(&X->v[i])); }
+    }
+    for (long i = 1; i < Y->n; ++i) for (int j = 0; j < Y->v[i].nbr.n; ++j) Y->v[i].nbr.v[j] = (int)X2Y[Y->v[i].nbr.v[j]];
+    free(X2Y);
+}
+
 /* ---- interpolate_treelist, one-directional links (:714-778) ---- */
 static void interpolate_treelist(nvec *t, float step, int type)
 {
@@ -313,7 +333,8 @@ int64_t orc_reconstruct(const orc_node *nodes, int64_t n_nodes, const int32_t *l
     non_blurring(&n0, &n1, sig2radius, refine_iter, epsilon2);
     group1(&n1, &n2, group_radius);
     bfs2(&n2, &tr, 1);
-    extract_trees(&tr, &t3, tree_size_min);
+    if (tree_size_min < 0) extract_largest_tree(&tr, &t3); /* ENFORCE_SINGLE_TREE (:2142-2152) */
+    else extract_trees(&tr, &t3, tree_size_min);
     interpolate_treelist(&t3, 1.0f, 2 /* AXON */);
     int64_t n = t3.n;
     for (int64_t i = 0; i < n && i < cap; i++) {

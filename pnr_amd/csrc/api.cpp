@@ -903,6 +903,7 @@ int pnr_reconstruct(const pnr_node *nodes, int64_t n_nodes, const int32_t *links
     if (epsilon2 > 0) rp.epsilon2 = epsilon2;
     if (group_radius > 0) rp.group_radius = group_radius;
     if (tree_size_min > 0) rp.tree_size_min = tree_size_min;
+    rp.single_tree = tree_size_min < 0;
     rp.threads = pnr::host_threads(pnr::Options()); // rank 0 post-processes alone: every CPU this process may use
     std::vector<pnr_node> in(nodes, nodes + n_nodes), out;
     std::vector<int32_t> lk(links, links + 2 * n_links), par;
@@ -911,6 +912,30 @@ int pnr_reconstruct(const pnr_node *nodes, int64_t n_nodes, const int32_t *links
     const size_t m = (size_t)std::min<int64_t>(cap, *n_out);
     if (out_nodes) std::memcpy(out_nodes, out.data(), sizeof(pnr_node) * m);
     if (out_parent) std::memcpy(out_parent, par.data(), 4 * m);
+    return PNR_OK;
+}
+
+int pnr_reconstruct_stage(const pnr_node *nodes, int64_t n_nodes, const int32_t *links, int64_t n_links, float trace_rsmpl, float sig2radius,
+                          int refine_iter, float epsilon2, float group_radius, int stage, pnr_node *out_nodes, int64_t cap_nodes,
+                          int64_t *n_out_nodes, int32_t *out_links, int64_t cap_links, int64_t *n_out_links)
+{
+    PNR_REQUIRE(nodes && n_nodes >= 1 && n_out_nodes && n_out_links && (n_links == 0 || links), PNR_E_ARG, "null argument");
+    PNR_REQUIRE(stage >= advantra::RECON_N0RES && stage <= advantra::RECON_N2TREE, PNR_E_ARG, "stage %d outside [1, 4]", stage);
+    for (int64_t k = 0; k < 2 * n_links; k++) PNR_REQUIRE(links[k] >= 0 && links[k] < n_nodes, PNR_E_ARG, "link index out of range");
+    advantra::ReconParams rp;
+    if (trace_rsmpl > 0) rp.trace_rsmpl = trace_rsmpl;
+    if (sig2radius > 0) rp.sig2radius = sig2radius;
+    if (refine_iter > 0) rp.refine_iter = refine_iter;
+    if (epsilon2 > 0) rp.epsilon2 = epsilon2;
+    if (group_radius > 0) rp.group_radius = group_radius;
+    rp.threads = pnr::host_threads(pnr::Options());
+    std::vector<pnr_node> in(nodes, nodes + n_nodes), out;
+    std::vector<int32_t> lk(links, links + 2 * n_links), par, sl;
+    advantra::reconstruct(in, lk, rp, out, par, stage, &sl);
+    *n_out_nodes = (int64_t)out.size();
+    *n_out_links = (int64_t)sl.size() / 2;
+    if (out_nodes) std::memcpy(out_nodes, out.data(), sizeof(pnr_node) * (size_t)std::min<int64_t>(cap_nodes, *n_out_nodes));
+    if (out_links) std::memcpy(out_links, sl.data(), 8 * (size_t)std::min<int64_t>(cap_links, *n_out_links));
     return PNR_OK;
 }
 

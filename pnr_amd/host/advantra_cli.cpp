@@ -33,6 +33,7 @@ int main(int argc, char **argv)
         if (!strcmp(argv[i], "-v")) { advantra::settings().verbose = true; continue; }
         if (!strcmp(argv[i], "--timing")) { advantra::settings().timing = true; continue; }
         if (!strcmp(argv[i], "--save-midres")) { advantra::settings().save_midres = true; continue; }
+        if (!strcmp(argv[i], "--single-tree")) { advantra::settings().single_tree = true; continue; }
         if (!strcmp(argv[i], "--rng-seed") && i + 1 < argc) { advantra::settings().rng_seed = (uint32_t)strtoul(argv[++i], nullptr, 10); continue; }
         if (!strcmp(argv[i], "-d") && i + 1 < argc) { raw_dims = argv[++i]; continue; }
         if (!strcmp(argv[i], "-i")) { while (i + 1 < argc && argv[i + 1][0] != '-') infiles.push_back(argv[++i]); continue; }

@@ -535,7 +535,7 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
         for (;;) {
             R.tree.resize((size_t)cap);
             R.parent.resize((size_t)cap);
-            if (pnr_reconstruct(R.nodes.data(), nn, R.links.data(), nl, 0, 0, 0, 0, 0, 0, R.tree.data(), R.parent.data(), cap, &nt) != PNR_OK) {
+            if (pnr_reconstruct(R.nodes.data(), nn, R.links.data(), nl, 0, 0, 0, 0, 0, settings().single_tree ? -1 : 0, R.tree.data(), R.parent.data(), cap, &nt) != PNR_OK) {
                 fprintf(stderr, "%s\n", pnr_last_error());
                 pnr_destroy(ctx);
                 return false;
@@ -548,9 +548,25 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
     }
     auto t5 = clk::now();
     R.t_recon = secs(t4, t5);
-    R.swc_path = inimg_file + "_Advantra.swc"; // :2164
+    R.swc_path = inimg_file + (settings().single_tree ? "_Advantra1.swc" : "_Advantra.swc"); // :2152 / :2164
     save_treelist(R.tree, R.parent, R.swc_path, -1, 1.f, "Advantra", swc_comment(paras, p));
-    if (settings().save_midres) save_nodelist(R.nodes, R.links, inimg_file + "_n0_.swc"); // saveMidres tap (:2099)
+    if (settings().save_midres) { // the saveMidres taps of reconstruct() (:2098-2141)
+        save_nodelist(R.nodes, R.links, inimg_file + "_n0_.swc");
+        static const char *const names[] = {"", "_n0res_.swc", "_n1_.swc", "_n2_.swc", "_n2tree_.swc"};
+        for (int stage = 1; stage <= 4; stage++) {
+            int64_t sn = 0, sl = 0;
+            if (pnr_reconstruct_stage(R.nodes.data(), nn, R.links.data(), nl, 0, 0, 0, 0, 0, stage, nullptr, 0, &sn, nullptr, 0, &sl) != PNR_OK) break;
+            std::vector<pnr_node> tn((size_t)sn);
+            std::vector<int32_t> tl((size_t)(2 * sl));
+            if (pnr_reconstruct_stage(R.nodes.data(), nn, R.links.data(), nl, 0, 0, 0, 0, 0, stage, tn.data(), sn, &sn, tl.data(), sl, &sl) != PNR_OK) break;
+            if (stage < 4) save_nodelist(tn, tl, inimg_file + names[stage]);
+            else { // a tree list: every node carries its parent (or none)
+                std::vector<int32_t> par((size_t)sn, -1);
+                for (int64_t k = 0; k < sl; k++) par[(size_t)tl[(size_t)(2 * k)]] = tl[(size_t)(2 * k + 1)];
+                save_treelist(tn, par, inimg_file + names[stage], -1, 1.f, "", "");
+            }
+        }
+    }
     R.t_write = secs(t5, clk::now());
     printf("%s\n%lld trace nodes, %lld traces, %lld SMC iterations, %zu tree nodes | frangi %.3f s, seeds %.3f s, selection %.3f s, "
            "tracing %.3f s, reconstruct %.3f s\n",

@@ -42,7 +42,9 @@ struct Result {
 struct Settings {
     bool verbose = false;     // -v: per-trace progress and stop reasons in the reference's words (tracker.cpp:866,879,908,916; Advantra_plugin.cpp:2677)
     bool timing = false;      // --timing: the library's stage statistics on stderr (options trace_timing, seed_timing, recon_timing)
-    bool save_midres = false; // --save-midres: also write <inimg>_n0_.swc, the node graph before reconstruct() (:2099)
+    bool save_midres = false; // --save-midres: also write the plugin's saveMidres node lists (:2098-2141): <inimg>_n0_.swc (the node graph before
+                              // reconstruct()), _n0res_, _n1_, _n2_, _n2tree_
+    bool single_tree = false; // --single-tree: the plugin's ENFORCE_SINGLE_TREE branch (:81, :2142-2152): only the largest tree, written to <inimg>_Advantra1.swc
     uint32_t rng_seed = 42;   // --rng-seed: replaces srand(time(NULL)) of tracker.cpp:1003,1098
     // --ranks N: this process is rank `rank` of `world` processes of one host, one GPU each, that reconstruct ONE stack together
     // (z-slabs of Frangi / seeds, sorted seeds dealt round-robin, finished traces exchanged through shared memory: INTEGRATION.md);

@@ -338,6 +338,26 @@ void drop_small_trees(const List &X, List &Y, int min_size)
         for (int &v : Y[i].nbr) v = to[v];
 }
 
+// :546-589 (extract_largest_tree, the ENFORCE_SINGLE_TREE branch of reconstruct() :2142-2152) -- keep the largest tree of a tree list
+// only.  The reference measures a tree by the distance between consecutive roots, starting with root_curr = root_prev = 1: mirrored.
+void keep_largest_tree(const List &X, List &Y)
+{
+    const long n = (long)X.size();
+    long root_cur = 1, root_prev = 1, best = -(long)INT32_MAX, beg = -(long)INT32_MAX, end = -(long)INT32_MAX;
+    for (long i = 1; i <= n; i++)
+        if (i == n || X[(size_t)i].nbr.empty()) {
+            root_prev = root_cur;
+            root_cur = i;
+            if (root_cur - root_prev > best) { best = root_cur - root_prev; beg = root_prev; end = root_cur; }
+        }
+    std::vector<int> to((size_t)n, -1);
+    Y.clear();
+    for (long i = 0; i < n; i++)
+        if (i == 0 || (i >= beg && i < end)) { to[(size_t)i] = (int)Y.size(); Y.push_back(X[(size_t)i]); }
+    for (size_t i = 1; i < Y.size(); i++)
+        for (int &v : Y[i].nbr) v = to[(size_t)v];
+}
+
 // :714-778 -- resample the (one-directional) tree links
 void resample_tree(List &t, float step, int type)
 {
@@ -366,8 +386,23 @@ static std::atomic<bool> g_recon_timing{false};
 void set_recon_timing(bool on) { g_recon_timing.store(on, std::memory_order_relaxed); }
 bool recon_timing() { return g_recon_timing.load(std::memory_order_relaxed); }
 
+static void export_list(const List &g, bool tree, std::vector<pnr_node> &out_nodes, std::vector<int32_t> &out_links)
+{
+    out_nodes.resize(g.size());
+    out_links.clear();
+    for (size_t i = 0; i < g.size(); i++) {
+        const N &s = g[i];
+        out_nodes[i] = pnr_node{s.x, s.y, s.z, s.vx, s.vy, s.vz, s.corr, s.sig, s.type};
+        for (int j : s.nbr)
+            if (tree || (size_t)j > i || std::find(g[(size_t)j].nbr.begin(), g[(size_t)j].nbr.end(), (int)i) == g[(size_t)j].nbr.end()) {
+                out_links.push_back((int32_t)i); // tree lists: (child, parent); node lists: every undirected link once
+                out_links.push_back((int32_t)j);
+            }
+    }
+}
+
 void reconstruct(const std::vector<pnr_node> &nodes, const std::vector<int32_t> &links, const ReconParams &rp,
-                 std::vector<pnr_node> &out_nodes, std::vector<int32_t> &out_parent)
+                 std::vector<pnr_node> &out_nodes, std::vector<int32_t> &out_parent, int stop_after, std::vector<int32_t> *stage_links)
 {
     List n0(nodes.size());
     for (size_t i = 0; i < nodes.size(); i++) {
@@ -388,16 +423,28 @@ void reconstruct(const std::vector<pnr_node> &nodes, const std::vector<int32_t> 
         t_prev = t;
     };
     lap("graph", n0.size());
+    // stop_after (the saveMidres taps of :2098-2141): the list as it stands behind that stage, with its links
+    auto tap = [&](int stage, const List &g, bool tree) {
+        if (stop_after != stage || !stage_links) return false;
+        export_list(g, tree, out_nodes, *stage_links);
+        out_parent.clear();
+        return true;
+    };
     resample_links(n0, rp.trace_rsmpl);
     lap("resample_links", n0.size());
+    if (tap(RECON_N0RES, n0, false)) return;
     mean_shift(n0, rp.sig2radius, rp.refine_iter, rp.epsilon2, rp.threads);
     lap("mean_shift", n0.size());
+    if (tap(RECON_N1, n0, false)) return;
     group_spheres(n0, n2, rp.group_radius);
     lap("group_spheres", n2.size());
+    if (tap(RECON_N2, n2, false)) return;
     bfs_forest(n2, forest);
     lap("bfs_forest", forest.size());
-    drop_small_trees(forest, kept, rp.tree_size_min);
-    lap("drop_small", kept.size());
+    if (tap(RECON_N2TREE, forest, true)) return;
+    if (rp.single_tree) keep_largest_tree(forest, kept); // ENFORCE_SINGLE_TREE (:2142-2152)
+    else drop_small_trees(forest, kept, rp.tree_size_min);
+    lap(rp.single_tree ? "largest_tree" : "drop_small", kept.size());
     resample_tree(kept, 1.0f, 2 /* Node::AXON */);
     lap("resample_tree", kept.size());
     out_nodes.resize(kept.size());

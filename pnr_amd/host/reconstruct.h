@@ -20,7 +20,12 @@ struct ReconParams {          // Advantra_plugin.cpp:72-83
     float group_radius = 2.0f; // GROUP_RADIUS
     int tree_size_min = 10;    // TREE_SIZE_MIN
     int threads = 0;           // host threads of the mean-shift (its nodes are independent); 0 = one per CPU this process may use
+    bool single_tree = false;  // ENFORCE_SINGLE_TREE (:81, :2142-2152): keep the largest tree only (extract_largest_tree :546-589)
 };
+
+// the node lists reconstruct() passes through, in the order of the plugin's saveMidres taps (:2098-2141)
+enum { RECON_FINAL = 0, RECON_N0RES = 1 /* after interpolate_nodelist */, RECON_N1 = 2 /* after non_blurring */, RECON_N2 = 3 /* after group1 */,
+       RECON_N2TREE = 4 /* compute_trees: the BFS forest, (child, parent) links */ };
 
 // nodes[0] is the dummy; links = pairs (a,b): a.nbr.push_back(b); b.nbr.push_back(a).
 // out_nodes/out_parent: the tree list (index 0 dummy; parent -1 = root), as save_nodelist would write it.
@@ -29,7 +34,10 @@ struct ReconParams {          // Advantra_plugin.cpp:72-83
 void set_recon_timing(bool on);
 bool recon_timing();
 
+// stop_after != RECON_FINAL (with stage_links): out_nodes / *stage_links receive the list behind that stage instead (links as pairs:
+// every undirected link once; for RECON_N2TREE (child, parent)), out_parent is left empty.
 void reconstruct(const std::vector<pnr_node> &nodes, const std::vector<int32_t> &links, const ReconParams &rp,
-                 std::vector<pnr_node> &out_nodes, std::vector<int32_t> &out_parent);
+                 std::vector<pnr_node> &out_nodes, std::vector<int32_t> &out_parent, int stop_after = RECON_FINAL,
+                 std::vector<int32_t> *stage_links = nullptr);
 
 } // namespace advantra

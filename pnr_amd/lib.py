@@ -131,7 +131,7 @@ def load():
 PRODUCT_EXPORTS = ["pnr_last_error", "pnr_default_params", "pnr_create", "pnr_destroy", "pnr_set_stream", "pnr_synchronize",
                    "pnr_set_volume", "pnr_set_volume_device", "pnr_frangi", "pnr_get_frangi", "pnr_extract_seeds", "pnr_extract_seeds_range",
                    "pnr_zncc_batch", "pnr_score_filter_sort_seeds", "pnr_trace_batch", "pnr_replay_traces", "pnr_replay_traces_ctx",
-                   "pnr_frangi_slab", "pnr_quantise_j8", "pnr_soma", "pnr_get_soma", "pnr_trace_replay", "pnr_reconstruct", "pnr_set_profiling",
+                   "pnr_frangi_slab", "pnr_quantise_j8", "pnr_soma", "pnr_get_soma", "pnr_trace_replay", "pnr_reconstruct", "pnr_reconstruct_stage", "pnr_set_profiling",
                    "pnr_set_smc_driver", "pnr_get_kernel_ms", "pnr_reset_kernel_ms", "pnr_get_graph", "pnr_trace_replay_sharded",
                    "pnr_set_option", "pnr_get_option", "pnr_score_filter_seeds", "pnr_sort_seeds", "pnr_get_trace_log",
                    "pnr_shm_exchange_open", "pnr_shm_allgather", "pnr_shm_exchange_close",
@@ -572,6 +572,23 @@ def reconstruct(nodes, links, trace_rsmpl=0.0, sig2radius=0.0, refine_iter=0, ep
         if n.value <= cap:
             return out[:n.value].copy(), par[:n.value].copy()
         cap = int(n.value)
+
+
+def reconstruct_stage(nodes, links, stage, trace_rsmpl=0.0, sig2radius=0.0, refine_iter=0, epsilon2=0.0, group_radius=0.0):
+    """the node list behind a stage of reconstruct() (pnr_reconstruct_stage: 1 _n0res_, 2 _n1_, 3 _n2_, 4 _n2tree_) -> nodes, link pairs"""
+    L = load()
+    nodes = np.ascontiguousarray(nodes, NODE_DT)
+    links = np.ascontiguousarray(links, np.int32).reshape(-1, 2)
+    L.pnr_reconstruct_stage.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int,
+                                        C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    nn, nl = C.c_int64(), C.c_int64()
+    check(L.pnr_reconstruct_stage(nodes.ctypes.data, len(nodes), links.ctypes.data, len(links), trace_rsmpl, sig2radius, refine_iter, epsilon2,
+                                  group_radius, stage, None, 0, C.byref(nn), None, 0, C.byref(nl)))
+    out = np.zeros(nn.value, NODE_DT)
+    lk = np.zeros((nl.value, 2), np.int32)
+    check(L.pnr_reconstruct_stage(nodes.ctypes.data, len(nodes), links.ctypes.data, len(links), trace_rsmpl, sig2radius, refine_iter, epsilon2,
+                                  group_radius, stage, out.ctypes.data, len(out), C.byref(nn), lk.ctypes.data, len(lk), C.byref(nl)))
+    return out, lk
 
 
 def kernel_source_hash(names=("smc_phased.hip", "smc_device.h", "smc.hip", "ctx.h", "stream_sched.h")):

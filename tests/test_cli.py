@@ -195,6 +195,15 @@ def test_cli_verbose_prints_the_reference_trace_lines(tmp_path):
     r = run("-v", "--save-midres", "-f", "advantra_func", "-i", tif, "-p", *paras)
     assert r.returncode == 0 and quiet.returncode == 0, r.stderr
     assert open(tif + "_Advantra.swc").read() == swc_quiet and os.path.exists(tif + "_n0_.swc")
+    for tap in ("_n0res_", "_n1_", "_n2_", "_n2tree_"):  # the other saveMidres lists of reconstruct() (:2112-2141)
+        ids = swc_diff.read_swc(tif + tap + ".swc")[0]
+        assert len(ids) > 50, tap
+    # --single-tree: the plugin's ENFORCE_SINGLE_TREE branch (:2142-2152) writes the largest tree to <inimg>_Advantra1.swc
+    r1 = run("--single-tree", "-f", "advantra_func", "-i", tif, "-p", *paras)
+    assert r1.returncode == 0 and os.path.exists(tif + "_Advantra1.swc")
+    ids1, _, _, par1 = swc_diff.read_swc(tif + "_Advantra1.swc")
+    ids_all, _, _, par_all = swc_diff.read_swc(tif + "_Advantra.swc")
+    assert 10 < len(ids1) <= len(ids_all) and (np.asarray(par1) == -1).sum() == 1 and (np.asarray(par_all) == -1).sum() >= 1
     out = r.stdout
     ntr = out.count("\nTrace: ")
     ends = sum(out.count(k) for k in ("], DENSITY, nodespervol=4", "], success=0, corr=", "], TRACK LIMIT, niter=40", "], SOMA, idx="))

@@ -251,6 +251,55 @@ def test_reconstruct_with_nan_corr_nodes():
             assert np.array_equal(got_n[k], want_n[k], equal_nan=True), k
 
 
+def test_reconstruct_single_tree_and_stage_taps(oracle):
+    """the plugin's ENFORCE_SINGLE_TREE branch (Advantra_plugin.cpp:81, :2142-2152; extract_largest_tree :546-589: tree_size_min < 0)
+    against the oracle, and the saveMidres taps of reconstruct() (:2098-2141, pnr_reconstruct_stage): the lists behind the stages are
+    consistent with each other and with the final result"""
+    img = synth.synth(64, 56, 32, seed=2)
+    s, T, xc = _traces_from_oracle(oracle, img, [2.0], 24, 30, 2.0, nseeds=40)
+    nodes, links, _ = orc.replay(oracle, s, T, xc, 30, img.shape, 4, 1)
+    nodes = nodes.astype(lib.NODE_DT)
+    want_n, want_p = orc.reconstruct(oracle, nodes, links, tree_size_min=-1)
+    got_n, got_p = lib.reconstruct(nodes, links, tree_size_min=-1)
+    assert len(got_n) == len(want_n) > 10 and np.array_equal(got_p, want_p)
+    for k in got_n.dtype.names:
+        assert np.array_equal(got_n[k], want_n[k], equal_nan=True), k
+    assert (got_p[1:] == -1).sum() == 1                      # one tree
+    # three separate chains of 12 / 20 / 7 nodes: all three survive tree_size_min = 2, only the longest the single-tree branch
+    n = 12 + 20 + 7
+    ch = np.zeros(n + 1, lib.NODE_DT)
+    off = 1
+    lk = []
+    for c, m in enumerate((12, 20, 7)):
+        ch["x"][off:off + m] = 10 + 2.0 * np.arange(m)
+        ch["y"][off:off + m] = 10 + 40 * c
+        ch["z"][off:off + m] = 8
+        lk += [[off + i + 1, off + i] for i in range(m - 1)]
+        off += m
+    ch["sig"][1:] = 2.0
+    ch["corr"][1:] = np.linspace(0.9, 0.4, n)
+    ch["type"][1:] = 2
+    lk = np.array(lk, np.int32)
+    all_n, all_p = lib.reconstruct(ch, lk, tree_size_min=2)
+    one_n, one_p = lib.reconstruct(ch, lk, tree_size_min=-1)
+    wn, wp = orc.reconstruct(oracle, ch, lk, tree_size_min=-1)
+    assert (all_p[1:] == -1).sum() == 3 and (one_p[1:] == -1).sum() == 1 and len(one_n) < len(all_n)
+    assert np.array_equal(one_p, wp) and all(np.array_equal(one_n[k], wn[k], equal_nan=True) for k in wn.dtype.names)
+    assert np.all(np.abs(one_n["y"][1:] - 50) < 1e-3) and len(one_n) - 1 >= 20  # the 20-node chain (mean-shifted, grouped, resampled)
+    # stage taps: 1 resampled links (every link <= TRACE_RSMPL... at most ~1 voxel), 2 mean-shift keeps nodes and links, 3 grouping
+    # shrinks the list, 4 the BFS forest keeps every node of a tree of >= 2 nodes with at most one parent
+    n0r, l0r = lib.reconstruct_stage(nodes, links, 1)
+    n1, l1 = lib.reconstruct_stage(nodes, links, 2)
+    n2, l2 = lib.reconstruct_stage(nodes, links, 3)
+    n2t, l2t = lib.reconstruct_stage(nodes, links, 4)
+    assert len(n0r) >= len(nodes) and len(l0r) >= len(links)
+    d = np.sqrt(sum((n0r[k][l0r[:, 0]] - n0r[k][l0r[:, 1]]) ** 2 for k in "xyz"))
+    assert d.max() <= 1.0 + 1e-4
+    assert len(n1) == len(n0r) and np.array_equal(l1, l0r) and not np.array_equal(n1["x"], n0r["x"])
+    assert len(n2) < len(n1) and len(l2) > 0 and l2.max() < len(n2)
+    assert len(n2t) <= len(n2) and len(np.unique(l2t[:, 0])) == len(l2t) and l2t.max() < len(n2t)
+
+
 def test_reconstruct_degenerate_inputs():
     """only the dummy node; isolated nodes; a self-link and duplicate links (what a DENSITY stop can produce)"""
     dummy = np.zeros(1, lib.NODE_DT)
