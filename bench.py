@@ -328,7 +328,7 @@ def main():
                 dist.barrier()
                 dist.destroy_process_group()
             return
-        km = {g: ctx.kernel_ms(g) for g in ("gauss", "hessian_tile", "hessian_eigen", "j8", "seed_maxima", "zncc", "smc", "smc_sums", "smc_predict", "smc_update")}
+        km = {g: ctx.kernel_ms(g) for g in ("gauss", "hessian_tile", "hessian_eigen", "j8", "seed_maxima", "zncc", "smc", "smc_sums", "smc_predict", "smc_update", "smc_cube")}
         # The dominant kernels are the particle evaluation of the SMC step (tracker.cpp:1891-1964 is ONE evaluation: the gather and
         # the ordered ZNCC sums): ph_predict + ph_sample + ph_sums + ph_update with the phased driver (one launch of each per SMC
         # step over all active traces), smc_trace with the persistent one.  Algorithmic bytes: 8 corner bytes x
@@ -339,8 +339,9 @@ def main():
         Mtot = sum(len(ctx.table(f"model_wgt{s}")) for s in range(len(sigs)))
         groups_opt = ctx.get_option("groups")
         groups = groups_opt if groups_opt > 0 else (1 if world > 1 and a.mode == "shard" else 2)  # 0 = automatic (pnr_hip.h)
-        EV = ("smc_predict", "smc", "smc_sums", "smc_update")
-        KNAME = {"smc_predict": "ph_predict", "smc": "ph_sample<54, false>", "smc_sums": "ph_sums", "smc_update": "ph_update"} if a.driver == "phased" else {"smc": "smc_trace"}
+        # (ph_cube: the traces' cubes fetched from the image once per step; absent -- zero launches -- with option cube_copy = 0)
+        EV = ("smc_predict", "smc_cube", "smc", "smc_sums", "smc_update") if (a.driver == "phased" and km["smc_cube"][1] > 0) else ("smc_predict", "smc", "smc_sums", "smc_update")
+        KNAME = {"smc_predict": "ph_predict", "smc_cube": "ph_cube", "smc": "ph_sample<54, false, true>", "smc_sums": "ph_sums", "smc_update": "ph_update"} if a.driver == "phased" else {"smc": "smc_trace"}
         smc_n = km["smc"][1]
         smc_all_ms = sum(km[g][0] for g in EV)
         evals = st["iters"] * (a.np + 1)
@@ -384,7 +385,7 @@ def main():
                 # what the kernels' traffic is made of)
                 it_prof, st_prof = wl.get("smc_iterations"), wl.get("smc_steps")
                 scale = ((st["iters"] * a.steps / steps_smc) / (it_prof / st_prof)) if (it_prof and st_prof) else 1.0
-                for key in (("ph_predict", "ph_sample", "ph_sums", "ph_update") if a.driver == "phased" else ("smc_trace",)):
+                for key in (("ph_predict", "ph_cube", "ph_sample", "ph_sums", "ph_update") if a.driver == "phased" else ("smc_trace",)):
                     e = tj.get(key, {})
                     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
                         traffic_k[key] = (e["FETCH_SIZE"]["bytes_per_launch"] + e["WRITE_SIZE"]["bytes_per_launch"]) * scale

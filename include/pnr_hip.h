@@ -268,6 +268,7 @@ int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
  *   trace_timing, seed_timing (0/1) statistics on stderr | recon_timing (0/1) stage times of every pnr_reconstruct on stderr (process-wide: that call takes no context) | trace_log (0/1) keep every trace's end for pnr_get_trace_log | replay_batches (0/1), batch_growth, batch_max: rank batches instead
  *   of the streaming window | no_stash (0/1) persistent driver without the sample stash | exchange_block (0 = 256 KB / world) bytes per rank
  *   and exchange of pnr_trace_replay_sharded | frangi_prune (1) skip the eigen-solver below the first J8 level (pnr_get_frangi) |
+ *   cube_copy (1) phased driver: a trace's cube is fetched from the image once per step and copied by its sampling work-groups (0: each stages it itself) |
  *   tentative (1) the streaming scheduler pauses traces that a tentative replay of everything recorded so far cuts, and ends them
  *   itself once that verdict is final (fewer wasted SMC iterations; same graph).
  *   pnr_get_option also knows "host_threads_effective" and "frangi_recomputes" (how often pnr_get_frangi / pnr_quantise_j8 had to
@@ -277,7 +278,7 @@ int pnr_set_option(pnr_ctx *ctx, const char *key, int64_t value);
 int pnr_get_option(pnr_ctx *ctx, const char *key, int64_t *value);
 
 /* Per-kernel-group device time (HIP events on the ctx stream) accumulated since the last reset:
- * groups: "gauss","hessian_eigen","j8","seed_maxima","soma","zncc","smc" (sampling kernel; the whole trace kernel of the persistent driver),"smc_sums","smc_predict","smc_update".  Enabled by set_profiling. */
+ * groups: "gauss","hessian_eigen","j8","seed_maxima","soma","zncc","smc" (sampling kernel; the whole trace kernel of the persistent driver),"smc_sums","smc_predict","smc_update","smc_cube" (the traces' cubes fetched once per step).  Enabled by set_profiling. */
 int pnr_set_profiling(pnr_ctx *ctx, int enable);
 int pnr_get_kernel_ms(pnr_ctx *ctx, const char *group, double *ms, int64_t *launches);
 int pnr_reset_kernel_ms(pnr_ctx *ctx);

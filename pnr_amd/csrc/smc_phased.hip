@@ -47,6 +47,8 @@ struct PhState {
     float *stash;
     long long trace_floats;
     int stash_base; // first stash row of this trace group (the groups step concurrently: each has a region of its own)
+    unsigned char *cubes; // [stash_base + position][PH_CS * PH_PLANE] the traces' cubes in LDS layout, fetched from the image ONCE per step by ph_cube
+                          // (nullptr: every sampling work-group stages its cube from the image itself)
     int *list;     // [2][cap]: traces still running in iteration it: list[it & 1][0 .. cnt[it & 1])
     int *cnt;      // [2]
     int *ctr;      // [NT] sampling work-item counter of the current iteration
@@ -79,6 +81,56 @@ __device__ __forceinline__ unsigned int pose_hash(float x, float y, float z, flo
 // ngf = nch / 64 full groups of 64 lanes and a last group of rem = nch % 64 chains whose stash rows are R floats wide
 __device__ __forceinline__ int last_group_stride(int rem) { return rem > 32 ? 64 : (rem > 16 ? 32 : 16); }
 
+
+// Stage the rows of the cube the templates can reach: a wave-load fetches four (z,y) rows, 16 lanes x one unaligned dword each, NR of
+// them in flight per wave; wave `wv` of `nwv` takes the rows wv * 4 + sub, + nwv * 4, ...; `cube32` = the cube in LDS layout (LDS in
+// ph_sample, the compact global copy in ph_cube).  What made the first version slow (45 k cycles per work-group, 18 % of the kernel;
+// scripts/ph_stamps.py) was neither the memory latency (8, 12 or 23 loads in flight: the same), nor the unaligned addresses (aligned
+// dwords + DPP shift + v_alignbyte: the same), nor the path into LDS (LDS-DMA: global_load_lds_dword lands one 256-byte block per ~96
+// cycles and CU, 57 k cycles for a cube) but the address arithmetic: a division by the run-time row count per load and four byte
+// writes per dword.  The (plane, row) pair advances incrementally, and the rows are PH_PITCH = 56 bytes apart so that every dword
+// lands with one aligned 32-bit store (the last dword of a row carries two pad bytes).
+struct CubeRows { int ox, oy, oz, y0, y1, z0, z1; }; // the cube's origin in the volume and the rows / planes of it the templates can reach
+template <class DST>
+__device__ __forceinline__ void stage_cube_rows(const Vol &V, const CubeRows &R, int wv, int nwv, int lane, DST *cube32)
+{
+    static_assert(PH_PITCH % 4 == 0 && PH_PITCH >= PH_CS && PH_PITCH <= 64, "one dword per lane, 16 lanes per row");
+    constexpr int NR = 16;
+    typedef unsigned __attribute__((aligned(1))) u32u;
+    // dword d of a row holds the voxels x = 4 d .. 4 d + 3
+    const int sub = lane >> 4, l4 = (lane & 15) * 4, sx = l4;
+    const int y0 = R.y0, ny = R.y1 - y0, z0 = R.z0, nrows = (R.z1 - z0) * ny;
+    const i64 nvox = V.wh * V.l;
+    const int stride = nwv * 4;                       // rows between two loads of a lane
+    const int sq = stride / ny, sr = stride - sq * ny; // wave-uniform: one division per work-group
+    int r = wv * 4 + sub;
+    int zq = r / ny, yr = r - zq * ny;                 // plane / row of r, advanced without dividing again
+    for (; r - sub < nrows; ) { // wave-uniform trip count (r - sub is the wave's first row of this round)
+        unsigned v[NR];
+        int at[NR];
+        bool ok[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            ok[j] = r < nrows;
+            const int zz = z0 + (ok[j] ? zq : 0), yy = y0 + (ok[j] ? yr : 0);
+            const int zg = R.oz + zz < V.l ? R.oz + zz : V.l - 1, yg = R.oy + yy < V.h ? R.oy + yy : V.h - 1;
+            const i64 idx = (i64)zg * V.wh + (i64)yg * V.w + R.ox + sx;
+            if (idx + 3 < nvox) {
+                v[j] = *(const u32u *)(V.img + idx);
+            } else { // the last bytes of the volume: byte loads, clamped (values past the row end are never addressed)
+                v[j] = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[j] |= (unsigned)V.img[idx + q < nvox ? idx + q : nvox - 1] << (8 * q);
+            }
+            at[j] = (zz * PH_PLANE + yy * PH_PITCH + l4) >> 2;
+            r += stride; zq += sq; yr += sr;
+            if (yr >= ny) { yr -= ny; zq++; }
+        }
+#pragma unroll
+        for (int j = 0; j < NR; j++)
+            if (ok[j] && l4 < PH_PITCH) cube32[at[j]] = v[j];
+    }
+}
 
 #ifdef PNR_SMC_STAMPS
 // diagnostic build only: shader-clock sums over the phases of ph_predict ([0..6], [7] = work-groups) and ph_update ([8..14], [15])
@@ -365,13 +417,30 @@ __global__ __launch_bounds__(256) void ph_predict(Tab T, TabX X, PhState P, cons
 #endif
 }
 
+// The cube of every trace of the step, fetched from the image ONCE (PH_CUBE_SPLIT work-groups per trace) into the compact copy the
+// sampling work-groups load (PhState::cubes).  Runs between ph_predict (which places the cube) and ph_sample.
+// Small work-groups (four waves, one per SIMD): they find room beside the other trace group's sampling work-groups, which a
+// 1024-thread work-group only does once one of those has drained (24 us per launch instead of the memory latency it needs).
+constexpr int PH_CUBE_SPLIT = 16, PH_CUBE_THREADS = 256;
+__global__ __launch_bounds__(PH_CUBE_THREADS) void ph_cube(Vol V, PhState P, int lp, int nslots)
+{
+    const int slot = blockIdx.x % nslots, part = blockIdx.x / nslots, tid = threadIdx.x;
+    if (slot >= P.cnt[lp]) return;
+    const int tr = P.list[lp * P.cap + slot];
+    const int *fl = P.flags + (i64)tr * FL_N;
+    if (fl[FL_PAUSE]) return;
+    const CubeRows R = {fl[FL_OX], fl[FL_OY], fl[FL_OZ], fl[FL_Y0], fl[FL_Y1], fl[FL_Z0], fl[FL_Z1]};
+    unsigned *dst = (unsigned *)(P.cubes + (i64)(P.stash_base + slot) * ((i64)PH_CS * PH_PLANE));
+    stage_cube_rows(V, R, part * (PH_CUBE_THREADS >> 6) + (tid >> 6), PH_CUBE_SPLIT * (PH_CUBE_THREADS >> 6), tid & 63, dst);
+}
+
 #ifdef PNR_SMC_STAMPS
 // diagnostic build only (make stamps): shader-clock sums over the sampling work-groups: [0] cube staging, [1] item loop of wave 0,
 // [2] work-groups, [3] items taken by wave 0 of each work-group
 __device__ unsigned long long g_ph_stamps[8];
 #endif
 
-template <int CS, bool IS2D>
+template <int CS, bool IS2D, bool GCUBE>
 __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) void ph_sample(Vol V, Tab T, TabX X, PhState P, int np, int ni, int it_arg, int lp, int nslots)
 {
     extern __shared__ unsigned char cube[];
@@ -394,51 +463,25 @@ __global__ __launch_bounds__(PH_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5
     if (Bx.ox + Bx.oy + Bx.oz + fl[FL_Y0] + fl[FL_Y1] + fl[FL_Z0] + fl[FL_Z1] == -12345) return; // the flags have landed
     const unsigned long long st0b = __builtin_amdgcn_s_memtime();
 #endif
-    { // Stage the rows of the cube the templates can reach: a wave-load fetches four (z,y) rows, 16 lanes x one unaligned dword
-      // each, NR of them in flight per wave.  What made the first version slow (45 k cycles per work-group, 18 % of the kernel;
-      // scripts/ph_stamps.py) was neither the memory latency (8, 12 or 23 loads in flight: the same), nor the unaligned addresses
-      // (aligned dwords + DPP shift + v_alignbyte: the same), nor the path into LDS (LDS-DMA: global_load_lds_dword lands one
-      // 256-byte block per ~96 cycles and CU, 57 k cycles for a cube) but the address arithmetic: a division by the run-time row
-      // count per load and four byte writes per dword.  The (plane, row) pair now advances incrementally, and the rows are
-      // PH_PITCH = 56 bytes apart in LDS so that every dword lands with one aligned ds_write_b32 (the last dword of a row carries
-      // two pad bytes).
-        static_assert(PH_PITCH % 4 == 0 && PH_PITCH >= PH_CS && PH_PITCH <= 64, "one dword per lane, 16 lanes per row");
-        constexpr int NR = 16;
-        typedef unsigned __attribute__((aligned(1))) u32u;
-        // dword d of a row holds the voxels x = 4 d .. 4 d + 3
-        const int lane = tid & 63, wv = tid >> 6, nwv = B >> 6, sub = lane >> 4, l4 = (lane & 15) * 4, sx = l4;
-        const int y0 = fl[FL_Y0], ny = fl[FL_Y1] - y0, z0 = fl[FL_Z0], nrows = (fl[FL_Z1] - z0) * ny;
-        const i64 nvox = V.wh * V.l;
-        unsigned *const cube32 = (unsigned *)cube;
-        const int stride = nwv * 4;                       // rows between two loads of a lane
-        const int sq = stride / ny, sr = stride - sq * ny; // wave-uniform: one division per work-group
-        int r = wv * 4 + sub;
-        int zq = r / ny, yr = r - zq * ny;                 // plane / row of r, advanced without dividing again
-        for (; r - sub < nrows; ) { // wave-uniform trip count (r - sub is the wave's first row of this round)
-            unsigned v[NR];
-            int at[NR];
-            bool ok[NR];
-#pragma unroll
-            for (int j = 0; j < NR; j++) {
-                ok[j] = r < nrows;
-                const int zz = z0 + (ok[j] ? zq : 0), yy = y0 + (ok[j] ? yr : 0);
-                const int zg = Bx.oz + zz < V.l ? Bx.oz + zz : V.l - 1, yg = Bx.oy + yy < V.h ? Bx.oy + yy : V.h - 1;
-                const i64 idx = (i64)zg * V.wh + (i64)yg * V.w + Bx.ox + sx;
-                if (idx + 3 < nvox) {
-                    v[j] = *(const u32u *)(V.img + idx);
-                } else { // the last bytes of the volume: byte loads, clamped (values past the row end are never addressed)
-                    v[j] = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) v[j] |= (unsigned)V.img[idx + q < nvox ? idx + q : nvox - 1] << (8 * q);
-                }
-                at[j] = (zz * PH_PLANE + yy * PH_PITCH + l4) >> 2;
-                r += stride; zq += sq; yr += sr;
-                if (yr >= ny) { yr -= ny; zq++; }
-            }
-#pragma unroll
-            for (int j = 0; j < NR; j++)
-                if (ok[j] && l4 < PH_PITCH) cube32[at[j]] = v[j];
+    if constexpr (GCUBE) {
+        // The cube was fetched from the image once, by ph_cube, into a compact copy in LDS layout: every work-group of the trace copies
+        // the planes the templates can reach with 16-byte loads and stores (the planes are whole multiples of 16 bytes).  Fetched here by
+        // every work-group, the 54-byte rows cost whole 128-byte lines of the image each -- 0.42 GB of HBM reads per 106-trace step,
+        // 13 % of the evaluation's traffic -- and a dword load with its address arithmetic per four voxels.
+        static_assert(PH_PLANE % 16 == 0, "whole uint4 per plane");
+        const int z0 = fl[FL_Z0], z1 = fl[FL_Z1];
+        const uint4 *src = (const uint4 *)(P.cubes + (i64)(P.stash_base + slot) * ((i64)PH_CS * PH_PLANE) + (i64)z0 * PH_PLANE);
+        uint4 *dst = (uint4 *)(cube + (size_t)z0 * PH_PLANE);
+        const int n16 = (z1 - z0) * (PH_PLANE / 16);
+        int i = tid;
+        for (; i + 3 * B < n16; i += 4 * B) { // four loads in flight per thread
+            const uint4 a0 = src[i], a1 = src[i + B], a2 = src[i + 2 * B], a3 = src[i + 3 * B];
+            dst[i] = a0; dst[i + B] = a1; dst[i + 2 * B] = a2; dst[i + 3 * B] = a3;
         }
+        for (; i < n16; i += B) dst[i] = src[i];
+    } else {
+        const CubeRows R = {Bx.ox, Bx.oy, Bx.oz, fl[FL_Y0], fl[FL_Y1], fl[FL_Z0], fl[FL_Z1]};
+        stage_cube_rows(V, R, tid >> 6, B >> 6, tid & 63, (unsigned *)cube);
     }
     __syncthreads();
 #ifdef PNR_SMC_STAMPS
@@ -1006,7 +1049,7 @@ struct pnr_phased {
 static void phased_free(pnr_phased *h)
 {
     hipFree(h->P.part); hipFree(h->P.prior); hipFree(h->P.idxres); hipFree(h->P.corr); hipFree(h->P.xcs);
-    hipFree(h->P.stash); hipFree(h->P.list); hipFree(h->P.cnt) /* (and the flags behind the counters) */; hipFree(h->P.ctr); hipFree(h->P.uidx); hipFree(h->P.cmap); hipFree(h->d_s6);
+    hipFree(h->P.stash); hipFree(h->P.cubes); hipFree(h->P.list); hipFree(h->P.cnt) /* (and the flags behind the counters) */; hipFree(h->P.ctr); hipFree(h->P.uidx); hipFree(h->P.cmap); hipFree(h->d_s6);
     hipFree(h->O.T); hipFree(h->O.stop); hipFree(h->O.xc); hipFree(h->O.xfilt); hipFree(h->O.idxres); hipFree(h->O.neff);
     h->P = PhState{};
     h->O = TraceOut{};
@@ -1098,6 +1141,23 @@ static int pick_nsplit(int active, int ncu, int max_split, int x10 /* work-group
     return ns < 1 ? 1 : (ns > max_split ? max_split : ns);
 }
 
+// the sampling launch of a step: the traces' cubes fetched once into their compact copies (ph_cube), then the sampling work-groups
+static void launch_cube(hipStream_t st, const Vol &V, const PhState &P, int active, int lp)
+{
+    hipLaunchKernelGGL(ph_cube, dim3((unsigned)(active * PH_CUBE_SPLIT)), dim3(PH_CUBE_THREADS), 0, st, V, P, lp, active);
+}
+static void launch_sample(hipStream_t st, const Vol &V, const Tab &T, const TabX &X, const PhState &P, int np, int ni, int it, int lp, int active, int nsplit, size_t cube_bytes)
+{
+    const dim3 grid((unsigned)(active * nsplit)), blk(PH_THREADS);
+    if (P.cubes) {
+        if (V.l == 1) hipLaunchKernelGGL((ph_sample<PH_CS, true, true>), grid, blk, cube_bytes, st, V, T, X, P, np, ni, it, lp, active);
+        else hipLaunchKernelGGL((ph_sample<PH_CS, false, true>), grid, blk, cube_bytes, st, V, T, X, P, np, ni, it, lp, active);
+    } else {
+        if (V.l == 1) hipLaunchKernelGGL((ph_sample<PH_CS, true, false>), grid, blk, cube_bytes, st, V, T, X, P, np, ni, it, lp, active);
+        else hipLaunchKernelGGL((ph_sample<PH_CS, false, false>), grid, blk, cube_bytes, st, V, T, X, P, np, ni, it, lp, active);
+    }
+}
+
 struct PhEnv {
     Vol V; Tab T; TabX X; PhState P;
     int np, ni, S, np_pad, ng, ncu, max_split, dbg_iters;
@@ -1117,6 +1177,9 @@ static int ensure_stash(pnr_ctx *c, pnr_phased *h, int64_t traces, long long tra
     (void)hipFree(h->P.stash);
     h->P.stash = nullptr; h->cap_stash = 0;
     PNR_HIP(hipMalloc(&h->P.stash, (size_t)traces * trace_floats * 4));
+    (void)hipFree(h->P.cubes);
+    h->P.cubes = nullptr;
+    PNR_HIP(hipMalloc(&h->P.cubes, (size_t)traces * PH_CS * PH_PLANE)); // the compact cubes (ph_cube), one per list position as well
     h->cap_stash = traces;
     // a stale stash value is only ever read for a chain whose result is discarded, but keep it finite
     PNR_HIP(hipMemsetAsync(h->P.stash, 0, (size_t)traces * trace_floats * 4, c->stream));
@@ -1218,8 +1281,11 @@ static int phased_env(pnr_ctx *c, int64_t want, int dbg_iters, bool xfilt, bool 
     E.max_split = std::max(1, c->opt.max_split);
     PNR_REQUIRE(E.upd_lds <= 160 * 1024, PNR_E_ARG, "np=%d with %d scales needs %zu B of LDS in the update step (limit 160 KB)", np, S, E.upd_lds);
     PNR_HIP(hipFuncSetAttribute((const void *)ph_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.upd_lds));
-    PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
-    PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
+    PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
+    PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
+    PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
+    PNR_HIP(hipFuncSetAttribute((const void *)ph_sample<PH_CS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)E.cube_bytes));
+    if (!c->opt.cube_copy) E.P.cubes = nullptr; // option "cube_copy" = 0: every sampling work-group stages its cube from the image itself
     return PNR_OK;
 }
 
@@ -1281,11 +1347,13 @@ int pnr_trace_run_phased(pnr_ctx *c, const pnr_seed *seeds, int64_t n, int32_t *
             c->tic(st);
             hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), ph_predict_lds(np, P.dedup), st, T, X, P, (const float *)h->d_s6, V, np, ni, it, it & 1, CS, ph_tbl(np));
             c->toc("smc_predict", 1, st);
+            if (P.cubes) {
+                c->tic(st);
+                launch_cube(st, V, P, active, it & 1);
+                c->toc("smc_cube", 1, st);
+            }
             c->tic(st);
-            if (V.l == 1)
-                hipLaunchKernelGGL((ph_sample<CS, true>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), cube_bytes, st, V, T, X, P, np, ni, it, it & 1, active);
-            else
-                hipLaunchKernelGGL((ph_sample<CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), cube_bytes, st, V, T, X, P, np, ni, it, it & 1, active);
+            launch_sample(st, V, T, X, P, np, ni, it, it & 1, active, nsplit, cube_bytes);
             c->toc("smc", 1, st);
             c->tic(st);
             if (sums_deep(c, active, 1))
@@ -1437,7 +1505,8 @@ struct PhasedEngine final : pnr::StreamEngine {
         if (rc) { msg = pnr_last_error(); return rc; }
         gcap = ncap;
         E.P.stash = h->P.stash;
-        for (int k = 0; k < pnr_phased::MAXG; k++) { grp[k].P.stash = h->P.stash; grp[k].P.stash_base = (k < ngroups ? k : 0) * gcap; }
+        if (E.P.cubes) E.P.cubes = h->P.cubes;
+        for (int k = 0; k < pnr_phased::MAXG; k++) { grp[k].P.stash = h->P.stash; grp[k].P.cubes = E.P.cubes; grp[k].P.stash_base = (k < ngroups ? k : 0) * gcap; }
         return PNR_OK;
     }
     int launch(int g, int active, int poll, int lag) override
@@ -1462,11 +1531,13 @@ struct PhasedEngine final : pnr::StreamEngine {
             if (prof) c->tic(st, k > 0); // (the first step of a poll follows the admission copies: its own opening event)
             hipLaunchKernelGGL(ph_predict, dim3(active), dim3(256), ph_predict_lds(np, P.dedup), st, E.T, E.X, P, (const float *)h->d_s6, E.V, np, ni, -1, lp, PH_CS, ph_tbl(np));
             if (prof) c->toc("smc_predict", 1, st, pw);
+            if (P.cubes) {
+                if (prof) c->tic(st, true);
+                launch_cube(st, E.V, P, active, lp);
+                if (prof) c->toc("smc_cube", 1, st, pw);
+            }
             if (prof) c->tic(st, true);
-            if (E.V.l == 1)
-                hipLaunchKernelGGL((ph_sample<PH_CS, true>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
-            else
-                hipLaunchKernelGGL((ph_sample<PH_CS, false>), dim3((unsigned)(active * nsplit)), dim3(PH_THREADS), E.cube_bytes, st, E.V, E.T, E.X, P, np, ni, -1, lp, active);
+            launch_sample(st, E.V, E.T, E.X, P, np, ni, -1, lp, active, nsplit, E.cube_bytes);
             if (prof) c->toc("smc", 1, st, pw);
             if (prof) c->tic(st, true);
             if (sums_deep(c, active, sharing))

@@ -16,7 +16,7 @@ rows = []
 for f in glob.glob("$OUT/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 def short(n):
-    for k in ("ph_predict", "ph_sample", "ph_sums", "ph_update", "ph_poll", "copyBuf", "fillBuffer"):
+    for k in ("ph_predict", "ph_cube", "ph_sample", "ph_sums", "ph_update", "ph_poll", "copyBuf", "fillBuffer"):
         if k in n: return k
     return n.split("(")[0][-20:]
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?")) for r in rows]

@@ -13,7 +13,7 @@ OUT=$ROOT/gpurun_out/traffic
 rm -rf $OUT && mkdir -p $OUT
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --output-format csv -d $OUT/calib_$ctr -- $ROOT/scripts/probes/fetch_calib > $OUT/calib_$ctr.log 2>&1
-  rocprofv3 --pmc $ctr --kernel-include-regex "smc_trace|ph_predict|ph_sample|ph_sums|ph_update|hessian_tile|eigen_queue|gauss|j8_kernel|layer_maxima" --output-format csv -d $OUT/bench_$ctr -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra "$@" > $OUT/bench_$ctr.json 2> $OUT/bench_$ctr.err
+  rocprofv3 --pmc $ctr --kernel-include-regex "smc_trace|ph_predict|ph_cube|ph_sample|ph_sums|ph_update|hessian_tile|eigen_queue|gauss|j8_kernel|layer_maxima" --output-format csv -d $OUT/bench_$ctr -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra "$@" > $OUT/bench_$ctr.json 2> $OUT/bench_$ctr.err
 done
 python - <<PY
 import csv, glob, collections, json
@@ -22,7 +22,7 @@ def load(pat):
     for f in glob.glob(pat, recursive=True):
         for r in csv.DictReader(open(f)):
             import re
-            m = re.search(r'(smc_trace|ph_predict|ph_sample|ph_sums|ph_update|hessian_tile|eigen_queue|gauss_xy_u8|gauss_x_u8|gauss_axis_t|gauss_axis|j8_kernel|layer_maxima|rd|wr|fillBuffer)', r['Kernel_Name'])
+            m = re.search(r'(smc_trace|ph_predict|ph_cube|ph_sample|ph_sums|ph_update|hessian_tile|eigen_queue|gauss_xy_u8|gauss_x_u8|gauss_axis_t|gauss_axis|j8_kernel|layer_maxima|rd|wr|fillBuffer)', r['Kernel_Name'])
             k = m.group(1) if m else r['Kernel_Name'][:30]
             agg[(k, r['Counter_Name'])][0] += float(r['Counter_Value']); agg[(k, r['Counter_Name'])][1] += 1
     return agg

@@ -41,22 +41,24 @@ def find(usage, frag):
 
 def test_register_and_scratch_budgets(compiled):
     usage, _ = compiled
-    smp, _ = find(usage, "ph_sampleILi54ELb0EE")   # 3-D stacks
-    smp2, _ = find(usage, "ph_sampleILi54ELb1EE")  # single slice
+    smp, _ = find(usage, "ph_sampleILi54ELb0ELb1EE")   # 3-D stacks (the cube copied from ph_cube's compact copy)
+    smp2, _ = find(usage, "ph_sampleILi54ELb1ELb1EE")  # single slice
     shallow, _ = find(usage, "ph_sumsILb0EE")
     deep, _ = find(usage, "ph_sumsILb1EE")
     assert smp["VGPRs"] <= 96 and smp2["VGPRs"] <= 96, (smp, smp2)          # 4 waves x 96 + one ph_sums wave <= 512
     assert smp["ScratchSize"] <= 32 and smp2["ScratchSize"] <= 32, (smp, smp2)  # a handful of dwords, see the ISA test below
     assert shallow["VGPRs"] <= 96 and shallow["ScratchSize"] == 0, shallow   # beside four sampling waves with room to spare
     assert deep["VGPRs"] <= 128 and deep["ScratchSize"] == 0, deep          # 4 x 96 + 128 = 512
-    for frag in ("ph_predict", "ph_update"):
+    own, _ = find(usage, "ph_sampleILi54ELb0ELb0EE")  # option cube_copy = 0: every work-group stages its cube from the image
+    assert own["VGPRs"] <= 96 and own["ScratchSize"] <= 32, own
+    for frag in ("ph_predict", "ph_update", "ph_cube"):
         u, _ = find(usage, frag)
         assert u["ScratchSize"] == 0 and u["VGPRs"] <= 128, (frag, u)
 
 
 def test_ph_sample_scratch_stays_outside_the_sample_loops(compiled):
     usage, asm = compiled
-    _, name = find(usage, "ph_sampleILi54ELb0EE")
+    _, name = find(usage, "ph_sampleILi54ELb0ELb1EE")
     start = next(i for i, ln in enumerate(asm) if ln.startswith(name + ":"))
     end = next(i for i in range(start, len(asm)) if asm[i].startswith(".Lfunc_end"))
     depth, worst, n = 0, 0, 0
