@@ -378,6 +378,7 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
         return false;
     }
     pnr_set_option(ctx, "local_ranks", world);
+    const auto t_created = clk::now();
     Result R;
     bool ok = true;
     auto run_soma = [&]() { // SOMA EXTR. (:2426-2486): erosion, xy blur, max-entropy threshold, regions -> soma nodes
@@ -394,6 +395,7 @@ bool reconstruction_func(const unsigned char *data1d, long long w, long long h, 
     auto t0 = clk::now(), t1 = t0, t2 = t0;
     if (!sharded) {
         ok = pnr_set_volume(ctx, data1d, w, h, l) == PNR_OK;
+        if (settings().timing) fprintf(stderr, "[pnr host] context %.3f s, upload of %.2f GB %.3f s\n", secs(t_begin, t_created), (double)(w * h * l) / 1e9, secs(t_created, clk::now()));
         if (ok) run_soma();
         t0 = clk::now();
         ok = ok && pnr_frangi(ctx, &R.Jmin, &R.Jmax) == PNR_OK; // :2496-2512

@@ -21,7 +21,7 @@ for rep in range(2):  # (the first run pays the page cache and the driver's firs
     pr = subprocess.run(cmd, capture_output=True, text=True)
     wall = time.time() - t0
     for ln in pr.stderr.splitlines():  # (--timing: the stages of reconstruct())
-        if ln.startswith("[pnr reconstruct]") or ln.startswith("[pnr trace]"): print(ln, file=sys.stderr)
+        if ln.startswith("[pnr reconstruct]") or ln.startswith("[pnr trace]") or ln.startswith("[pnr host]"): print(ln, file=sys.stderr)
     m = re.search(r"wall: load ([\d.]+) s, context \+ upload ([\d.]+) s, frangi ([\d.]+) s, seeds ([\d.]+) s, selection ([\d.]+) s, tracing ([\d.]+) s, reconstruct ([\d.]+) s, write ([\d.]+) s \| total ([\d.]+) s", pr.stdout)
     m2 = re.search(r"(\d+) trace nodes, (\d+) traces, (\d+) SMC iterations, (\d+) tree nodes", pr.stdout)
     if not m:

@@ -244,7 +244,7 @@ def test_bench_gpus_2_starts_two_ranks_and_matches_one_gpu():
     assert two["counts"]["traces_used"] == one["counts"]["traces_used"]
     for k in ("roofline", "roofline_sample", "roofline_sums"):
         assert two[k]["frac"] > 0 and one[k]["frac"] > 0
-    assert one["roofline"]["kernel"] == "ph_predict+ph_sample<54, false>+ph_sums+ph_update" and one["roofline"]["dominant_by_device_time"] in one["roofline"]["kernel"]
+    assert one["roofline"]["kernel"] == "ph_predict+ph_cube+ph_sample<54, false, true>+ph_sums+ph_update" and one["roofline"]["dominant_by_device_time"] in one["roofline"]["kernel"]
 
 
 def test_bench_gpus_2_with_the_rccl_shaped_exchange():
