@@ -300,11 +300,20 @@ __global__ __launch_bounds__(64 * GT) void gauss_axis_t(const float *__restrict_
     const float *base = in + (i64)o * other_stride;
     constexpr int rows = TAT + 2 * L;
     if (x < w) {
-#pragma unroll 4
-        for (int r = grp; r < rows; r += GT) {
-            int a = a0 - L + r;
+        // all of a thread's rows requested before the first is stored (one memory latency per work-group)
+        constexpr int NITA = (rows + GT - 1) / GT;
+        float rv[NITA];
+#pragma unroll
+        for (int i = 0; i < NITA; i++) {
+            const int r = grp + GT * i;
+            int a = a0 - L + (r < rows ? r : rows - 1);
             a = a < 0 ? 0 : (a > n_axis - 1 ? n_axis - 1 : a);
-            s_in[r * 64 + lane] = base[(i64)a * axis_stride + x];
+            rv[i] = base[(i64)a * axis_stride + x];
+        }
+#pragma unroll
+        for (int i = 0; i < NITA; i++) {
+            const int r = grp + GT * i;
+            if (i + 1 < NITA || r < rows) s_in[r * 64 + lane] = rv[i];
         }
     }
     __syncthreads();
@@ -352,12 +361,25 @@ __global__ __launch_bounds__(256) void gauss_xy_u8_t(const uint8_t *__restrict__
         const int a = (x0 - L) & ~3;
         mis = (x0 - L) - a;
         typedef unsigned __attribute__((aligned(1))) u32u;
-        for (int e = tid; e < NR * NDW; e += 256) {
-            const int r = e / NDW, d = e - r * NDW;
+        // every dword of the tile is requested before the first one is stored: a thread's NIT loads are in flight together (one
+        // memory latency per work-group instead of NIT in a row -- the loop form waited for each load with vmcnt(0), ten times at
+        // L = 18, which was a third of the kernel's time)
+        constexpr int NE = NR * NDW, NIT = (NE + 255) / 256;
+        unsigned qv[NIT];
+        int so[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int e = tid + 256 * i;
+            const bool on = i + 1 < NIT || e < NE;
+            const int r = (on ? e : 0) / NDW, d = (on ? e : 0) - r * NDW;
             int y = y0 - L + r;
             y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-            *(unsigned *)(s_u8 + r * PB + 4 * d) = *(const u32u *)(plane + (i64)y * w + a + 4 * d);
+            so[i] = on ? r * PB + 4 * d : -1;
+            qv[i] = on ? *(const u32u *)(plane + (i64)y * w + a + 4 * d) : 0u;
         }
+#pragma unroll
+        for (int i = 0; i < NIT; i++)
+            if (i + 1 < NIT || so[i] >= 0) *(unsigned *)(s_u8 + so[i]) = qv[i];
     } else {
         for (int e = tid; e < NR * SPAN; e += 256) { // clamp-to-edge in x and y (frangi.cpp:690, :725)
             const int r = e / SPAN, cidx = e - r * SPAN;
@@ -742,14 +764,31 @@ __device__ __forceinline__ float td2(const Tile &T, int ci, int ni, int co, int 
     return td1<AI>(T, 0, 0, 0, ci, ni) - td1<AI>(T, -ox, -oy, -oz, ci - same, ni);
 }
 
+// The same second derivative where every rule is the centred one (no voxel of the stencil within 2 of a border), times sigma^2:
+// td2 computes 0.5 (0.5 a - 0.5 b) with a, b two f32 differences, then x s2.  Scaling by a power of two is exact and commutes with
+// rounding (no operand here can underflow: a difference of two Gaussian sums of a u8 image is 0 or above 1e-12), so that value is
+// fl(fl(a - b) x (0.25 s2)) -- three subtractions and one multiplication instead of three, three and one: the same bits (the golden
+// Hessians decide, tests/test_gpu_frangi.py) for 18 vector instructions per voxel less in a kernel that issues ~90.
+template <int AI, int AO>
+__device__ __forceinline__ float td2c(const Tile &T, float q4)
+{
+    constexpr int ix = AI == 0, iy = AI == 1, iz = AI == 2, ox = AO == 0, oy = AO == 1, oz = AO == 2;
+    const float a = t_at(T, ox + ix, oy + iy, oz + iz) - t_at(T, ox - ix, oy - iy, oz - iz);
+    const float b = t_at(T, -ox + ix, -oy + iy, -oz + iz) - t_at(T, -ox - ix, -oy - iy, -oz - iz);
+    return (a - b) * q4;
+}
+
 struct HessQueue {
     float *h;            // [region][6][HT_REGION]
     unsigned int *idx;   // [region][HT_REGION]: (z - z0) << HT_POSBITS | y in tile << 6 | x in tile
     unsigned int *count; // [region]
 };
 
+#ifndef PNR_HT_EU
+#define PNR_HT_EU 8
+#endif
 template <bool DUMP>
-__global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restrict__ F, int w, int h, int l, int tiles_x, int tiles_y, int zc0, int zc1,
+__global__ __launch_bounds__(HT_THREADS) __attribute__((amdgpu_waves_per_eu(PNR_HT_EU, 8))) void hessian_tile(const float *__restrict__ F, int w, int h, int l, int tiles_x, int tiles_y, int zc0, int zc1,
                                                            float s2, HessQueue Q, unsigned int *__restrict__ minmax, int first, int zs0, int zs1, HessOut dump,
                                                            float two_c2, int prune)
 {
@@ -803,10 +842,13 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
         gofs[q] = (i64)clampi(y0 - 2 + r, h - 1) * w + clampi(x0 - 2 + cc, w - 1);
     }
     struct PlaneVals { float v[HT_LD]; };
+    // (every thread loads HT_LD elements -- a thread without a last element re-reads element 0 and drops it in put(): a load behind an
+    // exec-mask branch makes the number of loads in flight depend on the path, and the compiler then waits for ALL of them, vmcnt(0),
+    // where the ring needs the oldest plane only)
     auto fetch = [&](int zp, PlaneVals &pv) {
         const i64 zo = (i64)clampi(zp, l - 1) * wh;
 #pragma unroll
-        for (int q = 0; q < HT_LD; q++) pv.v[q] = (q + 1 < HT_LD || hasv[q]) ? F[zo + gofs[q]] : 0.f;
+        for (int q = 0; q < HT_LD; q++) pv.v[q] = F[zo + gofs[q]];
     };
     auto put = [&](int slot, const PlaneVals &pv) {
 #pragma unroll
@@ -834,16 +876,22 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
     bool zero_here = false;
     const double s2max = s_s2max; // (written before the barrier above)
     const float s2max_f = (float)(s2max * 0.99999);
+    const float q4 = 0.25f * s2; // (exact)
     // One plane of the march.  `s0` = ring slot of plane z - 2.  FAST: no voxel of this plane of the tile is within 2 of a border (the
     // centred differences everywhere) AND s0 is a compile-time constant: the 19 stencil reads are ds_read_b32 with immediate offsets
     // from one address register and the slot arithmetic is gone.  Why it matters (PMC, profiles/r04_frangi_pmc_baseline.txt): the
     // kernel issued 117 scalar instructions per plane and wave against 92 vector ones -- ring-slot selects, 64-bit plane offsets, the
     // exec-mask bookkeeping of the border rules -- and the scalar unit is shared by the four SIMDs of a CU.
-    auto plane = [&](const int z, const int s0, auto fast_tag) {
-        constexpr bool FAST = decltype(fast_tag)::value;
+    // INNER: a FAST plane with at least two more planes of the march behind it -- the request for plane z + 4 and the store of plane
+    // z + 3 are unconditional, so no scalar branch stands between the loads and the wait in front of the store and the compiler can
+    // count: it waits for the older plane (vmcnt(HT_LD)) and leaves the newer one in flight.  With the conditions in place the ISA had
+    // s_waitcnt vmcnt(0) there: ONE plane in flight, not two, and the kernel sat on its memory latency.
+    auto plane = [&](const int z, const int s0, auto fast_tag, auto inner_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value, INNER = decltype(inner_tag)::value;
+        static_assert(FAST || !INNER, "");
         PlaneVals nx;
-        const bool more = z + 1 < z1;
-        if (z + 2 < z1) fetch(z + 4, nx); // lands while this plane and the next are computed
+        const bool more = INNER || z + 1 < z1;
+        if (INNER || z + 2 < z1) fetch(z + 4, nx); // lands while this plane and the next are computed
         Tile T;
 #pragma unroll
         for (int k = 0; k < 5; k++) { const int sl = s0 + k; T.pl[k] = ring[sl >= HT_RING ? sl - HT_RING : sl]; }
@@ -859,12 +907,12 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
             if (FAST || (interior_xy && z >= 2 && z + 2 < l)) {
                 // the same operations as the general path below takes for such a voxel (coordinate 2 of 5 stands for "interior"), but
                 // with the border rules resolved at compile time: 19 LDS reads instead of every variant's
-                Dzz = td2<2, 2>(T, 2, 5, 2, 5) * s2;
-                Dyy = td2<1, 1>(T, 2, 5, 2, 5) * s2;
-                Dyz = td2<1, 2>(T, 2, 5, 2, 5) * s2;
-                Dxx = td2<0, 0>(T, 2, 5, 2, 5) * s2;
-                Dxy = td2<0, 1>(T, 2, 5, 2, 5) * s2;
-                Dxz = td2<0, 2>(T, 2, 5, 2, 5) * s2;
+                Dzz = td2c<2, 2>(T, q4);
+                Dyy = td2c<1, 1>(T, q4);
+                Dyz = td2c<1, 2>(T, q4);
+                Dxx = td2c<0, 0>(T, q4);
+                Dxy = td2c<0, 1>(T, q4);
+                Dxz = td2c<0, 2>(T, q4);
             } else {
                 Dzz = td2<2, 2>(T, z, l, z, l) * s2;
                 Dyy = td2<1, 1>(T, y, h, y, h) * s2;
@@ -958,12 +1006,16 @@ __global__ __launch_bounds__(HT_THREADS) void hessian_tile(const float *__restri
     int s0 = 0; // slot of plane z - 2 = (z - z0) mod HT_RING
 #pragma unroll 1
     while (z < z1) {
-        if (interior_xy && s0 == 0 && z >= 2 && z + HT_RING + 2 <= l && z + HT_RING <= z1) {
+        if (interior_xy && s0 == 0 && z >= 2 && z + HT_RING + 2 <= l && z + HT_RING + 2 <= z1) {
 #pragma unroll
-            for (int k = 0; k < HT_RING; k++) plane(z + k, k, std::true_type{});
+            for (int k = 0; k < HT_RING; k++) plane(z + k, k, std::true_type{}, std::true_type{});
+            z += HT_RING;
+        } else if (interior_xy && s0 == 0 && z >= 2 && z + HT_RING + 2 <= l && z + HT_RING <= z1) {
+#pragma unroll
+            for (int k = 0; k < HT_RING; k++) plane(z + k, k, std::true_type{}, std::false_type{});
             z += HT_RING;
         } else {
-            plane(z, s0, std::false_type{});
+            plane(z, s0, std::false_type{}, std::false_type{});
             z++;
             s0 = s0 + 1 >= HT_RING ? 0 : s0 + 1;
         }
