@@ -850,7 +850,7 @@ const OptEntry OPTS[] = {
     {"replay_batches", &pnr::Options::replay_batches, nullptr, 0, 1}, {"batch_growth", &pnr::Options::batch_growth, nullptr, 100, 100000},
     {"batch_max", &pnr::Options::batch_max, nullptr, 1, 1 << 24}, {"no_stash", &pnr::Options::no_stash, nullptr, 0, 1},
     {"exchange_block", nullptr, &pnr::Options::exchange_block, 0, 1 << 28}, {"frangi_prune", &pnr::Options::frangi_prune, nullptr, 0, 1},
-    {"cube_copy", &pnr::Options::cube_copy, nullptr, 0, 1},
+    {"cube_copy", &pnr::Options::cube_copy, nullptr, 0, 1},      {"gauss_march", &pnr::Options::gauss_march, nullptr, 0, 1},
     {"tentative", &pnr::Options::tentative, nullptr, 0, 1},      {"target", &pnr::Options::target, nullptr, -1, 1 << 20},
     {"sums_deep", &pnr::Options::sums_deep, nullptr, -1, 1},      {"sums_deep_max", &pnr::Options::sums_deep_max, nullptr, 0, 1 << 20},
     {"lag", &pnr::Options::lag, nullptr, -1, 1023},               {"profile_every", &pnr::Options::profile_every, nullptr, 1, 1024},

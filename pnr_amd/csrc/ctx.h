@@ -83,6 +83,7 @@ struct Options {
     int no_stash = 0;         // persistent driver: in-lane two-pass sums
     int frangi_prune = 1;       // skip the eigen-solver where the response cannot reach the first non-zero J8 level (frangi.hip)
     int tentative = 1;          // streaming scheduler: pause traces that a tentative replay of everything recorded so far cuts (stream_sched.h)
+    int gauss_march = 1;        // the fused x-y Gaussian marches down strips of a slice (gauss_xy_u8_m; 0: one 64 x 64 tile per work-group)
     int cube_copy = 1;          // phased driver: the cube of a trace is fetched from the image once per step (ph_cube) and copied by its sampling work-groups (0: each stages it itself)
     int64_t exchange_block = 0; // bytes per rank and exchange of the sharded tracer; 0 = automatic (256 KB / world, at least 32 KB)
 };

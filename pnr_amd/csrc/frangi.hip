@@ -422,6 +422,144 @@ __global__ __launch_bounds__(256) void gauss_xy_u8_t(const uint8_t *__restrict__
     }
 }
 
+// The fused x-y pass MARCHING down a strip (round 5): a work-group owns 64 columns x GXM_SEG rows of one slice and walks them in
+// chunks of 64 output rows.  The x pass of a row is computed once and stays in LDS for the 2L + 1 output rows that need it (the tile
+// kernel above recomputes the 2L halo rows of every 64-row tile: (64 + 2L) / 64 of the x arithmetic, 1.56 x at L = 18), a chunk is
+// exactly two rounds of x tasks and two of y tasks for the 256 threads (the tile kernel: 3.1 rounds of x tasks), and the bytes of
+// the next chunk are requested before the current one is computed, so no wave ever waits for the image.  Same sums, same order:
+// bit-identical.  Buffer: rows [0, 2L) hold the x pass of the 2L rows above the chunk's own (carried over from the previous chunk
+// by an LDS copy), rows [2L, 2L + 64) the chunk's new rows.
+constexpr int GXM_SEG = 512;
+template <int L>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void gauss_xy_u8_m(const uint8_t *__restrict__ img, float *__restrict__ out, int w, int h, int tiles_x, int segs,
+                                                      const float *__restrict__ taps)
+{
+    static_assert(2 * L <= 64, "the carried rows fit one chunk");
+    constexpr int CH = 64;
+    constexpr int NRB = CH + 2 * L;
+    constexpr int SPAN = 64 + 2 * L;
+    constexpr int NDW = (SPAN + 6) / 4;
+    constexpr int PB = ((SPAN + 3 + 3) / 4 * 4) | 4;
+    constexpr int PX = 65;
+    constexpr int NE = CH * NDW, NIT = (NE + 255) / 256; // dwords of a chunk's new rows, per thread
+    __shared__ unsigned char s_u8[CH * PB];
+    __shared__ float s_x[NRB * PX];
+    unsigned b = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int x0 = (int)(b % (unsigned)tiles_x) * 64;
+    b /= (unsigned)tiles_x;
+    const int seg = (int)(b % (unsigned)segs);
+    const i64 z = b / (unsigned)segs;
+    const int ys = seg * GXM_SEG, ye = ys + GXM_SEG < h ? ys + GXM_SEG : h;
+    const uint8_t *plane = img + z * (i64)w * h;
+    const int tid = threadIdx.x;
+    const bool interior = x0 - L >= 0 && x0 + 64 + L + 4 <= w; // whole (unaligned) dwords of a row, no clamping in x
+    const int a = interior ? (x0 - L) & ~3 : 0, mis = interior ? (x0 - L) - a : 0;
+    typedef unsigned __attribute__((aligned(1))) u32u;
+    auto clampy = [&](int y) { return y < 0 ? 0 : (y > h - 1 ? h - 1 : y); };
+    // the NR rows from ybase on: requested into registers (interior) ...
+    auto request = [&](int ybase, unsigned (&qv)[NIT]) {
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int e = tid + 256 * i;
+            const bool on = i + 1 < NIT || e < NE;
+            const int r = (on ? e : 0) / NDW, d = (on ? e : 0) - r * NDW;
+            qv[i] = *(const u32u *)(plane + (i64)clampy(ybase + r) * w + a + 4 * d);
+        }
+    };
+    auto deposit = [&](const unsigned (&qv)[NIT]) {
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int e = tid + 256 * i;
+            if (i + 1 < NIT || e < NE) {
+                const int r = e / NDW, d = e - r * NDW;
+                *(unsigned *)(s_u8 + r * PB + 4 * d) = qv[i];
+            }
+        }
+    };
+    // ... or byte by byte with clamp-to-edge in x and y (frangi.cpp:690, :725): the tiles at the left and right border
+    auto stage_slow = [&](int ybase, int nrows) {
+        for (int e = tid; e < nrows * SPAN; e += 256) {
+            const int r = e / SPAN, cidx = e - r * SPAN;
+            int x = x0 - L + cidx;
+            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+            s_u8[r * PB + cidx] = plane[(i64)clampy(ybase + r) * w + x];
+        }
+    };
+    // x pass of rows [0, nrows) of s_u8 into rows [dst0, dst0 + nrows) of s_x; task = (row, chunk of GR outputs), lane = row
+    auto xpass = [&](int nrows, int dst0) {
+        for (int task = tid; task < nrows * (64 / GR); task += 256) {
+            const int c = task / nrows, r = task - c * nrows;
+            const unsigned char *src = s_u8 + r * PB + mis + c * GR;
+            gf32x2 acc[GR / 2];
+#pragma unroll
+            for (int m = 0; m < GR / 2; m++) acc[m] = (gf32x2){0.f, 0.f};
+            gauss_sums_packed<L>(acc, taps, [&](int q) { return (gf32x2){(float)src[2 * q], (float)src[2 * q + 1]}; });
+#pragma unroll
+            for (int j = 0; j < GR; j++) s_x[(dst0 + r) * PX + c * GR + j] = (j & 1) ? acc[j / 2].x : acc[j / 2].y;
+        }
+    };
+    unsigned qv[NIT];
+    // the 2L rows above the first chunk's own: rows ys - L .. ys + L - 1 (clamped at the top of the slice)
+    if (interior) { request(ys - L, qv); deposit(qv); }
+    else stage_slow(ys - L, 2 * L);
+    __syncthreads();
+    xpass(2 * L, 0);
+    if (interior) request(ys + L, qv);
+    const int lane = tid & 63;
+    const int x = x0 + lane;
+    for (int y0 = ys; y0 < ye; y0 += CH) {
+        __syncthreads(); // the x pass has read s_u8, the y pass of the previous chunk has read s_x
+        if (y0 > ys) { // carry the last 2L rows of the buffer to its top (source and destination are disjoint: 2L <= 64)
+            constexpr int NC = 2 * L * 64, NCI = (NC + 255) / 256;
+            float cv[NCI];
+#pragma unroll
+            for (int i = 0; i < NCI; i++) {
+                const int e = tid + 256 * i;
+                cv[i] = (i + 1 < NCI || e < NC) ? s_x[(CH + (e >> 6)) * PX + (e & 63)] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < NCI; i++) {
+                const int e = tid + 256 * i;
+                if (i + 1 < NCI || e < NC) s_x[(e >> 6) * PX + (e & 63)] = cv[i];
+            }
+        }
+        if (interior) deposit(qv);
+        else stage_slow(y0 + L, CH);
+        __syncthreads();
+        if (interior && y0 + CH < ye) request(y0 + CH + L, qv); // lands while this chunk is computed
+        xpass(CH, 2 * L);
+        __syncthreads();
+        for (int gy = tid >> 6; gy < CH / GR; gy += 4) {
+            gf32x2 acc[GR / 2];
+#pragma unroll
+            for (int m = 0; m < GR / 2; m++) acc[m] = (gf32x2){0.f, 0.f};
+            const float *col = s_x + gy * GR * PX + lane;
+            gauss_sums_packed<L>(acc, taps, [&](int q) { return (gf32x2){col[2 * q * PX], col[(2 * q + 1) * PX]}; });
+            if (x < w) {
+#pragma unroll
+                for (int j = 0; j < GR; j++) {
+                    const int y = y0 + gy * GR + j;
+                    if (y < ye) out[(z * h + y) * (i64)w + x] = (j & 1) ? acc[j / 2].x : acc[j / 2].y;
+                }
+            }
+        }
+    }
+}
+
+static bool launch_gauss_xy_m(hipStream_t st, const uint8_t *src, float *dst, int w, int h, i64 l, const float *d_taps, int L)
+{
+    const int tiles_x = (w + 63) / 64, segs = (h + GXM_SEG - 1) / GXM_SEG;
+    const i64 nblk = (i64)tiles_x * segs * l;
+    if (nblk >= 2147483647LL) return false;
+    const dim3 grid((unsigned)nblk);
+#define PNR_GXM(LL) case LL: hipLaunchKernelGGL(gauss_xy_u8_m<LL>, grid, dim3(256), 0, st, src, dst, w, h, tiles_x, segs, d_taps); return true;
+    switch (L) {
+        PNR_GXM(6) PNR_GXM(12) PNR_GXM(18)
+    default: return false;
+    }
+#undef PNR_GXM
+}
+
 static bool launch_gauss_xy_t(hipStream_t st, const uint8_t *src, float *dst, int w, int h, i64 l, const float *d_taps, int L)
 {
     const int tiles_x = (w + 63) / 64, tiles_y = (h + GXY_TY - 1) / GXY_TY;
@@ -1366,7 +1504,8 @@ static int gaussian3d(pnr_ctx *c, const std::vector<float> &gxy, const std::vect
     float *bufZ = d_out;
     c->tic();
     int nlaunch = two_d ? 1 : 2;
-    if (!launch_gauss_xy_t(c->stream, c->d_img, bufY, w, h, l, d_txy, Lxy)) { // x and y in one kernel for the usual radii; else pass by pass
+    if (!((c->opt.gauss_march && launch_gauss_xy_m(c->stream, c->d_img, bufY, w, h, l, d_txy, Lxy)) ||
+          launch_gauss_xy_t(c->stream, c->d_img, bufY, w, h, l, d_txy, Lxy))) { // x and y in one kernel for the usual radii; else pass by pass
         nlaunch++;
         if (!launch_gauss_x_t(c->stream, c->d_img, bufX, w, (i64)h * l, d_txy, Lxy)) {
             const int tiles_x = (w + GX_BLOCK - 1) / GX_BLOCK;
