@@ -871,8 +871,15 @@ __device__ __forceinline__ double vesselness(const double (&d)[3], float two_a2,
 // (HT_VY voxels per thread, rows ty, ty + 8, ... of the tile.  Two per thread -- a 64 x 16 tile, the per-plane scalar work shared by
 // twice the voxels, the x / y halo 1.33 instead of 1.59 x the tile -- was measured in round 4: 93 VGPRs instead of 62, two instead of
 // four work-groups per CU, 16.2 instead of 13.3 ms per stack.  The kernel lives on its occupancy: one voxel per thread.)
-constexpr int HT_X = 64, HT_VY = 1, HT_TY = 8, HT_Y = HT_TY * HT_VY, HT_Z = 32, HT_PX = HT_X + 4, HT_PY = HT_Y + 4, HT_PLANE = HT_PX * HT_PY, HT_THREADS = HT_X * HT_TY;
-constexpr int HT_YBITS = 3, HT_POSBITS = 6 + HT_YBITS; // queue entry: (z - z0) << HT_POSBITS | y in tile << 6 | x in tile
+#ifndef PNR_HT_TY
+#define PNR_HT_TY 8
+#define PNR_HT_YB 3
+#endif
+#ifndef PNR_HT_Z
+#define PNR_HT_Z 32
+#endif
+constexpr int HT_X = 64, HT_VY = 1, HT_TY = PNR_HT_TY, HT_Y = HT_TY * HT_VY, HT_Z = PNR_HT_Z, HT_PX = HT_X + 4, HT_PY = HT_Y + 4, HT_PLANE = HT_PX * HT_PY, HT_THREADS = HT_X * HT_TY;
+constexpr int HT_YBITS = PNR_HT_YB, HT_POSBITS = 6 + HT_YBITS; // queue entry: (z - z0) << HT_POSBITS | y in tile << 6 | x in tile
 static_assert(HT_X == 64 && (1 << HT_YBITS) == HT_Y, "the position code of a queue entry");
 constexpr int HT_LD = (HT_PLANE + HT_THREADS - 1) / HT_THREADS; // halo'd plane elements a thread fetches
 constexpr int HT_REGION = HT_X * HT_Y * HT_Z; // queue entries a work-group can produce
@@ -1366,17 +1373,24 @@ __global__ __launch_bounds__(256) void j8_kernel(const float *__restrict__ J, un
                                                   float jmin, float jmax, int flat)
 {
     const i64 stride = (i64)gridDim.x * 256 * 4;
+    auto level = [&](float v) {
+        const double r = (double)(((v - jmin) / (jmax - jmin)) * 255);
+        int val = (int)((r > 0.0) ? floor(r + 0.5) : ceil(r - 0.5));
+        return (val < 0) ? 0 : (val > 255) ? 255 : val;
+    };
+    // most of J is the exact 0 it was cleared to (no response, or one that cannot reach level 1): its level is computed once, by the same
+    // operations, and a wave whose voxels are all zeros skips the division and the f64 rounding -- the kernel is then a plain stream
+    const int level0 = flat ? 0 : level(0.f);
     for (i64 i0 = ((i64)blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
         unsigned char o[4];
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i0 + k < n) ? J[i0 + k] : 0.f;
+        const bool zeros = v[0] == 0.f && v[1] == 0.f && v[2] == 0.f && v[3] == 0.f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const i64 i = i0 + k;
-            int val = 0;
-            if (!flat && i < n) {
-                const double r = (double)(((J[i] - jmin) / (jmax - jmin)) * 255);
-                val = (int)((r > 0.0) ? floor(r + 0.5) : ceil(r - 0.5));
-                val = (val < 0) ? 0 : (val > 255) ? 255 : val;
-            }
+            int val = (i0 + k < n) ? level0 : 0;
+            if (!flat && !zeros && i0 + k < n) val = level(v[k]);
             o[k] = (unsigned char)val;
         }
         if (i0 + 3 < n && ((uintptr_t)(J8 + i0) & 3) == 0)
