@@ -932,6 +932,14 @@ struct HessQueue {
 #ifndef PNR_HT_EU
 #define PNR_HT_EU 8
 #endif
+#ifdef PNR_HT_STAMPS
+// diagnostic build only (make variant NAME=hts DEFS=-DPNR_HT_STAMPS; scripts/ht_stamps.py): shader-clock sums per wave over the INNER planes
+// of hessian_tile: [0] stencil (LDS reads + the six derivatives), [1] tests + queue, [2] the wait for the plane requested two planes
+// ago + its LDS store, [3] the barrier, [4] wave-planes counted
+__device__ unsigned long long g_ht_stamps[8];
+#define HT_STAMP_V(t, vdep) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(vdep) : "memory")
+#define HT_STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory")
+#endif
 template <bool DUMP>
 __global__ __launch_bounds__(HT_THREADS) __attribute__((amdgpu_waves_per_eu(PNR_HT_EU, 8))) void hessian_tile(const float *__restrict__ F, int w, int h, int l, int tiles_x, int tiles_y, int zc0, int zc1,
                                                            float s2, HessQueue Q, unsigned int *__restrict__ minmax, int first, int zs0, int zs1, HessOut dump,
@@ -1018,6 +1026,9 @@ __global__ __launch_bounds__(HT_THREADS) __attribute__((amdgpu_waves_per_eu(PNR_
     const bool interior_xy = x0 >= 2 && x0 + HT_X + 2 <= w && y0 >= 2 && y0 + HT_Y + 2 <= h; // block-uniform
     float *const qh = DUMP ? nullptr : Q.h + (size_t)region * 6 * HT_REGION;
     unsigned int *const qi = DUMP ? nullptr : Q.idx + (size_t)region * HT_REGION;
+#ifdef PNR_HT_STAMPS
+    unsigned long long hs0 = 0, hs1 = 0, hs2 = 0, hs3 = 0, hsn = 0;
+#endif
     bool zero_here = false;
     const double s2max = s_s2max; // (written before the barrier above)
     const float s2max_f = (float)(s2max * 0.99999);
@@ -1036,6 +1047,10 @@ __global__ __launch_bounds__(HT_THREADS) __attribute__((amdgpu_waves_per_eu(PNR_
         static_assert(FAST || !INNER, "");
         PlaneVals nx;
         const bool more = INNER || z + 1 < z1;
+#ifdef PNR_HT_STAMPS
+        unsigned long long ht0 = 0, ht1 = 0, ht2 = 0, ht3 = 0, ht4 = 0;
+        if (INNER) HT_STAMP(ht0);
+#endif
         if (INNER || z + 2 < z1) fetch(z + 4, nx); // lands while this plane and the next are computed
         Tile T;
 #pragma unroll
@@ -1066,6 +1081,9 @@ __global__ __launch_bounds__(HT_THREADS) __attribute__((amdgpu_waves_per_eu(PNR_
                 Dxy = td2<0, 1>(T, x, w, y, h) * s2;
                 Dxz = td2<0, 2>(T, x, w, z, l) * s2;
             }
+#ifdef PNR_HT_STAMPS
+            if (INNER) HT_STAMP_V(ht1, ((Dzz + Dyy) + (Dyz + Dxx)) + (Dxy + Dxz));
+#endif
             if (DUMP) {
                 const i64 i = (i64)z * wh + (i64)y * w + x;
                 dump.Dzz[i] = Dzz; dump.Dyy[i] = Dyy; dump.Dyz[i] = Dyz;
@@ -1137,12 +1155,21 @@ __global__ __launch_bounds__(HT_THREADS) __attribute__((amdgpu_waves_per_eu(PNR_
             }
         }
         } // v
+#ifdef PNR_HT_STAMPS
+        if (INNER) HT_STAMP(ht2);
+#endif
         if (more) {
             const int sl = s0 + 5; // plane z + 3 replaces plane z - 3, which nobody reads any more
             put(sl >= HT_RING ? sl - HT_RING : sl, pend);
         }
+#ifdef PNR_HT_STAMPS
+        if (INNER) HT_STAMP(ht3);
+#endif
         pend = nx;
         __syncthreads();
+#ifdef PNR_HT_STAMPS
+        if (INNER) { HT_STAMP(ht4); hs0 += ht1 - ht0; hs1 += ht2 - ht1; hs2 += ht3 - ht2; hs3 += ht4 - ht3; hsn++; }
+#endif
     };
     // the march: runs of HT_RING planes with compile-time ring slots wherever the tile and the planes are clear of every border,
     // single planes with the general rules otherwise (the first / last two planes of the stack, tiles at an x / y border, the
@@ -1165,6 +1192,12 @@ __global__ __launch_bounds__(HT_THREADS) __attribute__((amdgpu_waves_per_eu(PNR_
             s0 = s0 + 1 >= HT_RING ? 0 : s0 + 1;
         }
     }
+#ifdef PNR_HT_STAMPS
+    if ((tid & 63) == 0 && hsn) {
+        atomicAdd(&g_ht_stamps[0], hs0); atomicAdd(&g_ht_stamps[1], hs1); atomicAdd(&g_ht_stamps[2], hs2); atomicAdd(&g_ht_stamps[3], hs3);
+        atomicAdd(&g_ht_stamps[4], hsn);
+    }
+#endif
     if (DUMP) return;
     if (zero_here) s_zero = 1;
     __syncthreads();
@@ -1405,6 +1438,14 @@ __global__ __launch_bounds__(256) void j8_kernel(const float *__restrict__ J, un
 // ========================================================================================
 // host side
 // ========================================================================================
+#ifdef PNR_HT_STAMPS
+extern "C" int pnr_debug_ht_stamps(unsigned long long *out8, int reset)
+{
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ht_stamps), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ht_stamps), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 int pnr_ensure_frangi_buffers(pnr_ctx *c)
 {
     if (c->frangi_cap >= c->N && c->d_J) return PNR_OK;
