@@ -453,7 +453,7 @@ def main():
             "roofline_sample": kernel_block("smc", bytes_total, "the gather half alone: the evaluation's algorithmic gather bytes over the sampling kernel's own launch time (served from the LDS cube: VALU / LDS bound, not HBM)"),
             "roofline_sums": None if a.driver != "phased" else kernel_block("smc_sums", stash_bytes, "ordered sums alone against their REAL stash bytes: every stashed f32 sample is streamed twice (mean, then corr), 2 x 4 x sum(M) x %d B per SMC iteration -- an upper bound, exact duplicate poses are evaluated once" % stash_row_floats(a.np)),
             "roofline_frangi": None if not fr_vox or fr_ms <= 0 else {
-                "kernels": "gauss_x_u8_t+gauss_axis_t(y,z)+hessian_tile+eigen_queue+j8", "bound": "hbm", "achieved": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9,
+                "kernels": "gauss_xy_u8_m(x,y)+gauss_axis_t(z)+hessian_tile+eigen_queue+j8", "bound": "hbm", "achieved": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (len(sigs) + 12) * fr_vox / (fr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "device_ms_per_step": fr_ms,
                 "note": "(S+12) B/voxel compulsory bytes over the Frangi kernel group; VALU-bound: three Gaussian passes with separate multiply and add (the reference's rounding) and the Hessian stencil with its zero-response tests; the fp64 JAMA eigen-solver runs only where the response can reach J8 > 0"},
             "stages_ms": {k: v for k, v in st.items() if k.endswith("_ms")},

@@ -42,6 +42,26 @@ def test_gaussian_row_ends_on_exactly_sized_device_buffer(oracle, w, sig):
     c.close()
 
 
+@pytest.mark.parametrize("sig", [2.0, 4.0, 6.0])
+def test_gaussian_marching_xy_pass(oracle, sig):
+    """gauss_xy_u8_m (the fused x-y pass marching down strips of 512 rows in chunks of 64) on a stack whose slices hold a second,
+    partly filled strip (600 rows), an interior tile between two border tiles (150 columns at L = 6: x0 = 64) and a last chunk
+    of 24 rows: F equals the oracle's and the tile kernel's (option gauss_march = 0), bit for bit"""
+    w, h, l = 150, 600, 3
+    img = synth.synth(w, h, l, seed=21)
+    want = np.empty(img.shape, np.float32)
+    oracle.orc_imgaussian3d(img, w, h, l, sig, 2.0, want)
+    got = []
+    for march in (1, 0):
+        c = ctx_for([sig], 2.0)
+        c.set_option("gauss_march", march)
+        c.set_volume(img)
+        got.append(c.gaussian(sig))
+        c.close()
+    assert np.array_equal(got[0], want)
+    assert np.array_equal(got[1], want)
+
+
 def test_device_eigen_solver_on_reference_kats():
     """Frangi::eigen_decomposition (frangi.cpp:1269-1493: tred2, tql2, the |lambda| re-sort) as compiled for the DEVICE, fed the 512
     known-answer matrices the reference itself produced (tests/golden/eigen_kat.npz: zero, diagonal, repeated and near-repeated
