@@ -886,6 +886,14 @@ __global__ __launch_bounds__(256) void ph_update(Vol V, Tab T, PhState P, int np
 #endif
 }
 
+// the state the host reads after a poll (the step lists' counters and the flags of all slots: contiguous in P.cnt) into its pinned
+// snapshot
+__global__ __launch_bounds__(256) void ph_snapshot(const int4 *__restrict__ src, int4 *__restrict__ dst, int n4)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) dst[i] = src[i];
+}
+
 // streaming mode: hand `m` free slots to new traces and append them to the list of this step (one work-group, runs
 // alone in stream order between two steps)
 __global__ __launch_bounds__(256) void ph_admit(PhState P, float *__restrict__ s6, const int *__restrict__ new_slots,
@@ -1489,7 +1497,7 @@ struct PhasedEngine final : pnr::StreamEngine {
     int admit(int g, const int *slots, const float *s6, int m) override
     {
         Grp &q = grp[g];
-        PE_HIP(hipEventSynchronize(h->ev_adm[g]));      // pinned staging of this group: its previous admission has been consumed
+        PE_HIP(hipEventSynchronize(h->ev_ctl[g]));      // pinned staging of this group: its previous admission has been consumed (one event per ph_poll: flush())
         std::memcpy(q.h_new, slots, (size_t)m * 4);     // (normally long ago: a wait() lies between two admissions unless the group
         std::memcpy(q.h_new_s6, s6, (size_t)m * 24);    // had nothing to step)
         q.p_m = m; // (flush(): the kernel reads the pinned staging itself -- a few hundred bytes over the bus, no copies in front of it)
@@ -1513,7 +1521,7 @@ struct PhasedEngine final : pnr::StreamEngine {
     {
         if (g >= ngroups) { msg = "trace group beyond the stash regions"; return PNR_E_STATE; }
         if (active > gcap) { const int rc = grow_stash(active); if (rc) return rc; }
-        { const int rc = flush(g); if (rc) return rc; }
+        { const int rc = flush(g, /*followed_by_steps*/ true); if (rc) return rc; }
         Grp &q = grp[g];
         hipStream_t st = q.st;
         const PhState &P = q.P;
@@ -1553,7 +1561,12 @@ struct PhasedEngine final : pnr::StreamEngine {
             if (k == poll - 1 - lag) { // what wait() hands to the host: the state behind this step (the last `lag` steps run on meanwhile)
                 // one copy: the counters of all step lists and the flags of all slots (every copy is a dispatch of its own in the stream,
                 // ~10 us each on the chain of this group's steps)
-                PE_HIP(hipMemcpyAsync(q.h_snap, E.P.cnt, ((size_t)NT * FL_N + 2 * pnr_phased::MAXG) * 4, hipMemcpyDeviceToHost, st));
+                // (a kernel of our own that stores to the pinned snapshot, not hipMemcpyAsync: the runtime's copy is a blit dispatch between
+                // two barrier packets -- 12 us before it and 6.5 us behind it on the chain of this group's steps, per poll; this is 2 us)
+                {
+                    const int n4 = (int)(((size_t)NT * FL_N + 2 * pnr_phased::MAXG) / 4);
+                    hipLaunchKernelGGL(ph_snapshot, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const int4 *)E.P.cnt, (int4 *)q.h_snap, n4);
+                }
                 q.h_cnt = q.h_snap + 2 * g + q.lp; // the list of the step that follows
                 PE_HIP(hipEventRecord(q.ev_state, st));
             }
@@ -1563,7 +1576,7 @@ struct PhasedEngine final : pnr::StreamEngine {
     void idle(int g) override { grp[g].running = 0; }
     int wait(int g, int *active) override
     {
-        PE_HIP(hipEventSynchronize(grp[g].ev_state)); // (the steps queued behind the state copy may still be running)
+        PE_HIP(hipEventSynchronize(grp[g].ev_state)); // (the steps queued behind the snapshot may still be running; polling the event instead of sleeping on it changes nothing: A/B)
         PE_HIP(hipGetLastError());
         *active = grp[g].h_cnt[0];
         grp[g].running = *active;
@@ -1593,7 +1606,7 @@ struct PhasedEngine final : pnr::StreamEngine {
         return PNR_OK;
     }
     // one dispatch for what control() / density_update() / admit() of this turn asked for, in that order
-    int flush(int g)
+    int flush(int g, bool followed_by_steps = false)
     {
         Grp &q = grp[g];
         if (!q.p_ctl && q.p_m == 0 && q.p_nt == 0) return PNR_OK;
@@ -1602,9 +1615,12 @@ struct PhasedEngine final : pnr::StreamEngine {
                            (const int *)(hc + h->stream_cap), q.p_nr, (const int *)q.h_new, (const float *)q.h_new_s6, q.p_m, q.lp, E.ni, c->d_den,
                            (const i64 *)h->h_den_idx[g], (const unsigned char *)h->h_den_val[g], (int)q.p_nt);
         PE_HIP(hipGetLastError());
-        if (q.p_ctl) PE_HIP(hipEventRecord(h->ev_ctl[g], q.st));
-        if (q.p_m > 0) PE_HIP(hipEventRecord(h->ev_adm[g], q.st));
-        if (q.p_nt > 0) PE_HIP(hipEventRecord(h->ev_den[g], q.st));
+        // The three pinned staging areas the dispatch reads (control lists, admissions, density cells) are rewritten in the group's next
+        // turn at the earliest.  Where steps follow in this turn, that turn begins with wait(g) on a state snapshot queued BEHIND this
+        // dispatch: it has run by then, and no event is needed (every hipEventRecord is a packet of its own, ~5 us on the chain of the
+        // group's steps; there were up to three per poll).  Only a dispatch with nothing behind it (end_turn / settle of a group with
+        // nothing to step) is followed by ONE event, which the three waits share.
+        if (!followed_by_steps) PE_HIP(hipEventRecord(h->ev_ctl[g], q.st));
         q.p_ctl = false; q.p_np = q.p_nr = q.p_m = 0; q.p_nt = 0;
         return PNR_OK;
     }
@@ -1638,7 +1654,7 @@ struct PhasedEngine final : pnr::StreamEngine {
             PE_HIP(hipMalloc(&h->d_den_val[g], cap));
             h->den_cap[g] = cap;
         }
-        PE_HIP(hipEventSynchronize(h->ev_den[g])); // the previous update's copies have left the pinned staging
+        PE_HIP(hipEventSynchronize(h->ev_ctl[g])); // the previous update's cells have been read from the pinned staging (one event per ph_poll: flush())
         for (size_t i = 0; i < nt; i++) {
             h->h_den_idx[g][i] = r.touched[i];
             h->h_den_val[g][i] = (unsigned char)r.den_at(r.touched[i]); // final value: duplicates agree
