@@ -14,10 +14,9 @@ SRC = os.path.join(ROOT, "pnr_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-w"]
 
 
-@pytest.fixture(scope="module")
-def compiled(tmp_path_factory):
-    out = str(tmp_path_factory.mktemp("isa") / "smc_phased.s")
-    r = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-S", "--cuda-device-only", "smc_phased.hip", "-o", out],
+def compile_isa(tmp_path_factory, source):
+    out = str(tmp_path_factory.mktemp("isa") / (source + ".s"))
+    r = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-S", "--cuda-device-only", source, "-o", out],
                        cwd=SRC, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     usage, name = {}, None
@@ -31,6 +30,16 @@ def compiled(tmp_path_factory):
         if m and name:
             usage[name][m.group(1).split(" ")[0]] = int(m.group(2))
     return usage, open(out).read().splitlines()
+
+
+@pytest.fixture(scope="module")
+def compiled(tmp_path_factory):
+    return compile_isa(tmp_path_factory, "smc_phased.hip")
+
+
+@pytest.fixture(scope="module")
+def compiled_frangi(tmp_path_factory):
+    return compile_isa(tmp_path_factory, "frangi.hip")
 
 
 def find(usage, frag):
@@ -72,3 +81,41 @@ def test_ph_sample_scratch_stays_outside_the_sample_loops(compiled):
     # depth 1 = the loop over work items (one item = five template rows x 64 chains = 65 / 125 samples per lane); the row loop is
     # depth 2 and the five-sample groups depth 3: a spill there would be paid per sample
     assert worst <= 1, f"{n} scratch accesses, deepest at loop depth {worst}"
+
+
+def kernel_body(usage, asm, frag):
+    _, name = find(usage, frag)
+    start = next(i for i, ln in enumerate(asm) if ln.startswith(name + ":"))
+    end = next(i for i in range(start, len(asm)) if asm[i].startswith(".Lfunc_end"))
+    return asm[start:end]
+
+
+def test_frangi_kernels_keep_their_loads_in_flight(compiled_frangi):
+    """What round 5 found by reading the ISA and what must stay so: hessian_tile at eight waves per SIMD whose wait in front of the ring
+    store of an inner plane leaves the newer plane in flight (vmcnt(2) / vmcnt(3), it was vmcnt(0)), with its few spilled dwords
+    outside the runs of inner planes; the marching x-y Gaussian without scratch at four waves per SIMD, all of a chunk's loads issued back to back."""
+    usage, asm = compiled_frangi
+    ht, _ = find(usage, "hessian_tileILb0EE")
+    assert ht["VGPRs"] <= 64 and ht["Occupancy"] == 8 and ht["ScratchSize"] <= 32, ht
+    body = kernel_body(usage, asm, "hessian_tileILb0EE")
+    depth, inner = 0, []
+    for i, ln in enumerate(body):  # the waits in front of the ring stores of the inner planes: inside the march (loop depth >= 1)
+        if ln.startswith(".LBB"):
+            m = re.search(r"Depth=(\d+)", ln)
+            depth = int(m.group(1)) if m else 0
+        elif depth >= 1 and re.search(r"s_waitcnt vmcnt\((2|3)\)", ln):
+            inner.append(i)
+    assert len(inner) >= 8, len(inner)  # (a run of six planes, less its last two, in two instantiations: the newer plane stays in flight)
+    spills = [i for i, ln in enumerate(body) if "scratch_" in ln]
+    assert not [i for i in spills if inner[0] <= i <= inner[-1]], "scratch access inside the runs of inner planes of hessian_tile"
+    for L in (6, 12, 18):
+        u, _ = find(usage, f"gauss_xy_u8_mILi{L}E")
+        assert u["ScratchSize"] == 0 and u["VGPRs"] <= 128 and u["Occupancy"] >= 4, (L, u)
+        body = kernel_body(usage, asm, f"gauss_xy_u8_mILi{L}E")
+        run = best = 0
+        for ln in body:  # the longest run of global loads with no wait between them
+            if "global_load_dword" in ln:
+                run += 1; best = max(best, run)
+            elif "s_waitcnt vmcnt" in ln:
+                run = 0
+        assert best >= 4, (L, best)
