@@ -269,6 +269,7 @@ int pnr_set_smc_driver(pnr_ctx *ctx, int driver);
  *   of the streaming window | no_stash (0/1) persistent driver without the sample stash | exchange_block (0 = 256 KB / world) bytes per rank
  *   and exchange of pnr_trace_replay_sharded | frangi_prune (1) skip the eigen-solver below the first J8 level (pnr_get_frangi) |
  *   cube_copy (1) phased driver: a trace's cube is fetched from the image once per step and copied by its sampling work-groups (0: each stages it itself) |
+ *   gauss_march (1) the fused x-y Gaussian marches down strips of a slice (0: one 64 x 64 tile per work-group; the same bits) |
  *   tentative (1) the streaming scheduler pauses traces that a tentative replay of everything recorded so far cuts, and ends them
  *   itself once that verdict is final (fewer wasted SMC iterations; same graph).
  *   pnr_get_option also knows "host_threads_effective" and "frangi_recomputes" (how often pnr_get_frangi / pnr_quantise_j8 had to
